@@ -1,0 +1,179 @@
+/*
+ * slhip.h -- C ABI of libslhip.so, the MI355X (gfx950) scene-synthesis hot path.
+ *
+ * This is the drop-in boundary for the path stillleben implements with
+ *   - PhysX  : Scene::simulateTableTopScene / Scene::simulate / Scene::checkCollisions /
+ *              ManipulationSim::step       (reference src/scene.cpp:612-759, :903-925,
+ *                                           src/manipulation_sim.cpp:83-93)
+ *   - OpenGL : RenderPass::render           (reference src/render_pass.cpp:303-796 and
+ *                                           src/shaders/render_shader.{vert,geom,frag})
+ *   - CUDA   : generateSobelValidMask / dilateObjectMask (reference python/src/diff.cu,
+ *              python/src/bridge_diff.cpp:13-157) and the pose backward of
+ *              python/stillleben/diff.py:355-523
+ *
+ * Conventions
+ *   - plain C, no exceptions, no torch types.  Every function returns 0 on success and a
+ *     negative code on failure; slhip_last_error() returns a thread-local message.
+ *   - every pointer named d_* is a DEVICE pointer into caller-owned memory (the Python host
+ *     allocates it with torch); h_* are host pointers.  Nothing is allocated behind the
+ *     caller's back except the opaque handles created by *_create.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All launches are
+ *     asynchronous on that stream; nothing synchronises unless documented.
+ *   - matrices are ROW-major float[16] (m[4*r+c]); the reference's Magnum matrices are
+ *     column-major and its Python boundary transposes them (python/src/py_magnum.h:55-69),
+ *     so row-major here == the tensors the reference's Python API hands out.
+ *   - all structs are PODs with explicit sizes; arrays of structs are tightly packed.
+ */
+#ifndef SLHIP_H
+#define SLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLHIP_ABI_VERSION 1
+#define SLHIP_NUM_LIGHTS 3 /* reference include/stillleben/common.h:17 */
+
+/* ---------------------------------------------------------------------------------------------
+ * Render half
+ * ------------------------------------------------------------------------------------------- */
+
+/* Mesh pool: structure-of-arrays vertex storage shared by every scene of a batch.
+ * Replaces the 68-byte interleaved GL vertex buffer of consolidateMesh
+ * (reference src/mesh_tools/consolidate.cpp:53-61).  The 1-based `vertexIndex` attribute of
+ * the reference (consolidate.cpp:335) is implicit: vertexIndex = (vertex - vtx_base) + 1.   */
+typedef struct {
+    const float* d_pos;   /* float4[V]  x y z 1                                   */
+    const float* d_nrm;   /* float4[V]  nx ny nz 0                                */
+    const float* d_uv;    /* float2[V]                                            */
+    const float* d_col;   /* float4[V]  vertex colour (default 1,1,1,1)            */
+    const uint32_t* d_idx;/* u32[3T]    indices relative to the draw's vtx_base   */
+    const uint8_t* d_tex; /* RGBA8 texel pool (all base-colour textures, mip 0)   */
+    uint64_t n_vertices;
+    uint64_t n_indices;
+    uint64_t n_tex_bytes;
+} slhip_mesh_pool;
+
+/* draw flags */
+#define SLHIP_DRAW_HAS_BASE_TEX   1u  /* base colour texture bound (render_shader.cpp:430-433)   */
+#define SLHIP_DRAW_VERTEX_COLORS  2u  /* multiply base colour by vertex colour                   */
+#define SLHIP_DRAW_CASTS_SHADOW   4u  /* Object::castsShadows (render_pass.cpp:437)              */
+#define SLHIP_DRAW_ALPHA_TEST     8u  /* texture has an alpha channel: cut-off in the z pass     */
+#define SLHIP_DRAW_NO_VERTEX_ID  16u  /* mesh without the vertexIndex attribute (the background
+                                         plane): vertex ids read 0 (render_pass.cpp:573-581)     */
+
+/* One drawable (sub-mesh of an object, or the background plane) of one scene.
+ * Carries what RenderShader::setTransformations / setMaterial / setClassIndex /
+ * setInstanceIndex upload as uniforms (reference src/shaders/render_shader.cpp:233-265,
+ * :326-417) -- normal matrices and camera position are derived on the host exactly there.   */
+typedef struct {
+    float mesh_to_object[16];
+    float object_to_world[16];
+    float normal_to_world[12];   /* 3x3 row-major, rows padded to 4 floats */
+    float base_color[4];
+    float emissive[4];
+    float alpha_cutoff, metallic, roughness, _pad0;
+    uint32_t class_index, instance_index, flags, _pad1;
+    uint32_t vtx_base;           /* first vertex in the pool                          */
+    uint32_t idx_base;           /* first index in the pool                           */
+    uint32_t n_tris;
+    uint32_t prim_base;          /* id of triangle 0 in the scene's draw order        */
+    uint32_t tex_offset;         /* byte offset of the RGBA8 base-colour texture      */
+    uint32_t tex_w, tex_h, _pad2;
+} slhip_draw;                    /* 272 bytes */
+
+/* Per-scene camera + lights (reference Scene::setCameraIntrinsics src/scene.cpp:222-253,
+ * RenderShader::setManualLighting render_shader.cpp:298-316).                               */
+typedef struct {
+    float proj[16];
+    float world_to_cam[16];
+    float cam_position[4];
+    float light_dir[SLHIP_NUM_LIGHTS][4];    /* world frame; zero = inactive          */
+    float light_color[SLHIP_NUM_LIGHTS][4];
+    float shadow_mat[SLHIP_NUM_LIGHTS][16];  /* world -> light clip (render_pass.cpp:131-211) */
+    float ambient[4];
+    float manual_exposure;                   /* <0: auto exposure (tone_map_shader.frag:110) */
+    uint32_t draw_begin, draw_end;           /* range in the draw array               */
+    uint32_t n_prims;                        /* total triangles of the scene          */
+} slhip_scene;                               /* 464 bytes */
+
+/* A unit of raster work: `count` consecutive triangles of one draw (<= SLHIP_CHUNK_TRIS).
+ * Built on the host when the draw list is assembled so that every workgroup has a
+ * wave-uniform scene and draw (matrices live in SGPRs).                                    */
+#define SLHIP_CHUNK_TRIS 256
+typedef struct {
+    uint32_t scene, draw, first_tri, count;
+} slhip_chunk;
+
+/* output selection mask for slhip_render */
+#define SLHIP_OUT_RGB        0x01u
+#define SLHIP_OUT_COORD      0x02u   /* objectCoordinates xyz + camera z in w               */
+#define SLHIP_OUT_CLASS      0x04u
+#define SLHIP_OUT_INSTANCE   0x08u
+#define SLHIP_OUT_NORMALS    0x10u
+#define SLHIP_OUT_VERTEX_IDX 0x20u
+#define SLHIP_OUT_BARY       0x40u
+#define SLHIP_OUT_CAM_COORD  0x80u
+#define SLHIP_OUT_ALL        0xFFu
+#define SLHIP_OUT_GT6        0x1Fu   /* BASELINE "6-channel GT": rgb, coord+depth, class, instance, normals */
+
+#define SLHIP_RENDER_SSAO     0x100u /* RenderPass::ssaoEnabled (render_pass.h:150)          */
+#define SLHIP_RENDER_SHADOWS  0x200u /* shadow pass + PCF (render_pass.cpp:408-460)          */
+
+/* Result buffers, batch-major [B][H][W][C] -- the 8 colour attachments of
+ * RenderPass::Result (reference include/stillleben/render_pass.h:48-78, formats
+ * src/render_pass.cpp:347-365).  A NULL pointer == output not wanted.                       */
+typedef struct {
+    uint8_t*  d_rgb;          /* u8  [B,H,W,4]   tone-mapped, linear (tone_map_shader.frag:129-130) */
+    float*    d_coord;        /* f32 [B,H,W,4]   object xyz, camera z                        */
+    uint16_t* d_class;        /* u16 [B,H,W]                                                 */
+    uint16_t* d_instance;     /* u16 [B,H,W]                                                 */
+    float*    d_normals;      /* f32 [B,H,W,4]   camera-frame normal, w = n.v                */
+    uint32_t* d_vertex_idx;   /* u32 [B,H,W,4]   1-based ids, 4th = 0                        */
+    float*    d_bary;         /* f32 [B,H,W,4]   4th = 0                                     */
+    float*    d_cam_coord;    /* f32 [B,H,W,4]   camera xyz, 1                               */
+} slhip_render_out;
+
+/* Scratch the caller provides (sizes from slhip_render_scratch_bytes).                      */
+typedef struct {
+    uint64_t* d_vis;          /* u64 [B,H,W] visibility keys (depth24<<32 | prim id)         */
+    float*    d_hdr;          /* f32 [B,H,W,4] HDR colour (ssaoRGBInput / postprocessInput)  */
+    float*    d_ao;           /* f32 [B,H,W]                                                 */
+    float*    d_shadow;       /* f32 [B,NUM_LIGHTS,S,S] shadow depth (only active lights)    */
+    uint32_t* d_queue;        /* large-triangle work queue: [0]=count, then (prim,tile) pairs */
+    float*    d_lum;          /* f32 [B,4] HDR sums for auto exposure                        */
+    uint32_t  queue_capacity; /* number of (prim,tile) pairs that fit                        */
+    uint32_t  shadow_res;     /* S (reference: 2048, render_pass.cpp:271)                    */
+} slhip_render_scratch;
+
+/* Renders a batch of scenes.  Replaces RenderPass::render (src/render_pass.cpp:303-796):
+ * shadow pass, main G-buffer pass, SSAO, tone map.  d_depth_peel (f32 [B,H,W,4], the
+ * previous result's objectCoordinates; NULL = none) implements `depthBufferResult`.         */
+int slhip_render(const slhip_mesh_pool* pool,
+                 const slhip_scene* d_scenes, const slhip_draw* d_draws,
+                 const slhip_chunk* d_chunks, uint32_t n_scenes, uint32_t n_chunks,
+                 uint32_t width, uint32_t height, uint32_t flags,
+                 const float* d_depth_peel,
+                 const slhip_render_out* out, const slhip_render_scratch* scratch,
+                 void* stream);
+
+/* Bytes of each scratch buffer for a batch (host helper, no GPU needed).                    */
+int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uint32_t height,
+                               uint32_t shadow_res, uint32_t queue_capacity,
+                               uint64_t bytes_out[6]);
+
+/* ---------------------------------------------------------------------------------------------
+ * Library
+ * ------------------------------------------------------------------------------------------- */
+int slhip_abi_version(void);
+const char* slhip_last_error(void);
+/* hipSetDevice + sanity check that the device is gfx950.  Replaces Context::CreateCUDA's
+ * device selection (reference src/context.cpp:411-560).                                      */
+int slhip_device_init(int device_index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLHIP_H */

@@ -1,0 +1,85 @@
+"""ORACLE -- test infrastructure only.
+
+CPU restatements of the reference's hot path (oracle/*.c -> oracle/libslref.so).  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package; the
+product package (stillleben_amd) never does."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libslref.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    srcs.append(os.path.join(_HERE, "..", "include", "slhip.h"))
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libslref.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+class RenderResult:
+    pass
+
+
+def render(pool_arrays, srec, drec, W, H, flags, depth_peel=None, shadow_res=2048, want_hdr=False,
+           want_shadow=False):
+    """Runs the CPU reference renderer on the binary scene description produced by
+    stillleben_amd._batch.build_batch.  Returns numpy arrays shaped like the device buffers."""
+    from stillleben_amd import _abi
+
+    L = lib()
+    pos, nrm, uv, col, idx, tex = [np.ascontiguousarray(a) for a in pool_arrays]
+    pool = _abi.MeshPool()
+    pool.d_pos, pool.d_nrm, pool.d_uv, pool.d_col, pool.d_idx, pool.d_tex = (_p(a) for a in (pos, nrm, uv, col, idx, tex))
+    pool.n_vertices, pool.n_indices, pool.n_tex_bytes = len(pos), len(idx), tex.size
+    B = len(srec)
+    r = RenderResult()
+    r.rgb = np.zeros((B, H, W, 4), np.uint8)
+    r.coord = np.zeros((B, H, W, 4), np.float32)
+    r.cls = np.zeros((B, H, W, 1), np.uint16)
+    r.instance = np.zeros((B, H, W, 1), np.uint16)
+    r.normals = np.zeros((B, H, W, 4), np.float32)
+    r.vertex_idx = np.zeros((B, H, W, 4), np.uint32)
+    r.bary = np.zeros((B, H, W, 4), np.float32)
+    r.cam_coord = np.zeros((B, H, W, 4), np.float32)
+    r.hdr = np.zeros((B, H, W, 4), np.float32) if want_hdr else None
+    r.shadow = np.zeros((B, 3, shadow_res, shadow_res), np.float32) if want_shadow else None
+    out = _abi.RenderOut()
+    out.d_rgb, out.d_coord, out.d_class, out.d_instance = _p(r.rgb), _p(r.coord), _p(r.cls), _p(r.instance)
+    out.d_normals, out.d_vertex_idx, out.d_bary, out.d_cam_coord = _p(r.normals), _p(r.vertex_idx), _p(r.bary), _p(r.cam_coord)
+    srec = np.ascontiguousarray(srec)
+    drec = np.ascontiguousarray(drec)
+    L.slref_render.argtypes = [C.POINTER(_abi.MeshPool), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                               C.c_uint32, C.c_void_p, C.POINTER(_abi.RenderOut), C.c_uint32, C.c_void_p, C.c_void_p]
+    st = L.slref_render(C.byref(pool), _p(srec), _p(drec), B, W, H, flags, _p(depth_peel), C.byref(out), shadow_res,
+                        _p(r.hdr), _p(r.shadow))
+    if st != 0:
+        raise RuntimeError("slref_render failed: %d" % st)
+    return r
+
+
+def ssao_tables():
+    L = lib()
+    noise = np.zeros(48, np.float32)
+    kern = np.zeros(192, np.float32)
+    L.slref_ssao_tables(_p(noise), _p(kern))
+    return noise, kern

@@ -1,0 +1,168 @@
+"""ctypes mirror of include/slhip.h and loader of the C-ABI library ``lib/libslhip.so``.
+
+The product path has NO fallback: if the library is missing or no gfx950 device is present the
+calls raise (see :func:`lib`).  The struct definitions are also used by the tests to drive the
+CPU oracle (``oracle/libslref.so``) with the very same binary scene description.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+NUM_LIGHTS = 3
+CHUNK_TRIS = 256
+
+DRAW_HAS_BASE_TEX = 1
+DRAW_VERTEX_COLORS = 2
+DRAW_CASTS_SHADOW = 4
+DRAW_ALPHA_TEST = 8
+DRAW_NO_VERTEX_ID = 16
+
+OUT_RGB = 0x01
+OUT_COORD = 0x02
+OUT_CLASS = 0x04
+OUT_INSTANCE = 0x08
+OUT_NORMALS = 0x10
+OUT_VERTEX_IDX = 0x20
+OUT_BARY = 0x40
+OUT_CAM_COORD = 0x80
+OUT_ALL = 0xFF
+OUT_GT6 = 0x1F
+RENDER_SSAO = 0x100
+RENDER_SHADOWS = 0x200
+
+
+class MeshPool(C.Structure):
+    _fields_ = [
+        ("d_pos", C.c_void_p),
+        ("d_nrm", C.c_void_p),
+        ("d_uv", C.c_void_p),
+        ("d_col", C.c_void_p),
+        ("d_idx", C.c_void_p),
+        ("d_tex", C.c_void_p),
+        ("n_vertices", C.c_uint64),
+        ("n_indices", C.c_uint64),
+        ("n_tex_bytes", C.c_uint64),
+    ]
+
+
+# numpy dtypes with the exact layout of slhip_draw / slhip_scene / slhip_chunk
+DRAW_DTYPE = np.dtype(
+    [
+        ("mesh_to_object", np.float32, (16,)),
+        ("object_to_world", np.float32, (16,)),
+        ("normal_to_world", np.float32, (12,)),
+        ("base_color", np.float32, (4,)),
+        ("emissive", np.float32, (4,)),
+        ("alpha_cutoff", np.float32),
+        ("metallic", np.float32),
+        ("roughness", np.float32),
+        ("_pad0", np.float32),
+        ("class_index", np.uint32),
+        ("instance_index", np.uint32),
+        ("flags", np.uint32),
+        ("_pad1", np.uint32),
+        ("vtx_base", np.uint32),
+        ("idx_base", np.uint32),
+        ("n_tris", np.uint32),
+        ("prim_base", np.uint32),
+        ("tex_offset", np.uint32),
+        ("tex_w", np.uint32),
+        ("tex_h", np.uint32),
+        ("_pad2", np.uint32),
+    ],
+    align=False,
+)
+assert DRAW_DTYPE.itemsize == 272, DRAW_DTYPE.itemsize
+
+SCENE_DTYPE = np.dtype(
+    [
+        ("proj", np.float32, (16,)),
+        ("world_to_cam", np.float32, (16,)),
+        ("cam_position", np.float32, (4,)),
+        ("light_dir", np.float32, (NUM_LIGHTS, 4)),
+        ("light_color", np.float32, (NUM_LIGHTS, 4)),
+        ("shadow_mat", np.float32, (NUM_LIGHTS, 16)),
+        ("ambient", np.float32, (4,)),
+        ("manual_exposure", np.float32),
+        ("draw_begin", np.uint32),
+        ("draw_end", np.uint32),
+        ("n_prims", np.uint32),
+    ],
+    align=False,
+)
+assert SCENE_DTYPE.itemsize == 464, SCENE_DTYPE.itemsize
+
+CHUNK_DTYPE = np.dtype(
+    [("scene", np.uint32), ("draw", np.uint32), ("first_tri", np.uint32), ("count", np.uint32)]
+)
+
+
+class RenderOut(C.Structure):
+    _fields_ = [
+        ("d_rgb", C.c_void_p),
+        ("d_coord", C.c_void_p),
+        ("d_class", C.c_void_p),
+        ("d_instance", C.c_void_p),
+        ("d_normals", C.c_void_p),
+        ("d_vertex_idx", C.c_void_p),
+        ("d_bary", C.c_void_p),
+        ("d_cam_coord", C.c_void_p),
+    ]
+
+
+class RenderScratch(C.Structure):
+    _fields_ = [
+        ("d_vis", C.c_void_p),
+        ("d_hdr", C.c_void_p),
+        ("d_ao", C.c_void_p),
+        ("d_shadow", C.c_void_p),
+        ("d_queue", C.c_void_p),
+        ("d_lum", C.c_void_p),
+        ("queue_capacity", C.c_uint32),
+        ("shadow_res", C.c_uint32),
+    ]
+
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libslhip.so")
+
+
+class SlhipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Loads lib/libslhip.so (built by ``__graft_entry__.build()``); raises if absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise SlhipError(
+            "stillleben_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (there is no CPU fallback)" % _LIB_PATH
+        )
+    L = C.CDLL(_LIB_PATH)
+    L.slhip_abi_version.restype = C.c_int
+    L.slhip_last_error.restype = C.c_char_p
+    L.slhip_device_init.argtypes = [C.c_int]
+    L.slhip_render.argtypes = [
+        C.POINTER(MeshPool), C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+        C.c_void_p, C.POINTER(RenderOut), C.POINTER(RenderScratch), C.c_void_p,
+    ]
+    L.slhip_render_scratch_bytes.argtypes = [
+        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64 * 6)
+    ]
+    _LIB = L
+    return L
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().slhip_last_error()
+        raise SlhipError("%s failed (%d): %s" % (what, status, msg.decode() if msg else "?"))

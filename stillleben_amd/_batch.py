@@ -1,0 +1,210 @@
+"""Host-side assembly of the binary scene description consumed by slhip_render (and, in the
+tests, by the CPU oracle): mesh pool, per-scene camera/lights, draw list, raster chunks.
+
+Mirrors what RenderPass::render uploads as uniforms per drawable
+(reference src/render_pass.cpp:534-621, src/shaders/render_shader.cpp:233-265, :326-417)."""
+import numpy as np
+
+from . import _abi
+from . import _math as M
+from ._math import f32
+
+
+class PoolSlot:
+    __slots__ = ("vtx_base", "idx_base", "tex_offsets", "tex_sizes", "tex_alpha", "version", "n_vertices", "n_indices")
+
+
+class HostPool:
+    """Growing structure-of-arrays mesh pool (host copy).  Slot 0 is the background plane of
+    the reference (Primitives::planeSolid as a 2-triangle strip, render_pass.cpp:262,581)."""
+
+    def __init__(self):
+        self.pos = [np.array([[1, -1, 0, 1], [1, 1, 0, 1], [-1, -1, 0, 1], [-1, 1, 0, 1]], np.float32)]
+        self.nrm = [np.array([[0, 0, 1, 0]] * 4, np.float32)]
+        self.uv = [np.array([[1, 0], [1, 1], [0, 0], [0, 1]], np.float32)]
+        self.col = [np.ones((4, 4), np.float32)]
+        self.idx = [np.array([0, 1, 2, 2, 1, 3], np.uint32)]
+        self.tex = []
+        self.n_vertices = 4
+        self.n_indices = 6
+        self.n_tex_bytes = 0
+        self.dirty = True
+        self._textures = {}  # id(array) -> (offset, w, h)
+
+    def add_texture(self, rgba):
+        key = id(rgba)
+        if key in self._textures:
+            return self._textures[key]
+        off = self.n_tex_bytes
+        a = np.ascontiguousarray(rgba, dtype=np.uint8)
+        self.tex.append(a.reshape(-1))
+        self.n_tex_bytes += a.size
+        self._textures[key] = (off, a.shape[1], a.shape[0])
+        self.dirty = True
+        return self._textures[key]
+
+    def register(self, mesh):
+        slot = mesh._slot if getattr(mesh, "_slot_pool", None) is self else None
+        d = mesh._data
+        if slot is not None and slot.version == mesh._version:
+            return slot
+        nv, ni = len(d.positions), len(d.indices)
+        if slot is not None and slot.n_vertices == nv and slot.n_indices == ni:
+            # vertex data changed in place (update_positions & friends): rewrite the slices
+            self._rewrite(slot, d)
+            slot.version = mesh._version
+            self.dirty = True
+            return slot
+        slot = PoolSlot()
+        slot.vtx_base, slot.idx_base = self.n_vertices, self.n_indices
+        slot.n_vertices, slot.n_indices = nv, ni
+        self.pos.append(np.concatenate([d.positions, np.ones((nv, 1), np.float32)], axis=1))
+        self.nrm.append(np.concatenate([d.normals, np.zeros((nv, 1), np.float32)], axis=1))
+        self.uv.append(d.uvs.astype(np.float32))
+        self.col.append(d.colors.astype(np.float32))
+        self.idx.append(d.indices.astype(np.uint32))
+        self.n_vertices += nv
+        self.n_indices += ni
+        slot.tex_offsets, slot.tex_sizes = [], []
+        for t in d.textures:
+            off, w, h = self.add_texture(t)
+            slot.tex_offsets.append(off)
+            slot.tex_sizes.append((w, h))
+        slot.tex_alpha = list(getattr(d, "_tex_alpha", [False] * len(d.textures)))
+        slot.version = mesh._version
+        mesh._slot = slot
+        mesh._slot_pool = self
+        self.dirty = True
+        return slot
+
+    def _rewrite(self, slot, d):
+        self._flatten()
+        v0, nv = slot.vtx_base, slot.n_vertices
+        self.pos[0][v0:v0 + nv, :3] = d.positions
+        self.nrm[0][v0:v0 + nv, :3] = d.normals
+        self.col[0][v0:v0 + nv] = d.colors
+
+    def _flatten(self):
+        for name in ("pos", "nrm", "uv", "col", "idx", "tex"):
+            lst = getattr(self, name)
+            if len(lst) > 1:
+                setattr(self, name, [np.concatenate(lst)])
+
+    def arrays(self):
+        self._flatten()
+        tex = self.tex[0] if self.tex else np.zeros(4, np.uint8)
+        return self.pos[0], self.nrm[0], self.uv[0], self.col[0], self.idx[0], tex
+
+
+def _effective_material(mat, obj):
+    # RenderShader::setMaterial (render_shader.cpp:355-377)
+    metallic = f32(0.04) if mat.metallic is None else f32(mat.metallic)
+    roughness = f32(0.5) if mat.roughness is None else f32(mat.roughness)
+    if obj is not None:
+        if obj._metallic >= 0.0:
+            metallic = f32(obj._metallic)
+        if obj._roughness >= 0.0:
+            roughness = f32(obj._roughness)
+    return metallic, roughness
+
+
+def scene_record(scene, rec, shadow_mats=None):
+    rec["proj"] = scene._projection.reshape(-1)
+    w2c = M.inverted_rigid(scene._camera_pose)
+    rec["world_to_cam"] = w2c.reshape(-1)
+    # camPosition = worldToCam.invertedRigid().translation() (render_shader.cpp:246)
+    rec["cam_position"][:3] = M.inverted_rigid(w2c)[:3, 3]
+    rec["cam_position"][3] = 1.0
+    ld = scene._light_directions.detach().cpu().numpy().astype(np.float32)
+    lc = scene._light_colors.detach().cpu().numpy().astype(np.float32)
+    rec["light_dir"][:, :3] = ld
+    rec["light_color"][:, :3] = lc
+    rec["ambient"][:3] = scene._ambient_light
+    rec["manual_exposure"] = scene._manual_exposure
+    if shadow_mats is not None:
+        for i in range(_abi.NUM_LIGHTS):
+            rec["shadow_mat"][i] = shadow_mats[i].reshape(-1)
+
+
+def build_batch(scenes, pool, predicate=None, with_shadows=True):
+    """Returns (scene_records, draw_records, chunk_records) as numpy structured arrays."""
+    from . import _shadow
+
+    n_scenes = len(scenes)
+    srec = np.zeros(n_scenes, dtype=_abi.SCENE_DTYPE)
+    draws = []
+    chunks = []
+    for si, scene in enumerate(scenes):
+        objs = [o for o in scene._objects if predicate is None or predicate(o)]
+        mats = _shadow.shadow_matrices(scene) if with_shadows else None
+        scene_record(scene, srec[si], mats)
+        srec[si]["draw_begin"] = len(draws)
+        prim = 0
+        # background plane first (render_pass.cpp:545-582)
+        sz = scene._background_plane_size
+        if float(np.dot(sz, sz)) > 0:
+            d = np.zeros((), dtype=_abi.DRAW_DTYPE)
+            scaling = np.diag([sz[0] / f32(2.0), sz[1] / f32(2.0), f32(1.0), f32(1.0)]).astype(np.float32)
+            o2w = (scene._background_plane_pose @ scaling).astype(np.float32)
+            d["mesh_to_object"] = np.eye(4, dtype=np.float32).reshape(-1)
+            d["object_to_world"] = o2w.reshape(-1)
+            nm = np.zeros((3, 4), np.float32)
+            nm[:, :3] = M.normal_matrix(o2w)
+            d["normal_to_world"] = nm.reshape(-1)
+            flags = _abi.DRAW_NO_VERTEX_ID
+            tex = scene._background_plane_texture
+            if tex is not None:
+                off, w, h = pool.add_texture(tex._rgba)
+                d["base_color"] = (1.0, 1.0, 1.0, 1.0)
+                d["tex_offset"], d["tex_w"], d["tex_h"] = off, w, h
+                flags |= _abi.DRAW_HAS_BASE_TEX
+            else:
+                d["base_color"] = (0.0, 0.8, 0.0, 1.0)
+            d["alpha_cutoff"] = 0.5
+            d["metallic"], d["roughness"] = 0.04, 0.5
+            d["flags"] = flags
+            d["vtx_base"], d["idx_base"], d["n_tris"], d["prim_base"] = 0, 0, 2, prim
+            prim += 2
+            draws.append(d)
+        for obj in objs:
+            mesh = obj._mesh
+            slot = pool.register(mesh)
+            m2o = mesh._pretransform
+            o2w = obj._pose
+            nm = np.zeros((3, 4), np.float32)
+            nm[:, :3] = M.normal_matrix((o2w @ m2o).astype(np.float32))
+            for sm in mesh._data.submeshes:
+                mat = mesh._data.materials[sm.material]
+                d = np.zeros((), dtype=_abi.DRAW_DTYPE)
+                d["mesh_to_object"] = m2o.reshape(-1)
+                d["object_to_world"] = o2w.reshape(-1)
+                d["normal_to_world"] = nm.reshape(-1)
+                d["base_color"] = mat.base_color if obj._color is None or not obj._force_color else obj._color
+                d["emissive"][:3] = mat.emissive
+                d["alpha_cutoff"] = 0.5  # render_shader.cpp:382
+                d["metallic"], d["roughness"] = _effective_material(mat, obj)
+                d["class_index"] = mesh._class_index
+                d["instance_index"] = obj._instance_index
+                flags = _abi.DRAW_CASTS_SHADOW if obj._casts_shadows else 0
+                if mat.base_texture is not None:
+                    flags |= _abi.DRAW_HAS_BASE_TEX
+                    if slot.tex_alpha[mat.base_texture]:
+                        flags |= _abi.DRAW_ALPHA_TEST
+                    d["tex_offset"] = slot.tex_offsets[mat.base_texture]
+                    d["tex_w"], d["tex_h"] = slot.tex_sizes[mat.base_texture]
+                d["flags"] = flags
+                d["vtx_base"] = slot.vtx_base
+                d["idx_base"] = slot.idx_base + sm.first_index
+                d["n_tris"] = sm.n_indices // 3
+                d["prim_base"] = prim
+                prim += sm.n_indices // 3
+                draws.append(d)
+        srec[si]["draw_end"] = len(draws)
+        srec[si]["n_prims"] = prim
+        for di in range(int(srec[si]["draw_begin"]), len(draws)):
+            nt = int(draws[di]["n_tris"])
+            for first in range(0, nt, _abi.CHUNK_TRIS):
+                chunks.append((si, di, first, min(_abi.CHUNK_TRIS, nt - first)))
+    drec = np.array(draws, dtype=_abi.DRAW_DTYPE) if draws else np.zeros(0, dtype=_abi.DRAW_DTYPE)
+    crec = np.array(chunks, dtype=_abi.CHUNK_DTYPE) if chunks else np.zeros(0, dtype=_abi.CHUNK_DTYPE)
+    return srec, drec, crec

@@ -1,0 +1,131 @@
+"""Device-side state of the process: the mesh pool in HBM, scratch buffers, and the calls into
+the C-ABI (lib/libslhip.so).  torch is used for device memory and streams only."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._batch import HostPool, build_batch
+
+SHADOW_RES = 2048  # render_pass.cpp:271
+QUEUE_CAPACITY = 1 << 20
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class RenderBuffers:
+    """The 8 render targets of a batch, [B,H,W,C], allocated with torch on the HIP device."""
+
+    def __init__(self, device, B, H, W, mask):
+        self.B, self.H, self.W, self.mask = B, H, W, mask
+
+        def mk(bit, shape, dtype):
+            return torch.empty(shape, dtype=dtype, device=device) if mask & bit else None
+
+        self.rgb = mk(_abi.OUT_RGB, (B, H, W, 4), torch.uint8)
+        self.coord = mk(_abi.OUT_COORD, (B, H, W, 4), torch.float32)
+        self.cls = mk(_abi.OUT_CLASS, (B, H, W, 1), torch.int16)
+        self.instance = mk(_abi.OUT_INSTANCE, (B, H, W, 1), torch.int16)
+        self.normals = mk(_abi.OUT_NORMALS, (B, H, W, 4), torch.float32)
+        self.vertex_idx = mk(_abi.OUT_VERTEX_IDX, (B, H, W, 4), torch.int32)
+        self.bary = mk(_abi.OUT_BARY, (B, H, W, 4), torch.float32)
+        self.cam_coord = mk(_abi.OUT_CAM_COORD, (B, H, W, 4), torch.float32)
+
+    def abi(self):
+        o = _abi.RenderOut()
+        o.d_rgb, o.d_coord, o.d_class, o.d_instance = _ptr(self.rgb), _ptr(self.coord), _ptr(self.cls), _ptr(self.instance)
+        o.d_normals, o.d_vertex_idx, o.d_bary, o.d_cam_coord = _ptr(self.normals), _ptr(self.vertex_idx), _ptr(self.bary), _ptr(self.cam_coord)
+        return o
+
+
+class Engine:
+    def __init__(self, device_index):
+        L = _abi.lib()
+        if L.slhip_abi_version() != 1:
+            raise _abi.SlhipError("libslhip.so ABI version mismatch")
+        if not torch.cuda.is_available():
+            raise _abi.SlhipError(
+                "stillleben_amd needs a HIP device (MI355X / gfx950); none is visible and there is no CPU fallback")
+        _abi.check(L.slhip_device_init(device_index), "slhip_device_init")
+        self.L = L
+        self.device = torch.device("cuda", device_index)
+        self.pool = HostPool()
+        self._pool_dev = None
+        self._scratch = {}
+
+    # ---- mesh pool -------------------------------------------------------------------------
+    def register_mesh(self, mesh):
+        return self.pool.register(mesh)
+
+    def pool_abi(self):
+        if self.pool.dirty or self._pool_dev is None:
+            arrs = self.pool.arrays()
+            self._pool_dev = [torch.from_numpy(np.ascontiguousarray(a)).to(self.device) for a in arrs]
+            self.pool.dirty = False
+        p = _abi.MeshPool()
+        d = self._pool_dev
+        p.d_pos, p.d_nrm, p.d_uv, p.d_col, p.d_idx, p.d_tex = (_ptr(t) for t in d)
+        p.n_vertices, p.n_indices, p.n_tex_bytes = self.pool.n_vertices, self.pool.n_indices, self.pool.n_tex_bytes
+        return p
+
+    # ---- scratch ---------------------------------------------------------------------------
+    def scratch(self, B, H, W, want_rgb, ssao, shadows):
+        key = (B, H, W, want_rgb, ssao, shadows)
+        s = self._scratch.get(key)
+        if s is None:
+            sizes = (C.c_uint64 * 6)()
+            self.L.slhip_render_scratch_bytes(B, W, H, SHADOW_RES if shadows else 0, QUEUE_CAPACITY, C.byref(sizes))
+
+            def buf(n, need=True):
+                return torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device) if need else None
+
+            s = {
+                "vis": buf(sizes[0]), "hdr": buf(sizes[1], want_rgb), "ao": buf(sizes[2], ssao),
+                "shadow": buf(sizes[3], shadows), "queue": buf(sizes[4]), "lum": buf(sizes[5], want_rgb),
+            }
+            if len(self._scratch) > 4:
+                self._scratch.clear()
+            self._scratch[key] = s
+        a = _abi.RenderScratch()
+        a.d_vis, a.d_hdr, a.d_ao, a.d_shadow, a.d_queue, a.d_lum = (
+            _ptr(s["vis"]), _ptr(s["hdr"]), _ptr(s["ao"]), _ptr(s["shadow"]), _ptr(s["queue"]), _ptr(s["lum"]))
+        a.queue_capacity = QUEUE_CAPACITY
+        a.shadow_res = SHADOW_RES
+        return a, s
+
+    # ---- render ----------------------------------------------------------------------------
+    def upload_records(self, arr):
+        raw = np.frombuffer(arr.tobytes(), dtype=np.uint8) if arr.size else np.zeros(16, np.uint8)
+        return torch.from_numpy(raw.copy()).to(self.device)
+
+    def render(self, scenes, mask=_abi.OUT_ALL, ssao=True, shadows=True, depth_peel=None, predicate=None,
+               buffers=None):
+        W, H = scenes[0]._viewport
+        for s in scenes:
+            if s._viewport != (W, H):
+                raise ValueError("all scenes of a batch must share one viewport")
+        B = len(scenes)
+        want_rgb = bool(mask & _abi.OUT_RGB)
+        ssao = ssao and want_rgb
+        shadows = shadows and want_rgb
+        if ssao:
+            mask |= _abi.OUT_CAM_COORD | _abi.OUT_NORMALS
+        srec, drec, crec = build_batch(scenes, self.pool, predicate, with_shadows=shadows)
+        pool = self.pool_abi()
+        d_s, d_d, d_c = self.upload_records(srec), self.upload_records(drec), self.upload_records(crec)
+        if buffers is None or (buffers.B, buffers.H, buffers.W, buffers.mask) != (B, H, W, mask):
+            buffers = RenderBuffers(self.device, B, H, W, mask)
+        out = buffers.abi()
+        scratch, keep = self.scratch(B, H, W, want_rgb, ssao, shadows)
+        flags = mask | (_abi.RENDER_SSAO if ssao else 0) | (_abi.RENDER_SHADOWS if shadows else 0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            st = self.L.slhip_render(C.byref(pool), _ptr(d_s), _ptr(d_d), _ptr(d_c), B, len(crec), W, H, flags,
+                                     _ptr(depth_peel), C.byref(out), C.byref(scratch), C.c_void_p(stream))
+        _abi.check(st, "slhip_render")
+        # keep the record tensors alive until the stream has consumed them
+        buffers._keepalive = (d_s, d_d, d_c, keep)
+        return buffers

@@ -1,0 +1,1210 @@
+// slhip_render.hip -- G-buffer render path for gfx950 (MI355X), replacing the Magnum/OpenGL
+// RenderPass of the reference (src/render_pass.cpp:303-796 + src/shaders/render_shader.*).
+//
+// Design (see DESIGN.md "Render half"):
+//   k_raster   one thread per triangle of a chunk (scene/draw are workgroup-uniform).  Vertex
+//              transform chain, near clipping, 1/256-px snapping, exact integer edge functions.
+//              Small triangles are resolved by the owning thread with a 64-bit atomicMin on the
+//              visibility buffer (key = depth24 << 32 | primitive id, so the depth test AND the
+//              GL draw-order tie-break are one atomic); larger ones are split into 8x8-pixel
+//              tile items, compacted into a work queue with one wave-aggregated atomic per wave.
+//   k_large    one wave per (triangle, 8x8 tile) item: lane == pixel.
+//   k_shade    deferred: one thread per pixel decodes the winning primitive, re-runs the
+//              vertex stage for its three vertices, reproduces the interpolation of the
+//              fixed-function pipeline and evaluates the fragment shader; writes the selected
+//              render targets with fully coalesced 16 B/lane stores.
+//   k_shadow*  the same rasteriser, depth only, front faces culled, into the shadow maps.
+//   k_ssao / k_ssao_apply / k_tonemap  image-space passes.
+//
+// All arithmetic that feeds integer outputs or depth follows rules R1..R7 of
+// oracle/render_ref.c; this file is compiled with -ffp-contract=off so that only the explicit
+// fmaf() calls fuse.
+#include "slhip_common.h"
+
+namespace {
+
+static_assert(sizeof(slhip_draw) == 272, "slhip_draw layout");
+static_assert(sizeof(slhip_scene) == 464, "slhip_scene layout");
+static_assert(sizeof(slhip_chunk) == 16, "slhip_chunk layout");
+
+constexpr float kInvalid = 3000.0f;  // render_pass.cpp:316
+constexpr float kPi = 3.141592653589793f;
+constexpr unsigned long long kVisEmpty = ~0ull;
+constexpr int kSmallArea = 16;  // bbox pixels a single thread rasterises itself
+
+// ---------------------------------------------------------------------------------------------
+// fixed-order arithmetic (R1)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(const float* a, const float* b)
+{
+    float d = a[0] * b[0];
+    d = fmaf(a[1], b[1], d);
+    d = fmaf(a[2], b[2], d);
+    return d;
+}
+
+__device__ __forceinline__ void mv4(const float* __restrict__ M, const float* v, float* o)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = fmaf(M[4 * r + 0], v[0], 0.0f);
+        a = fmaf(M[4 * r + 1], v[1], a);
+        a = fmaf(M[4 * r + 2], v[2], a);
+        a = fmaf(M[4 * r + 3], v[3], a);
+        o[r] = a;
+    }
+}
+
+__device__ __forceinline__ void mv3p(const float* __restrict__ M, const float* v, float* o)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float a = fmaf(M[4 * r + 0], v[0], 0.0f);
+        a = fmaf(M[4 * r + 1], v[1], a);
+        a = fmaf(M[4 * r + 2], v[2], a);
+        o[r] = a;
+    }
+}
+
+__device__ __forceinline__ void mm4(const float* __restrict__ A, const float* B, float* C)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = fmaf(A[4 * r + 0], B[0 + c], 0.0f);
+            a = fmaf(A[4 * r + 1], B[4 + c], a);
+            a = fmaf(A[4 * r + 2], B[8 + c], a);
+            a = fmaf(A[4 * r + 3], B[12 + c], a);
+            C[4 * r + c] = a;
+        }
+}
+
+__device__ __forceinline__ void normalize3(float* v)
+{
+    float s = sqrtf(dot3(v, v));
+    v[0] = v[0] / s;
+    v[1] = v[1] / s;
+    v[2] = v[2] / s;
+}
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+__device__ __forceinline__ float interp(const float* b, float a0, float a1, float a2)
+{
+    return fmaf(b[2], a2 - a0, fmaf(b[1], a1 - a0, a0));
+}
+
+// ---------------------------------------------------------------------------------------------
+// triangle setup (R2-R4)
+// ---------------------------------------------------------------------------------------------
+struct Setup {
+    int X[3], Y[3];
+    float z[3], invw[3];
+    long long area2;  // > 0
+    int flipped;      // original area2 < 0  (== front facing under FrontFace = CW)
+    int bias[3];
+    int xmin, xmax, ymin, ymax;
+};
+
+__device__ __forceinline__ int snap(float w)
+{
+    float s = floorf(fmaf(w, 256.0f, 0.5f));
+    if (!(s == s)) s = 0.0f;
+    s = fminf(fmaxf(s, -67108864.0f), 67108864.0f);
+    return (int)s;
+}
+
+// c0..c2: clip-space positions.  Returns false if degenerate or outside the W x H target.
+__device__ __forceinline__ bool setup_tri(const float* c0, const float* c1, const float* c2, int W,
+                                          int H, Setup& t)
+{
+    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    const float* cs[3] = {c0, c1, c2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float* c = cs[i];
+        float xn = c[0] / c[3], yn = c[1] / c[3], zn = c[2] / c[3];
+        t.X[i] = snap(fmaf(xn, hw, hw));
+        t.Y[i] = snap(fmaf(yn, hh, hh));
+        t.z[i] = fmaf(zn, 0.5f, 0.5f);
+        t.invw[i] = 1.0f / c[3];
+    }
+    long long area2 = (long long)(t.X[1] - t.X[0]) * (long long)(t.Y[2] - t.Y[0]) -
+                      (long long)(t.Y[1] - t.Y[0]) * (long long)(t.X[2] - t.X[0]);
+    if (area2 == 0) return false;
+    t.flipped = area2 < 0;
+    t.area2 = area2 < 0 ? -area2 : area2;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int a = (i + 1) % 3, b = (i + 2) % 3;
+        int dx = t.X[b] - t.X[a], dy = t.Y[b] - t.Y[a];
+        if (t.flipped) { dx = -dx; dy = -dy; }
+        const bool owned = (dy < 0) || (dy == 0 && dx < 0);
+        t.bias[i] = owned ? 0 : -1;
+    }
+    int xmn = min(t.X[0], min(t.X[1], t.X[2])), xmx = max(t.X[0], max(t.X[1], t.X[2]));
+    int ymn = min(t.Y[0], min(t.Y[1], t.Y[2])), ymx = max(t.Y[0], max(t.Y[1], t.Y[2]));
+    int x0 = (xmn - 128 + 255) >> 8, x1 = (xmx - 128) >> 8;
+    int y0 = (ymn - 128 + 255) >> 8, y1 = (ymx - 128) >> 8;
+    x0 = max(x0, 0); y0 = max(y0, 0);
+    x1 = min(x1, W - 1); y1 = min(y1, H - 1);
+    if (x0 > x1 || y0 > y1) return false;
+    t.xmin = x0; t.xmax = x1; t.ymin = y0; t.ymax = y1;
+    return true;
+}
+
+// coverage + screen-space barycentrics at pixel (px,py) (R4, R5)
+__device__ __forceinline__ bool coverage(const Setup& t, int px, int py, float* lambda)
+{
+    const long long cx = 256ll * px + 128, cy = 256ll * py + 128;
+    long long E[3];
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int a = (i + 1) % 3, b = (i + 2) % 3;
+        long long e = (long long)(t.X[b] - t.X[a]) * (cy - t.Y[a]) -
+                      (long long)(t.Y[b] - t.Y[a]) * (cx - t.X[a]);
+        if (t.flipped) e = -e;
+        inside = inside && (e + t.bias[i] >= 0);
+        E[i] = e;
+    }
+    if (!inside) return false;
+    const float fa = (float)t.area2;
+    lambda[0] = (float)E[0] / fa;
+    lambda[1] = (float)E[1] / fa;
+    lambda[2] = (float)E[2] / fa;
+    return true;
+}
+
+__device__ __forceinline__ unsigned depth24(float z)
+{
+    float fd = floorf(fmaf(z, 16777215.0f, 0.5f));
+    unsigned d = (unsigned)fd;
+    return d > 0xFFFFFFu ? 0xFFFFFFu : d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// near-plane clipping (R7)
+// ---------------------------------------------------------------------------------------------
+struct ClipVert {
+    float clip[4];
+    float bary[3];
+};
+
+__device__ __forceinline__ int clip_near(const ClipVert* in, ClipVert* out)
+{
+    float d[3];
+    bool inside[3];
+    int n_in = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        d[i] = in[i].clip[2] + in[i].clip[3];
+        inside[i] = in[i].clip[2] >= -in[i].clip[3];
+        n_in += inside[i] ? 1 : 0;
+    }
+    if (n_in == 0) return 0;
+    if (n_in == 3) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i] = in[i];
+        return 3;
+    }
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = (i + 1) % 3;
+        if (inside[i]) out[n++] = in[i];
+        if (inside[i] != inside[j]) {
+            const ClipVert& a = inside[i] ? in[i] : in[j];
+            const ClipVert& b = inside[i] ? in[j] : in[i];
+            const float da = inside[i] ? d[i] : d[j], db = inside[i] ? d[j] : d[i];
+            const float tt = da / (da - db);
+            ClipVert o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.clip[k] = fmaf(tt, b.clip[k] - a.clip[k], a.clip[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o.bary[k] = fmaf(tt, b.bary[k] - a.bary[k], a.bary[k]);
+            out[n++] = o;
+        }
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vertex stage (render_shader.vert:57-95)
+// ---------------------------------------------------------------------------------------------
+struct VsOut {
+    float objc[4];
+    float world[3];
+    float cam[3];
+    float nrm[3];
+    float uv[2];
+    float clip[4];
+};
+
+// position-only part: clip position and camera z
+__device__ __forceinline__ void vertex_clip(const slhip_mesh_pool& pool, const slhip_scene* __restrict__ sc,
+                                            const slhip_draw* __restrict__ dr, unsigned v, float* clip,
+                                            float& camz)
+{
+    const float4 p = reinterpret_cast<const float4*>(pool.d_pos)[v];
+    const float pos[4] = {p.x, p.y, p.z, 1.0f};
+    float obj4[4], world4[4], cam4[4];
+    mv4(dr->mesh_to_object, pos, obj4);
+    mv4(dr->object_to_world, obj4, world4);
+    mv4(sc->world_to_cam, world4, cam4);
+    camz = cam4[2] / cam4[3];
+    mv4(sc->proj, cam4, clip);
+}
+
+__device__ __forceinline__ void vertex_full(const slhip_mesh_pool& pool, const slhip_scene* __restrict__ sc,
+                                            const slhip_draw* __restrict__ dr, unsigned v, VsOut& o)
+{
+    const float4 p = reinterpret_cast<const float4*>(pool.d_pos)[v];
+    const float pos[4] = {p.x, p.y, p.z, 1.0f};
+    float obj4[4], world4[4], cam4[4];
+    mv4(dr->mesh_to_object, pos, obj4);
+    o.objc[0] = obj4[0] / obj4[3];
+    o.objc[1] = obj4[1] / obj4[3];
+    o.objc[2] = obj4[2] / obj4[3];
+    mv4(dr->object_to_world, obj4, world4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.world[i] = world4[i] / world4[3];
+    mv4(sc->world_to_cam, world4, cam4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.cam[i] = cam4[i] / cam4[3];
+    o.objc[3] = o.cam[2];
+    const float4 n4 = reinterpret_cast<const float4*>(pool.d_nrm)[v];
+    const float n[3] = {n4.x, n4.y, n4.z};
+    mv3p(dr->normal_to_world, n, o.nrm);
+    normalize3(o.nrm);
+    mv4(sc->proj, cam4, o.clip);
+    const float2 uv = reinterpret_cast<const float2*>(pool.d_uv)[v];
+    o.uv[0] = uv.x;
+    o.uv[1] = uv.y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// texture fetch: bilinear, mip 0, repeat
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wrapi(int i, int n)
+{
+    int m = i % n;
+    return m < 0 ? m + n : m;
+}
+
+__device__ __forceinline__ void tex_bilinear(const uint8_t* __restrict__ tex, int w, int h, float u, float v,
+                                             float* out)
+{
+    const float x = fmaf(u, (float)w, -0.5f), y = fmaf(v, (float)h, -0.5f);
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    const int x0 = wrapi((int)fx, w), y0 = wrapi((int)fy, h);
+    const int x1 = wrapi((int)fx + 1, w), y1 = wrapi((int)fy + 1, h);
+    const uchar4 t00 = reinterpret_cast<const uchar4*>(tex)[(size_t)y0 * w + x0];
+    const uchar4 t10 = reinterpret_cast<const uchar4*>(tex)[(size_t)y0 * w + x1];
+    const uchar4 t01 = reinterpret_cast<const uchar4*>(tex)[(size_t)y1 * w + x0];
+    const uchar4 t11 = reinterpret_cast<const uchar4*>(tex)[(size_t)y1 * w + x1];
+    const unsigned char c00[4] = {t00.x, t00.y, t00.z, t00.w}, c10[4] = {t10.x, t10.y, t10.z, t10.w};
+    const unsigned char c01[4] = {t01.x, t01.y, t01.z, t01.w}, c11[4] = {t11.x, t11.y, t11.z, t11.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float a = (float)c00[c] / 255.0f, b = (float)c10[c] / 255.0f;
+        const float cc = (float)c01[c] / 255.0f, d = (float)c11[c] / 255.0f;
+        const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - cc, cc);
+        out[c] = fmaf(ay, bot - top, top);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fragment emission
+// ---------------------------------------------------------------------------------------------
+struct MainTarget {
+    unsigned long long* vis;  // scene's [H,W] keys
+    const float* peel;        // scene's [H,W,4] previous objectCoordinates or nullptr
+    int W;
+    unsigned prim;
+    // for the (rare) discard tests that run before the depth write
+    bool need_attr;
+    const float* camz;   // [3] camera z of the ORIGINAL vertices
+    const float* bary;   // [3][3] barycentrics of the sub-triangle vertices w.r.t. the original
+    const float* uv;     // [3][2]
+    const uint8_t* tex;
+    int tex_w, tex_h;
+    float base_alpha, alpha_cutoff;
+
+    __device__ __forceinline__ void emit(const Setup& t, int px, int py, const float* l) const
+    {
+        const float z = interp(l, t.z[0], t.z[1], t.z[2]);
+        if (!(z >= 0.0f && z <= 1.0f)) return;
+        const unsigned long long key = ((unsigned long long)depth24(z) << 32) | prim;
+        unsigned long long* slot = vis + (size_t)py * W + px;
+        // cheap monotone pre-test: keys only ever decrease, a stale read is conservative
+        if (__builtin_nontemporal_load(slot) <= key) return;
+        if (need_attr) {
+            const float pw0 = l[0] * t.invw[0], pw1 = l[1] * t.invw[1], pw2 = l[2] * t.invw[2];
+            const float sw = (pw0 + pw1) + pw2;
+            const float bs[3] = {pw0 / sw, pw1 / sw, pw2 / sw};
+            float b[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                b[k] = fmaf(bs[2], bary[6 + k], fmaf(bs[1], bary[3 + k], bs[0] * bary[k]));
+            if (peel) {
+                const float cz = interp(b, camz[0], camz[1], camz[2]);
+                if (cz - 0.00001f <= peel[4 * ((size_t)py * W + px) + 3]) return;
+            }
+            if (tex) {
+                const float u = interp(b, uv[0], uv[2], uv[4]);
+                const float v = interp(b, uv[1], uv[3], uv[5]);
+                float tc[4];
+                tex_bilinear(tex, tex_w, tex_h, u, v, tc);
+                if (base_alpha * tc[3] < alpha_cutoff) return;
+            }
+        }
+        atomicMin(slot, key);
+    }
+};
+
+struct ShadowTarget {
+    unsigned* sm;  // [S,S] float bits
+    int W;
+    __device__ __forceinline__ void emit(const Setup& t, int px, int py, const float* l) const
+    {
+        const float z = interp(l, t.z[0], t.z[1], t.z[2]);
+        if (!(z >= 0.0f && z <= 1.0f)) return;
+        unsigned* slot = sm + (size_t)py * W + px;
+        const unsigned bits = __float_as_uint(z);  // z >= 0: uint order == float order
+        if (__builtin_nontemporal_load(slot) <= bits) return;
+        atomicMin(slot, bits);
+    }
+};
+
+// work item of the large-triangle queue
+struct QItem {
+    unsigned draw;      // global draw index
+    unsigned tri_sub;   // triangle | sub-triangle << 31
+    unsigned scene_aux; // scene | light << 24
+    unsigned tile;      // tx | ty << 16   (8x8 pixel tiles)
+};
+
+// Rasterise one sub-triangle: small ones in place, larger ones to the queue (or in place if
+// the queue is full).
+template <class Target>
+__device__ __forceinline__ void raster_or_enqueue(const Setup& t, const Target& tgt, unsigned* queue,
+                                                  unsigned capacity, unsigned draw, unsigned tri_sub,
+                                                  unsigned scene_aux)
+{
+    const int bw = t.xmax - t.xmin + 1, bh = t.ymax - t.ymin + 1;
+    bool in_place = bw * bh <= kSmallArea;
+    if (!in_place) {
+        const int tx0 = t.xmin >> 3, tx1 = t.xmax >> 3, ty0 = t.ymin >> 3, ty1 = t.ymax >> 3;
+        const unsigned n = (unsigned)((tx1 - tx0 + 1) * (ty1 - ty0 + 1));
+        const unsigned base = atomicAdd(queue, n);
+        if (base + n <= capacity) {
+            QItem* items = reinterpret_cast<QItem*>(queue + 4);
+            unsigned k = base;
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) {
+                    QItem it;
+                    it.draw = draw; it.tri_sub = tri_sub; it.scene_aux = scene_aux;
+                    it.tile = (unsigned)tx | ((unsigned)ty << 16);
+                    items[k++] = it;
+                }
+        } else {
+            // queue full: fall back to the (slow) in-place loop; mark the reservation as void
+            // by writing empty items where it overlaps the queue
+            QItem* items = reinterpret_cast<QItem*>(queue + 4);
+            for (unsigned k = base; k < min(base + n, capacity); ++k) {
+                QItem it;
+                it.draw = 0xFFFFFFFFu; it.tri_sub = 0; it.scene_aux = 0; it.tile = 0;
+                items[k] = it;
+            }
+            in_place = true;
+        }
+    }
+    if (in_place) {
+        for (int py = t.ymin; py <= t.ymax; ++py)
+            for (int px = t.xmin; px <= t.xmax; ++px) {
+                float l[3];
+                if (coverage(t, px, py, l)) tgt.emit(t, px, py, l);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_raster: main pass, one thread per triangle
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+                                                const slhip_draw* __restrict__ draws,
+                                                const slhip_chunk* __restrict__ chunks, int W, int H,
+                                                const float* __restrict__ depth_peel,
+                                                unsigned long long* __restrict__ vis, unsigned* queue,
+                                                unsigned capacity)
+{
+    const slhip_chunk ch = chunks[blockIdx.x];
+    if (threadIdx.x >= ch.count) return;
+    const slhip_scene* sc = scenes + ch.scene;
+    const slhip_draw* dr = draws + ch.draw;
+    const unsigned tri = ch.first_tri + threadIdx.x;
+    const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
+    const unsigned vi[3] = {ip[0], ip[1], ip[2]};
+
+    ClipVert cv[3];
+    float camz[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        vertex_clip(pool, sc, dr, dr->vtx_base + vi[k], cv[k].clip, camz[k]);
+        cv[k].bary[0] = k == 0 ? 1.0f : 0.0f;
+        cv[k].bary[1] = k == 1 ? 1.0f : 0.0f;
+        cv[k].bary[2] = k == 2 ? 1.0f : 0.0f;
+    }
+    ClipVert poly[4];
+    const int n = clip_near(cv, poly);
+    if (n == 0) return;
+
+    const size_t P = (size_t)W * H;
+    MainTarget tgt;
+    tgt.vis = vis + (size_t)ch.scene * P;
+    tgt.peel = depth_peel ? depth_peel + 4 * (size_t)ch.scene * P : nullptr;
+    tgt.W = W;
+    tgt.prim = dr->prim_base + tri;
+    const bool alpha_test = (dr->flags & SLHIP_DRAW_ALPHA_TEST) && (dr->flags & SLHIP_DRAW_HAS_BASE_TEX);
+    tgt.need_attr = alpha_test || tgt.peel != nullptr;
+    float uvs[6] = {0, 0, 0, 0, 0, 0};
+    tgt.tex = nullptr;
+    if (alpha_test) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float2 uv = reinterpret_cast<const float2*>(pool.d_uv)[dr->vtx_base + vi[k]];
+            uvs[2 * k] = uv.x; uvs[2 * k + 1] = uv.y;
+        }
+        tgt.tex = pool.d_tex + dr->tex_offset;
+        tgt.tex_w = (int)dr->tex_w; tgt.tex_h = (int)dr->tex_h;
+    }
+    tgt.camz = camz;
+    tgt.uv = uvs;
+    tgt.base_alpha = dr->base_color[3];
+    tgt.alpha_cutoff = dr->alpha_cutoff;
+
+    for (int sub = 0; sub < n - 2; ++sub) {
+        Setup t;
+        if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
+        float bary[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bary[k] = poly[0].bary[k];
+            bary[3 + k] = poly[sub + 1].bary[k];
+            bary[6 + k] = poly[sub + 2].bary[k];
+        }
+        tgt.bary = bary;
+        // the discard tests need per-vertex data that only this thread holds: keep such
+        // triangles in place
+        if (tgt.need_attr) {
+            for (int py = t.ymin; py <= t.ymax; ++py)
+                for (int px = t.xmin; px <= t.xmax; ++px) {
+                    float l[3];
+                    if (coverage(t, px, py, l)) tgt.emit(t, px, py, l);
+                }
+        } else {
+            raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri | ((unsigned)sub << 31), ch.scene);
+        }
+    }
+}
+
+// k_large: one wave per (triangle, 8x8 tile); lane == pixel
+__global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+                                               const slhip_draw* __restrict__ draws, int W, int H,
+                                               unsigned long long* __restrict__ vis,
+                                               const unsigned* __restrict__ queue, unsigned capacity)
+{
+    const unsigned count = min(queue[0], capacity);
+    const QItem* items = reinterpret_cast<const QItem*>(queue + 4);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned i = wave; i < count; i += n_waves) {
+        const QItem it = items[i];
+        if (it.draw == 0xFFFFFFFFu) continue;
+        const slhip_scene* sc = scenes + it.scene_aux;
+        const slhip_draw* dr = draws + it.draw;
+        const unsigned tri = it.tri_sub & 0x7FFFFFFFu;
+        const int sub = (int)(it.tri_sub >> 31);
+        const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
+        ClipVert cv[3];
+        float camz;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            vertex_clip(pool, sc, dr, dr->vtx_base + ip[k], cv[k].clip, camz);
+            cv[k].bary[0] = cv[k].bary[1] = cv[k].bary[2] = 0.0f;
+        }
+        ClipVert poly[4];
+        const int n = clip_near(cv, poly);
+        if (sub > n - 3) continue;
+        Setup t;
+        if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
+        const int px = (int)((it.tile & 0xFFFFu) << 3) + (int)(lane & 7);
+        const int py = (int)((it.tile >> 16) << 3) + (int)(lane >> 3);
+        if (px < t.xmin || px > t.xmax || py < t.ymin || py > t.ymax) continue;
+        float l[3];
+        if (!coverage(t, px, py, l)) continue;
+        MainTarget tgt;
+        tgt.vis = vis + (size_t)it.scene_aux * W * H;
+        tgt.peel = nullptr;
+        tgt.W = W;
+        tgt.prim = dr->prim_base + tri;
+        tgt.need_attr = false;
+        tgt.tex = nullptr;
+        tgt.emit(t, px, py, l);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shadow pass (render_pass.cpp:408-460): depth only, front faces culled
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool light_active(const slhip_scene* sc, int l)
+{
+    const float* lc = sc->light_color[l];
+    const float* ld = sc->light_dir[l];
+    return !((lc[0] == 0.0f && lc[1] == 0.0f && lc[2] == 0.0f) ||
+             (ld[0] == 0.0f && ld[1] == 0.0f && ld[2] == 0.0f));
+}
+
+__device__ __forceinline__ void shadow_clip(const slhip_mesh_pool& pool, const float* T, unsigned v, float* clip)
+{
+    const float4 p = reinterpret_cast<const float4*>(pool.d_pos)[v];
+    const float pos[4] = {p.x, p.y, p.z, 1.0f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = fmaf(T[4 * r + 0], pos[0], 0.0f);
+        a = fmaf(T[4 * r + 1], pos[1], a);
+        a = fmaf(T[4 * r + 2], pos[2], a);
+        a = fmaf(T[4 * r + 3], pos[3], a);
+        clip[r] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+                                                       const slhip_draw* __restrict__ draws,
+                                                       const slhip_chunk* __restrict__ chunks, int S,
+                                                       unsigned* __restrict__ shadow, unsigned* queue,
+                                                       unsigned capacity)
+{
+    const slhip_chunk ch = chunks[blockIdx.x];
+    const int light = blockIdx.y;
+    if (threadIdx.x >= ch.count) return;
+    const slhip_scene* sc = scenes + ch.scene;
+    const slhip_draw* dr = draws + ch.draw;
+    if (!(dr->flags & SLHIP_DRAW_CASTS_SHADOW)) return;
+    if (!light_active(sc, light)) return;
+    float OM[16], T[16];
+    mm4(dr->object_to_world, dr->mesh_to_object, OM);
+    mm4(sc->shadow_mat[light], OM, T);
+    const unsigned tri = ch.first_tri + threadIdx.x;
+    const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
+    float c[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) shadow_clip(pool, T, dr->vtx_base + ip[k], c[k]);
+    Setup t;
+    if (!setup_tri(c[0], c[1], c[2], S, S, t)) return;
+    if (t.flipped) return;  // front face culled
+    ShadowTarget tgt;
+    tgt.sm = shadow + ((size_t)ch.scene * SLHIP_NUM_LIGHTS + light) * S * S;
+    tgt.W = S;
+    raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene | ((unsigned)light << 24));
+}
+
+__global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+                                                      const slhip_draw* __restrict__ draws, int S,
+                                                      unsigned* __restrict__ shadow,
+                                                      const unsigned* __restrict__ queue, unsigned capacity)
+{
+    const unsigned count = min(queue[0], capacity);
+    const QItem* items = reinterpret_cast<const QItem*>(queue + 4);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned i = wave; i < count; i += n_waves) {
+        const QItem it = items[i];
+        if (it.draw == 0xFFFFFFFFu) continue;
+        const unsigned scene = it.scene_aux & 0xFFFFFFu;
+        const int light = (int)(it.scene_aux >> 24);
+        const slhip_scene* sc = scenes + scene;
+        const slhip_draw* dr = draws + it.draw;
+        float OM[16], T[16];
+        mm4(dr->object_to_world, dr->mesh_to_object, OM);
+        mm4(sc->shadow_mat[light], OM, T);
+        const unsigned tri = it.tri_sub;
+        const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
+        float c[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) shadow_clip(pool, T, dr->vtx_base + ip[k], c[k]);
+        Setup t;
+        if (!setup_tri(c[0], c[1], c[2], S, S, t)) continue;
+        const int px = (int)((it.tile & 0xFFFFu) << 3) + (int)(lane & 7);
+        const int py = (int)((it.tile >> 16) << 3) + (int)(lane >> 3);
+        if (px < t.xmin || px > t.xmax || py < t.ymin || py > t.ymax) continue;
+        float l[3];
+        if (!coverage(t, px, py, l)) continue;
+        ShadowTarget tgt;
+        tgt.sm = shadow + ((size_t)scene * SLHIP_NUM_LIGHTS + light) * S * S;
+        tgt.W = S;
+        tgt.emit(t, px, py, l);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PBR shading (render_shader.frag:181-221, 248-399)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float distribution_ggx(const float* N, const float* Hv, float roughness)
+{
+    const float a = roughness * roughness;
+    const float a2 = a * a;
+    const float NdotH = fmaxf(dot3(N, Hv), 0.0f);
+    const float NdotH2 = NdotH * NdotH;
+    float denom = (NdotH2 * (a2 - 1.0f) + 1.0f);
+    denom = kPi * denom * denom;
+    return a2 / denom;
+}
+
+__device__ __forceinline__ float geometry_schlick_ggx(float NdotV, float roughness)
+{
+    const float r = roughness + 1.0f;
+    const float k = (r * r) / 8.0f;
+    return NdotV / (NdotV * (1.0f - k) + k);
+}
+
+__device__ __forceinline__ float shadow_tap(const float* __restrict__ sm, int S, float u, float v, float ref)
+{
+    const float x = fmaf(u, (float)S, -0.5f), y = fmaf(v, (float)S, -0.5f);
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = min(max(x0, 0), S - 1); x1 = min(max(x1, 0), S - 1);
+    y0 = min(max(y0, 0), S - 1); y1 = min(max(y1, 0), S - 1);
+    const float r = clampf(ref, 0.0f, 1.0f);
+    const float c00 = r <= sm[(size_t)y0 * S + x0] ? 1.0f : 0.0f;
+    const float c10 = r <= sm[(size_t)y0 * S + x1] ? 1.0f : 0.0f;
+    const float c01 = r <= sm[(size_t)y1 * S + x0] ? 1.0f : 0.0f;
+    const float c11 = r <= sm[(size_t)y1 * S + x1] ? 1.0f : 0.0f;
+    const float top = fmaf(ax, c10 - c00, c00), bot = fmaf(ax, c11 - c01, c01);
+    return fmaf(ay, bot - top, top);
+}
+
+__device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ sc, const slhip_draw* __restrict__ dr,
+                                               const float* base, const float* world, const float* nrm_in,
+                                               bool front_facing, const float* __restrict__ shadow, int S,
+                                               float* color, float* normal_out)
+{
+    float normal[3] = {nrm_in[0], nrm_in[1], nrm_in[2]};
+    if (!front_facing) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
+    float V[3] = {sc->cam_position[0] - world[0], sc->cam_position[1] - world[1],
+                  sc->cam_position[2] - world[2]};
+    normalize3(V);
+    const float NoV = clampf(dot3(normal, V), 1e-5f, 1.0f);
+    const float roughness = fmaxf(dr->roughness, 0.045f);
+    const float metallic = dr->metallic;
+
+    color[0] = color[1] = color[2] = 0.0f;
+    color[3] = base[3];
+
+    float F0[3], kS[3];
+    const float p5 = powf(1.0f - NoV, 5.0f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        F0[c] = 0.04f * (1.0f - metallic) + base[c] * metallic;
+        const float Fr = fmaxf(1.0f - roughness, F0[c]) - F0[c];
+        kS[c] = F0[c] + Fr * p5;
+    }
+    for (int i = 0; i < SLHIP_NUM_LIGHTS; ++i) {
+        if (!light_active(sc, i)) continue;
+        const float* lc = sc->light_color[i];
+        const float* ld = sc->light_dir[i];
+        float inverse_shadow = 1.0f;
+        if (shadow) {
+            const float w4[4] = {world[0], world[1], world[2], 1.0f};
+            float pc[4];
+            mv4(sc->shadow_mat[i], w4, pc);
+            const float px = 0.5f * (pc[0] / pc[3]) + 0.5f;
+            const float py = 0.5f * (pc[1] / pc[3]) + 0.5f;
+            const float pz = 0.5f * (pc[2] / pc[3]) + 0.5f;
+            const float* sm = shadow + (size_t)i * S * S;
+            const float scale = 1.0f / (float)S;
+            float acc = 0.0f;
+            for (int yy = 0; yy < 4; ++yy)
+                for (int xx = 0; xx < 4; ++xx) {
+                    const float ox = (-1.5f + (float)xx) * scale, oy = (-1.5f + (float)yy) * scale;
+                    acc += shadow_tap(sm, S, px + ox, py + oy, pz - 0.00003f);
+                }
+            inverse_shadow = acc / 16.0f;
+        }
+        float L[3] = {-ld[0], -ld[1], -ld[2]};
+        normalize3(L);
+        float Hv[3] = {V[0] + L[0], V[1] + L[1], V[2] + L[2]};
+        normalize3(Hv);
+        const float NDF = distribution_ggx(normal, Hv, roughness);
+        const float NdotVg = fmaxf(dot3(normal, V), 0.0f);
+        const float NdotL = fmaxf(dot3(normal, L), 0.0f);
+        const float G = geometry_schlick_ggx(NdotL, roughness) * geometry_schlick_ggx(NdotVg, roughness);
+        const float denominator = fmaxf(4.0f * NoV * NdotL, 0.001f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float specular = (NDF * G * kS[c]) / denominator;
+            const float kD = (1.0f - kS[c]) * (1.0f - metallic);
+            color[c] += inverse_shadow * (kD * base[c] / kPi + specular) * lc[c] * NdotL;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        color[c] += sc->ambient[c] * base[c];
+        color[c] += dr->emissive[c];
+    }
+    float nc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float a = fmaf(sc->world_to_cam[4 * r + 0], normal[0], 0.0f);
+        a = fmaf(sc->world_to_cam[4 * r + 1], normal[1], a);
+        a = fmaf(sc->world_to_cam[4 * r + 2], normal[2], a);
+        nc[r] = a;
+    }
+    normalize3(nc);
+    normal_out[0] = nc[0]; normal_out[1] = nc[1]; normal_out[2] = nc[2];
+    normal_out[3] = dot3(normal, V);
+}
+
+// tone map of one HDR texel (tone_map_shader.frag:102-131); exposure_div < 0 => multiply by
+// manual exposure
+__device__ __forceinline__ uchar4 tone_map_px(const float* c, float manual_exposure, float lum)
+{
+    const float X = 0.4124564f * c[0] + 0.3575761f * c[1] + 0.1804375f * c[2];
+    float Y = 0.2126729f * c[0] + 0.7151522f * c[1] + 0.0721750f * c[2];
+    const float Z = 0.0193339f * c[0] + 0.1191920f * c[1] + 0.9503041f * c[2];
+    const float inv = 1.0f / (X + Y + Z);
+    const float xx = X * inv, yy = Y * inv;
+    if (manual_exposure >= 0.0f) Y *= manual_exposure;
+    else Y /= (9.6f * lum + 0.0001f);
+    const float x2 = Y * xx / yy;
+    const float y2 = Y;
+    const float z2 = Y * (1.0f - xx - yy) / yy;
+    float o[3];
+    o[0] = 3.2404542f * x2 + -1.5371385f * y2 + -0.4985314f * z2;
+    o[1] = -0.9692660f * x2 + 1.8760108f * y2 + 0.0415560f * z2;
+    o[2] = 0.0556434f * x2 + -0.2040259f * y2 + 1.0572252f * z2;
+    unsigned char r[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float x = o[k];
+        float v = (x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f);
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        if (!(v == v)) v = 0.0f;
+        r[k] = (unsigned char)floorf(v * 255.0f + 0.5f);
+    }
+    const float a = fminf(fmaxf(c[3], 0.0f), 1.0f);
+    r[3] = (unsigned char)floorf(a * 255.0f + 0.5f);
+    return make_uchar4(r[0], r[1], r[2], r[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_shade: deferred resolve, one thread per pixel
+// ---------------------------------------------------------------------------------------------
+struct ShadeParams {
+    int W, H;
+    unsigned flags;
+    int S;
+    int inline_tonemap;  // 1: no SSAO and manual exposure -> write rgb directly
+    int want_lum;        // 1: write per-block HDR sums for auto exposure
+};
+
+__global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+                                               const slhip_draw* __restrict__ draws, ShadeParams prm,
+                                               const unsigned long long* __restrict__ vis,
+                                               slhip_render_out out, float* __restrict__ hdr,
+                                               const float* __restrict__ shadow, float* __restrict__ lum_part)
+{
+    const int W = prm.W, H = prm.H;
+    const size_t P = (size_t)W * H;
+    const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
+    const unsigned scene = blockIdx.x / blocks_per_scene;
+    const unsigned pix = (blockIdx.x % blocks_per_scene) * 256 + threadIdx.x;
+    const bool active = pix < P;
+    const slhip_scene* sc = scenes + scene;
+    const size_t gp = (size_t)scene * P + pix;
+
+    float color[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (active) {
+        const unsigned long long key = vis[gp];
+        float coord[4] = {kInvalid, kInvalid, kInvalid, kInvalid};
+        float camc[4] = {kInvalid, kInvalid, kInvalid, kInvalid};
+        float nout[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float bary[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        unsigned vidx[4] = {0u, 0u, 0u, 0u};
+        unsigned cls = 0u, inst = 0u;
+        if (key != kVisEmpty) {
+            const unsigned prim = (unsigned)(key & 0xFFFFFFFFull);
+            unsigned d = sc->draw_begin;
+            for (unsigned i = sc->draw_begin + 1; i < sc->draw_end; ++i)
+                if (prim >= draws[i].prim_base) d = i;
+            const slhip_draw* dr = draws + d;
+            const unsigned tri = prim - dr->prim_base;
+            const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
+            const unsigned vi[3] = {ip[0], ip[1], ip[2]};
+            VsOut vo[3];
+            ClipVert cv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                vertex_full(pool, sc, dr, dr->vtx_base + vi[k], vo[k]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cv[k].clip[c] = vo[k].clip[c];
+                cv[k].bary[0] = k == 0 ? 1.0f : 0.0f;
+                cv[k].bary[1] = k == 1 ? 1.0f : 0.0f;
+                cv[k].bary[2] = k == 2 ? 1.0f : 0.0f;
+            }
+            ClipVert poly[4];
+            const int n = clip_near(cv, poly);
+            const int px = (int)(pix % (unsigned)W), py = (int)(pix / (unsigned)W);
+            float b[3] = {0.0f, 0.0f, 0.0f};
+            bool found = false, front = false;
+            for (int sub = 0; sub < n - 2 && !found; ++sub) {
+                Setup t;
+                if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
+                float l[3];
+                if (px < t.xmin || px > t.xmax || py < t.ymin || py > t.ymax) continue;
+                if (!coverage(t, px, py, l)) continue;
+                const float pw0 = l[0] * t.invw[0], pw1 = l[1] * t.invw[1], pw2 = l[2] * t.invw[2];
+                const float sw = (pw0 + pw1) + pw2;
+                const float bs[3] = {pw0 / sw, pw1 / sw, pw2 / sw};
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    b[k] = fmaf(bs[2], poly[sub + 2].bary[k],
+                                fmaf(bs[1], poly[sub + 1].bary[k], bs[0] * poly[0].bary[k]));
+                front = t.flipped;
+                found = true;
+            }
+            if (found) {
+                const float camz = interp(b, vo[0].objc[3], vo[1].objc[3], vo[2].objc[3]);
+                float base[4] = {dr->base_color[0], dr->base_color[1], dr->base_color[2], dr->base_color[3]};
+                if (dr->flags & SLHIP_DRAW_HAS_BASE_TEX) {
+                    const float u = interp(b, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]);
+                    const float v = interp(b, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]);
+                    float tc[4];
+                    tex_bilinear(pool.d_tex + dr->tex_offset, (int)dr->tex_w, (int)dr->tex_h, u, v, tc);
+                    base[0] *= powf(tc[0], 2.2f);
+                    base[1] *= powf(tc[1], 2.2f);
+                    base[2] *= powf(tc[2], 2.2f);
+                    base[3] *= tc[3];
+                }
+                float world[3], nrm[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    world[k] = interp(b, vo[0].world[k], vo[1].world[k], vo[2].world[k]);
+                    nrm[k] = interp(b, vo[0].nrm[k], vo[1].nrm[k], vo[2].nrm[k]);
+                    coord[k] = interp(b, vo[0].objc[k], vo[1].objc[k], vo[2].objc[k]);
+                    camc[k] = interp(b, vo[0].cam[k], vo[1].cam[k], vo[2].cam[k]);
+                }
+                coord[3] = camz;
+                camc[3] = 1.0f;
+                const float* sm = (prm.flags & SLHIP_RENDER_SHADOWS) && shadow
+                                      ? shadow + (size_t)scene * SLHIP_NUM_LIGHTS * prm.S * prm.S
+                                      : nullptr;
+                shade_fragment(sc, dr, base, world, nrm, front, sm, prm.S, color, nout);
+                cls = dr->class_index & 0xFFFFu;
+                inst = dr->instance_index & 0xFFFFu;
+                if (!(dr->flags & SLHIP_DRAW_NO_VERTEX_ID)) { vidx[0] = vi[0] + 1; vidx[1] = vi[1] + 1; vidx[2] = vi[2] + 1; }
+                bary[0] = b[0]; bary[1] = b[1]; bary[2] = b[2];
+            }
+        }
+        if (out.d_coord) reinterpret_cast<float4*>(out.d_coord)[gp] = make_float4(coord[0], coord[1], coord[2], coord[3]);
+        if (out.d_class) out.d_class[gp] = (uint16_t)cls;
+        if (out.d_instance) out.d_instance[gp] = (uint16_t)inst;
+        if (out.d_normals) reinterpret_cast<float4*>(out.d_normals)[gp] = make_float4(nout[0], nout[1], nout[2], nout[3]);
+        if (out.d_vertex_idx) reinterpret_cast<uint4*>(out.d_vertex_idx)[gp] = make_uint4(vidx[0], vidx[1], vidx[2], vidx[3]);
+        if (out.d_bary) reinterpret_cast<float4*>(out.d_bary)[gp] = make_float4(bary[0], bary[1], bary[2], bary[3]);
+        if (out.d_cam_coord) reinterpret_cast<float4*>(out.d_cam_coord)[gp] = make_float4(camc[0], camc[1], camc[2], camc[3]);
+        if (prm.inline_tonemap) {
+            if (out.d_rgb) reinterpret_cast<uchar4*>(out.d_rgb)[gp] = tone_map_px(color, sc->manual_exposure, 0.0f);
+        } else if (hdr) {
+            reinterpret_cast<float4*>(hdr)[gp] = make_float4(color[0], color[1], color[2], color[3]);
+        }
+    }
+    if (prm.want_lum) {
+        // deterministic block sum (fixed tree) -> one partial per block
+        __shared__ float red[4][256];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = color[c];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < 4) lum_part[(size_t)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SSAO (ssao_shader.frag:20-56), blur/apply (ssao_apply_shader.frag:29-75), tone map
+// ---------------------------------------------------------------------------------------------
+__constant__ float c_ssao_noise[48];
+__constant__ float c_ssao_kernel[192];
+
+__device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, int W, int H, float x, float y)
+{
+    const float xs = x - 0.5f, ys = y - 0.5f;
+    const float fx = floorf(xs), fy = floorf(ys);
+    const float ax = xs - fx, ay = ys - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
+    y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
+    const float a = img[4 * ((size_t)y0 * W + x0) + 2], b = img[4 * ((size_t)y0 * W + x1) + 2];
+    const float c = img[4 * ((size_t)y1 * W + x0) + 2], d = img[4 * ((size_t)y1 * W + x1) + 2];
+    const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - c, c);
+    return fmaf(ay, bot - top, top);
+}
+
+__global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ scenes, int W, int H,
+                                              const float* __restrict__ cam, const float* __restrict__ nrm,
+                                              float* __restrict__ ao)
+{
+    const size_t P = (size_t)W * H;
+    const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
+    const unsigned scene = blockIdx.x / blocks_per_scene;
+    const unsigned pix = (blockIdx.x % blocks_per_scene) * 256 + threadIdx.x;
+    if (pix >= P) return;
+    const float* proj = scenes[scene].proj;
+    const float* camS = cam + 4 * (size_t)scene * P;
+    const size_t gp = (size_t)scene * P + pix;
+    const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
+    const float4 n4 = reinterpret_cast<const float4*>(nrm)[gp];
+    float n[3] = {n4.x, n4.y, n4.z};
+    if (n[0] == 0.0f && n[1] == 0.0f && n[2] == 0.0f) { ao[gp] = 1.0f; return; }
+    normalize3(n);
+    const float4 f4 = reinterpret_cast<const float4*>(cam)[gp];
+    const float frag[3] = {f4.x, f4.y, f4.z};
+    const float* rv0 = &c_ssao_noise[3 * ((j & 3) * 4 + (i & 3))];
+    float rv[3] = {rv0[0], rv0[1], rv0[2]};
+    normalize3(rv);
+    const float d = dot3(rv, n);
+    float tg[3] = {rv[0] - n[0] * d, rv[1] - n[1] * d, rv[2] - n[2] * d};
+    normalize3(tg);
+    const float bt[3] = {n[1] * tg[2] - n[2] * tg[1], n[2] * tg[0] - n[0] * tg[2], n[0] * tg[1] - n[1] * tg[0]};
+    const float radius = 0.1f, bias = 0.0025f;
+    float occlusion = 0.0f;
+    for (int k = 0; k < 64; ++k) {
+        const float* s = &c_ssao_kernel[3 * k];
+        float sp[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sp[c] = frag[c] + (tg[c] * s[0] + bt[c] * s[1] + n[c] * s[2]) * radius;
+        const float v4[4] = {sp[0], sp[1], sp[2], 1.0f};
+        float off[4];
+        mv4(proj, v4, off);
+        const float ox = (off[0] / off[3]) * 0.5f + 0.5f;
+        const float oy = (off[1] / off[3]) * 0.5f + 0.5f;
+        const float sd = rect_bilinear_z(camS, W, H, ox * (float)W, oy * (float)H);
+        const float tt = clampf(radius / fabsf(frag[2] - sd), 0.0f, 1.0f);
+        const float rc = tt * tt * (3.0f - 2.0f * tt);
+        occlusion += (sd <= sp[2] - bias ? 1.0f : 0.0f) * rc;
+    }
+    ao[gp] = 1.0f - occlusion / 64.0f;
+}
+
+__global__ __launch_bounds__(256) void k_ssao_apply(int W, int H, const float* __restrict__ hdr_in,
+                                                    const float* __restrict__ ao, const float* __restrict__ cam,
+                                                    float* __restrict__ hdr_out)
+{
+    const size_t P = (size_t)W * H;
+    const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
+    const unsigned scene = blockIdx.x / blocks_per_scene;
+    const unsigned pix = (blockIdx.x % blocks_per_scene) * 256 + threadIdx.x;
+    if (pix >= P) return;
+    const float* camS = cam + 4 * (size_t)scene * P;
+    const float* aoS = ao + (size_t)scene * P;
+    const size_t gp = (size_t)scene * P + pix;
+    const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
+    const float sigma = 3.0f * 0.5f;
+    const float falloff = 1.0f / (2.0f * sigma * sigma);
+    const float cd = rect_bilinear_z(camS, W, H, (float)i, (float)j);
+    float result = 0.0f, wt = 0.0f;
+    for (int x = -2; x < 2; ++x)
+        for (int y = -2; y < 2; ++y) {
+            const int xi = min(max(i + x, 0), W - 1), yj = min(max(j + y, 0), H - 1);
+            const float c = aoS[(size_t)yj * W + xi];
+            const float dz = rect_bilinear_z(camS, W, H, (float)(i + x), (float)(j + y));
+            const float r = sqrtf((float)(x * x + y * y));
+            const float dd = (dz - cd) * 300.0f;
+            const float w = exp2f(-r * r * falloff - dd * dd);
+            wt += w;
+            result += c * w;
+        }
+    const float a = result / wt;
+    const float4 h = reinterpret_cast<const float4*>(hdr_in)[gp];
+    reinterpret_cast<float4*>(hdr_out)[gp] = make_float4(h.x * a, h.y * a, h.z * a, h.w);
+}
+
+__global__ __launch_bounds__(256) void k_tonemap(const slhip_scene* __restrict__ scenes, int W, int H,
+                                                 const float* __restrict__ hdr, const float* __restrict__ lum_part,
+                                                 uint8_t* __restrict__ rgb)
+{
+    const size_t P = (size_t)W * H;
+    const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
+    const unsigned scene = blockIdx.x / blocks_per_scene;
+    const unsigned pix = (blockIdx.x % blocks_per_scene) * 256 + threadIdx.x;
+    const float manual = scenes[scene].manual_exposure;
+    __shared__ float s_lum;
+    if (!(manual >= 0.0f)) {
+        // every block re-reduces the scene's per-block partial sums in the same fixed order
+        __shared__ float red[4][256];
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* part = lum_part + (size_t)scene * blocks_per_scene * 4;
+        for (unsigned b = threadIdx.x; b < blocks_per_scene; b += 256)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += part[4 * b + c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = acc[c];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float inv = 1.0f / (float)P;
+            const float a0 = red[0][0] * inv, a1 = red[1][0] * inv, a2 = red[2][0] * inv, a3 = red[3][0] * inv;
+            s_lum = 0.1f * (0.2125f * (a0 / a3) + 0.7154f * (a1 / a3) + 0.0721f * (a2 / a3));
+        }
+        __syncthreads();
+    }
+    if (pix >= P) return;
+    const size_t gp = (size_t)scene * P + pix;
+    const float4 h = reinterpret_cast<const float4*>(hdr)[gp];
+    const float c[4] = {h.x, h.y, h.z, h.w};
+    reinterpret_cast<uchar4*>(rgb)[gp] = tone_map_px(c, manual, (manual >= 0.0f) ? 0.0f : s_lum);
+}
+
+__global__ void k_fill_u32(unsigned* p, unsigned v, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+bool g_ssao_tables_uploaded[16] = {};
+
+}  // namespace
+
+// SSAO tables (generated at build time by tools/gen_ssao_tables.py from the recipe of
+// ssao_shader.cpp:72-112)
+#include "ssao_tables.inc"
+
+extern "C" int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uint32_t height,
+                                          uint32_t shadow_res, uint32_t queue_capacity, uint64_t bytes_out[6])
+{
+    const uint64_t P = (uint64_t)width * height, B = n_scenes;
+    const uint64_t blocks = (P + 255) / 256;
+    bytes_out[0] = B * P * 8;                                              // d_vis
+    bytes_out[1] = 2 * B * P * 16;                                         // d_hdr (two planes)
+    bytes_out[2] = B * P * 4;                                              // d_ao
+    bytes_out[3] = B * SLHIP_NUM_LIGHTS * (uint64_t)shadow_res * shadow_res * 4;  // d_shadow
+    bytes_out[4] = 16 + (uint64_t)queue_capacity * 16;                     // d_queue
+    bytes_out[5] = B * blocks * 16;                                        // d_lum
+    return 0;
+}
+
+extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_scenes, const slhip_draw* d_draws,
+                            const slhip_chunk* d_chunks, uint32_t n_scenes, uint32_t n_chunks, uint32_t width,
+                            uint32_t height, uint32_t flags, const float* d_depth_peel,
+                            const slhip_render_out* out, const slhip_render_scratch* scratch, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!pool || !d_scenes || !d_draws || !out || !scratch) {
+        slhip::set_error("slhip_render: null argument");
+        return -1;
+    }
+    if (n_scenes == 0 || width == 0 || height == 0) return 0;
+    if (!scratch->d_vis || !scratch->d_queue) {
+        slhip::set_error("slhip_render: d_vis and d_queue scratch are required");
+        return -1;
+    }
+    const bool want_rgb = out->d_rgb != nullptr;
+    const bool ssao = (flags & SLHIP_RENDER_SSAO) && want_rgb;
+    const bool shadows = (flags & SLHIP_RENDER_SHADOWS) && want_rgb && scratch->d_shadow != nullptr;
+    if (ssao && (!out->d_cam_coord || !out->d_normals || !scratch->d_ao)) {
+        slhip::set_error("slhip_render: SSAO needs the cam_coord and normals outputs and d_ao scratch");
+        return -1;
+    }
+    if (want_rgb && (!scratch->d_hdr || !scratch->d_lum)) {
+        slhip::set_error("slhip_render: rgb output needs d_hdr and d_lum scratch");
+        return -1;
+    }
+    const int W = (int)width, H = (int)height;
+    const size_t P = (size_t)W * H;
+    const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
+    const unsigned pix_blocks = blocks_per_scene * n_scenes;
+    const int S = (int)scratch->shadow_res;
+
+    if (ssao) {
+        int dev = 0;
+        SLHIP_CHECK(hipGetDevice(&dev));
+        if (dev < 16 && !g_ssao_tables_uploaded[dev]) {
+            SLHIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ssao_noise), k_ssao_noise_host, sizeof(float) * 48, 0,
+                                               hipMemcpyHostToDevice, stream));
+            SLHIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ssao_kernel), k_ssao_kernel_host, sizeof(float) * 192, 0,
+                                               hipMemcpyHostToDevice, stream));
+            g_ssao_tables_uploaded[dev] = true;
+        }
+    }
+
+    // shadow pass
+    if (shadows && n_chunks > 0) {
+        const size_t n = (size_t)n_scenes * SLHIP_NUM_LIGHTS * S * S;
+        k_fill_u32<<<2048, 256, 0, stream>>>(reinterpret_cast<unsigned*>(scratch->d_shadow), 0x3F800000u, n);
+        SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
+        k_shadow_raster<<<dim3(n_chunks, SLHIP_NUM_LIGHTS), 256, 0, stream>>>(
+            *pool, d_scenes, d_draws, d_chunks, S, reinterpret_cast<unsigned*>(scratch->d_shadow),
+            scratch->d_queue, scratch->queue_capacity);
+        k_shadow_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, S,
+                                                 reinterpret_cast<unsigned*>(scratch->d_shadow), scratch->d_queue,
+                                                 scratch->queue_capacity);
+        SLHIP_LAUNCH_CHECK();
+    }
+
+    // main pass: visibility
+    SLHIP_CHECK(hipMemsetAsync(scratch->d_vis, 0xFF, (size_t)n_scenes * P * 8, stream));
+    SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
+    if (n_chunks > 0) {
+        k_raster<<<n_chunks, 256, 0, stream>>>(*pool, d_scenes, d_draws, d_chunks, W, H, d_depth_peel,
+                                               reinterpret_cast<unsigned long long*>(scratch->d_vis),
+                                               scratch->d_queue, scratch->queue_capacity);
+        k_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, W, H,
+                                          reinterpret_cast<unsigned long long*>(scratch->d_vis), scratch->d_queue,
+                                          scratch->queue_capacity);
+        SLHIP_LAUNCH_CHECK();
+    }
+
+    // deferred shade.  Auto exposure is decided per scene on the device; the host only
+    // knows whether ANY post pass is needed, so inline tone mapping is used only when the
+    // caller guarantees manual exposure through the flag below.
+    ShadeParams prm;
+    prm.W = W; prm.H = H; prm.flags = flags; prm.S = S;
+    prm.inline_tonemap = 0;
+    prm.want_lum = want_rgb ? 1 : 0;
+    float* hdr0 = want_rgb ? scratch->d_hdr : nullptr;
+    float* hdr1 = want_rgb ? scratch->d_hdr + 4 * (size_t)n_scenes * P : nullptr;
+    k_shade<<<pix_blocks, 256, 0, stream>>>(*pool, d_scenes, d_draws, prm,
+                                            reinterpret_cast<const unsigned long long*>(scratch->d_vis), *out, hdr0,
+                                            shadows ? scratch->d_shadow : nullptr, scratch->d_lum);
+    SLHIP_LAUNCH_CHECK();
+
+    if (want_rgb) {
+        const float* tm_in = hdr0;
+        if (ssao) {
+            k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, W, H, out->d_cam_coord, out->d_normals, scratch->d_ao);
+            k_ssao_apply<<<pix_blocks, 256, 0, stream>>>(W, H, hdr0, scratch->d_ao, out->d_cam_coord, hdr1);
+            tm_in = hdr1;
+        }
+        k_tonemap<<<pix_blocks, 256, 0, stream>>>(d_scenes, W, H, tm_in, scratch->d_lum, out->d_rgb);
+        SLHIP_LAUNCH_CHECK();
+    }
+    return 0;
+}

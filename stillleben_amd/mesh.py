@@ -1,0 +1,253 @@
+"""sl.Mesh -- host-side mirror of the reference's Mesh (include/stillleben/mesh.h:47-304,
+src/mesh.cpp, python/src/py_mesh.cpp:25-67,357-514)."""
+import enum
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import _loaders
+from ._math import as_mat4, f32
+
+
+class Range3D:
+    """Axis-aligned box (Magnum::Range3D as exposed by python/src/py_magnum.cpp)."""
+
+    def __init__(self, mn, mx):
+        self._min = np.asarray(mn, dtype=np.float32)
+        self._max = np.asarray(mx, dtype=np.float32)
+
+    @property
+    def min(self):
+        return torch.from_numpy(self._min.copy())
+
+    @property
+    def max(self):
+        return torch.from_numpy(self._max.copy())
+
+    @property
+    def center(self):
+        return torch.from_numpy(((self._min + self._max) / f32(2.0)).astype(np.float32))
+
+    @property
+    def size(self):
+        return torch.from_numpy((self._max - self._min).astype(np.float32))
+
+    @property
+    def diagonal(self):
+        d = (self._max - self._min).astype(np.float32)
+        return float(np.sqrt(np.dot(d, d)))
+
+    # numpy-side helpers used inside the package
+    def np_center(self):
+        return ((self._min + self._max) / f32(2.0)).astype(np.float32)
+
+    def np_size(self):
+        return (self._max - self._min).astype(np.float32)
+
+    def np_diagonal(self):
+        d = self.np_size()
+        return f32(np.sqrt(np.dot(d, d)))
+
+    def corners(self):
+        mn, mx = self._min, self._max
+        return np.array([[x, y, z] for z in (mn[2], mx[2]) for y in (mn[1], mx[1]) for x in (mn[0], mx[0])],
+                        dtype=np.float32)
+
+    def __repr__(self):
+        return "Range3D(min=%s, max=%s)" % (self._min.tolist(), self._max.tolist())
+
+
+class Mesh:
+    class Flag(enum.IntFlag):
+        NONE = 0
+        PHYSICS_FORCE_CONVEX_HULL = 1
+
+    def __init__(self, filename, visual=True, physics=True, flags=Flag.NONE):
+        from ._context import require_context
+
+        require_context()
+        self._filename = str(filename)  # accepts str or pathlib.Path (py_mesh.cpp:25-34)
+        self._flags = Mesh.Flag(int(flags))
+        self._data = _loaders.load_any(self._filename)
+        self._class_index = 1  # mesh.h:300
+        self._scale = f32(1.0)
+        self._pretransform_rigid = np.eye(4, dtype=np.float32)
+        self._pretransform = np.eye(4, dtype=np.float32)
+        self._raw_bbox = None
+        self._hulls = None
+        self._slot = None       # engine registration (render)
+        self._version = 0       # bumped when vertex data changes
+        pre = self._filename + ".pretransform"
+        self._update_bounding_box()
+        if os.path.exists(pre):  # mesh.cpp:888-921
+            self.pretransform = np.loadtxt(pre, dtype=np.float32).reshape(4, 4)
+        if physics:
+            self._load_physics()
+
+    @staticmethod
+    def load_threaded(filenames, visual=True, physics=True, flags=()):
+        flags = list(flags)
+        if flags and len(flags) != len(filenames):
+            raise ValueError("flags must be empty or have the same length as filenames")
+
+        def job(i):
+            return Mesh(filenames[i], visual, physics, flags[i] if flags else Mesh.Flag.NONE)
+
+        from ._context import require_context
+
+        require_context()
+        with ThreadPoolExecutor(max_workers=max(1, (os.cpu_count() or 2))) as ex:
+            return list(ex.map(job, range(len(filenames))))
+
+    # ---- geometry ------------------------------------------------------------------------
+    def _update_bounding_box(self):  # mesh.cpp:1001-1018
+        p = self._data.positions
+        self._raw_bbox = (p.min(axis=0).astype(np.float32), p.max(axis=0).astype(np.float32))
+
+    def _update_pretransform(self):  # mesh.cpp:1045-1048
+        s = np.diag([self._scale, self._scale, self._scale, f32(1.0)]).astype(np.float32)
+        self._pretransform = (s @ self._pretransform_rigid).astype(np.float32)
+
+    @property
+    def bbox(self):
+        # quirk q6: only min and max corners are transformed (mesh.cpp:1075-1081)
+        m = self._pretransform
+        lo = m[:3, :3] @ self._raw_bbox[0] + m[:3, 3]
+        hi = m[:3, :3] @ self._raw_bbox[1] + m[:3, 3]
+        return Range3D(lo, hi)
+
+    def center_bbox(self):  # mesh.cpp:1020-1024
+        c = (self._raw_bbox[0] + self._raw_bbox[1]) / f32(2.0)
+        self._pretransform_rigid[:3, 3] = -(self._pretransform_rigid[:3, :3] @ c)
+        self._update_pretransform()
+
+    def scale_to_bbox_diagonal(self, target_diagonal, mode="exact"):  # mesh.cpp:1026-1043
+        d = (self._raw_bbox[1] - self._raw_bbox[0]).astype(np.float32)
+        diagonal = f32(np.sqrt(np.dot(d, d)))
+        scale = f32(target_diagonal) / diagonal
+        if mode == "exact":
+            self._scale = f32(scale)
+        elif mode == "order_of_magnitude":
+            self._scale = f32(10.0 ** np.round(np.log10(float(scale))))
+        else:
+            raise ValueError("invalid value for mode argument")
+        self._update_pretransform()
+
+    @property
+    def pretransform(self):
+        return torch.from_numpy(self._pretransform.copy())
+
+    @pretransform.setter
+    def pretransform(self, m):  # mesh.cpp:1050-1073
+        m = as_mat4(m)
+        u, w, vt = np.linalg.svd(m[:3, :3].astype(np.float64))
+        if w.max() - w.min() > 1e-5:
+            raise ValueError("Scaling is not uniform")
+        self._scale = f32((w.max() + w.min()) / 2.0)
+        self._pretransform_rigid = np.eye(4, dtype=np.float32)
+        self._pretransform_rigid[:3, :3] = (u @ vt).astype(np.float32)
+        self._pretransform_rigid[:3, 3] = (f32(1.0) / self._scale) * m[:3, 3]
+        self._update_pretransform()
+
+    @property
+    def class_index(self):
+        return self._class_index
+
+    @class_index.setter
+    def class_index(self, v):
+        v = int(v)
+        if v < 0 or v > 65535:  # mesh.cpp:1083-1089
+            raise ValueError("Mesh::setClassIndex(): out of range")
+        self._class_index = v
+
+    @property
+    def filename(self):
+        return self._filename
+
+    @property
+    def points(self):
+        return torch.from_numpy(self._data.positions.copy())
+
+    @property
+    def normals(self):
+        return torch.from_numpy(self._data.normals.copy())
+
+    @property
+    def faces(self):
+        return torch.from_numpy(self._data.indices.astype(np.int32))
+
+    @property
+    def colors(self):
+        return torch.from_numpy(self._data.colors.copy())
+
+    # ---- vertex mutation (mesh.cpp:747-886); vertex_indices are the 1-based ids the
+    # renderer outputs (mesh.cpp:834 subtracts 1) ---------------------------------------
+    def _np(self, t, shape_tail):
+        if hasattr(t, "detach"):
+            t = t.detach().cpu().numpy()
+        a = np.asarray(t)
+        if shape_tail is not None:
+            a = a.reshape((-1,) + shape_tail)
+        return a
+
+    def _touch(self):
+        self._version += 1
+        self._update_bounding_box()
+
+    def update_positions(self, vertex_indices, position_update):
+        vi = self._np(vertex_indices, None).astype(np.int64).reshape(-1) - 1
+        self._data.positions[vi] = self._np(position_update, (3,)).astype(np.float32)
+        self._touch()
+
+    def update_colors(self, vertex_indices, color_update):
+        vi = self._np(vertex_indices, None).astype(np.int64).reshape(-1) - 1
+        self._data.colors[vi] = self._np(color_update, (4,)).astype(np.float32)
+        self._touch()
+
+    def update_positions_and_colors(self, vertex_indices, position_update, color_update):
+        self.update_positions(vertex_indices, position_update)
+        self.update_colors(vertex_indices, color_update)
+
+    def set_new_positions(self, new_positions):
+        p = self._np(new_positions, (3,)).astype(np.float32)
+        if p.shape != self._data.positions.shape:
+            raise ValueError("set_new_positions: shape mismatch")
+        self._data.positions = p.copy()
+        self._touch()
+
+    def set_new_colors(self, new_colors):
+        c = self._np(new_colors, (4,)).astype(np.float32)
+        if c.shape != self._data.colors.shape:
+            raise ValueError("set_new_colors: shape mismatch")
+        self._data.colors = c.copy()
+        self._touch()
+
+    # ---- physics shapes (mesh.cpp:304-533) -------------------------------------------------
+    def _load_physics(self):
+        if self._hulls is None:
+            from . import hulls
+
+            self._hulls = hulls.hulls_for_mesh(self)
+        return self._hulls
+
+    @property
+    def physics_mesh_data(self):
+        out = []
+        for h in self._load_physics():
+            out.append({"positions": torch.from_numpy(h.vertices.copy()),
+                        "indices": torch.from_numpy(h.triangles.astype(np.int32))})
+        return out
+
+    def dump_physics_meshes(self, directory):
+        os.makedirs(directory, exist_ok=True)
+        for i, h in enumerate(self._load_physics()):
+            with open(os.path.join(directory, "physics_%03d.ply" % i), "w") as f:
+                f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+                        "property float z\nelement face %d\nproperty list uchar int vertex_indices\nend_header\n"
+                        % (len(h.vertices), len(h.triangles)))
+                for v in h.vertices:
+                    f.write("%g %g %g\n" % tuple(v))
+                for t in h.triangles:
+                    f.write("3 %d %d %d\n" % tuple(t))

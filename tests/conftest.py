@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FIXTURES = os.path.join(ROOT, "tests", "fixtures")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu`)")
+
+
+@pytest.fixture(scope="session")
+def sl():
+    import stillleben_amd as sl
+
+    sl.init()
+    return sl
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle
+
+    oracle.build()
+    return oracle
