@@ -165,6 +165,94 @@ int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uint32_t heigh
                                uint64_t bytes_out[6]);
 
 /* ---------------------------------------------------------------------------------------------
+ * Settle half (replaces PhysX as driven by Scene::simulateTableTopScene, scene.cpp:612-759)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Convex collision shape: a vertex cloud in the OBJECT frame (mesh pretransform incl. scale
+ * already applied -- the counterpart of PxConvexMeshGeometry + PxMeshScale + shape local pose,
+ * reference src/object.cpp:173-204).  <= 64 vertices (VHACD.h:235).                          */
+#define SLHIP_MAX_HULL_VERTS 64
+typedef struct {
+    uint32_t vtx_begin;      /* first vertex in the hull vertex pool (float4 each)            */
+    uint32_t vtx_count;
+    uint32_t _pad[2];
+    float sphere[4];         /* bounding sphere: centre (object frame), radius                */
+} slhip_hull;                /* 32 bytes */
+
+#define SLHIP_BODY_STATIC   1u   /* Object::isStatic -> eKINEMATIC (object.cpp:515-520)       */
+#define SLHIP_BODY_ASLEEP   2u
+
+/* Rigid body state.  `pose` is the object pose exactly as sl.Object.pose() returns it.       */
+typedef struct {
+    float pose[16];
+    float lin_vel[4];        /* velocity of the centre of mass, world frame                   */
+    float ang_vel[4];
+    float com[4];            /* centre of mass, object frame                                  */
+    float inv_inertia[12];   /* inverse inertia about the COM in object axes, 3 rows padded   */
+    float inv_mass;          /* 0 for static bodies                                           */
+    float mu_s, mu_d, restitution;    /* material (context.cpp:250-252 / object.cpp:565-605)  */
+    float bsphere[4];        /* bounding sphere of all hulls (object frame centre, radius)    */
+    float bbox_center[4];    /* mesh bbox centre (object frame); w = bbox diagonal / 2        */
+    float max_lin_vel;       /* Object::setLinearVelocityLimit (object.cpp:259-264)           */
+    float separation;        /* out: min contact separation of the last step (scene.cpp:73-116) */
+    float wake_counter;
+    uint32_t flags;
+    uint32_t hull_begin, hull_end;
+    int32_t stuck_counter;
+    uint32_t _pad;
+} slhip_body;                /* 240 bytes */
+
+/* One scene of the settle batch: bodies [body_begin, body_end).                              */
+typedef struct {
+    uint32_t body_begin, body_end;
+    uint32_t has_plane;      /* 1: static table box, top face at z = plane_z (scene.cpp:629-663) */
+    float plane_z;
+} slhip_settle_scene;
+
+/* Constants of the step (defaults == the reference's call sites).   */
+typedef struct {
+    float dt;                    /* 0.01  = 1/25/4  (scene.cpp:681-684)                      */
+    uint32_t substeps;           /* 4                                                         */
+    uint32_t frames;             /* 100   (scene.cpp:720)                                     */
+    uint32_t pos_iters, vel_iters; /* 4, 4 (object.cpp:209)                                  */
+    float gravity[3];            /* 0,0,-9.81 (scene.cpp:157,665)                             */
+    float contact_offset;        /* 0.004 = 0.02 * tolerance length 0.2 [ext]                 */
+    float rest_offset;           /* 0.0015 (object.cpp:201); the plane box has 0              */
+    float bounce_threshold;      /* 2.0   = 0.2 * tolerance speed 10 [ext]                    */
+    float sleep_threshold;       /* 5e-3  = 5e-5 * speed^2 [ext]                              */
+    float wake_time;             /* 0.4 s [ext]                                               */
+    float angular_damping;       /* 0.05 [ext]                                                */
+    float max_angular_velocity;  /* 100 rad/s [ext]                                           */
+    float plane_mu_s, plane_mu_d, plane_restitution; /* 0.5, 0.5, 0 (scene.cpp:645)          */
+    float redrop_z;              /* -0.5 (scene.cpp:746)                                      */
+    float stuck_separation;      /* -0.01 (scene.cpp:748)                                     */
+    int32_t stuck_frames;        /* 10 = 0.4 s * 25 FPS (scene.cpp:750)                       */
+    uint32_t tabletop;           /* 1: run the redrop logic of simulateTableTopScene          */
+} slhip_settle_params;
+
+/* per-scene scratch (device), sized by slhip_settle_scratch_bytes */
+#define SLHIP_MAX_BODIES     64   /* bodies per scene                                          */
+#define SLHIP_MAX_HULL_PAIRS 512  /* candidate hull pairs per scene and step                   */
+
+/* Steps every scene of the batch `frames * substeps` times (one persistent workgroup per
+ * scene, no host round trip), including the redrop heuristic when params->tabletop.
+ * d_bodies is updated in place (pose, velocities, separation).  Replaces the hot loop of
+ * Scene::simulateTableTopScene (scene.cpp:720-756) and, with frames=substeps=1 and
+ * tabletop=0, Scene::simulate(dt) (scene.cpp:903-912).                                       */
+int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
+                 slhip_body* d_bodies, const slhip_hull* d_hulls, const float* d_hull_verts,
+                 const slhip_settle_params* params, void* d_scratch, uint64_t scratch_bytes,
+                 void* stream);
+int slhip_settle_scratch_bytes(uint32_t n_scenes, uint64_t* bytes_out);
+
+/* Boolean any-overlap query per body against all OTHER bodies of its scene (and the plane if
+ * present): d_flags[body] = 1 if it collides.  Replaces Scene::isObjectColliding /
+ * checkCollisions (scene.cpp:355-385, :914-925).                                             */
+int slhip_overlap_any(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
+                      const slhip_body* d_bodies, const slhip_hull* d_hulls,
+                      const float* d_hull_verts, uint8_t* d_flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Library
  * ------------------------------------------------------------------------------------------- */
 int slhip_abi_version(void);

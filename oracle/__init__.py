@@ -83,3 +83,40 @@ def ssao_tables():
     kern = np.zeros(192, np.float32)
     L.slref_ssao_tables(_p(noise), _p(kern))
     return noise, kern
+
+
+def settle(srec, bodies, hulls, hull_verts, params):
+    """Runs the CPU reference stepper in place on `bodies` (numpy structured array)."""
+    L = lib()
+    srec = np.ascontiguousarray(srec)
+    hulls = np.ascontiguousarray(hulls)
+    hull_verts = np.ascontiguousarray(hull_verts, dtype=np.float32)
+    params = np.ascontiguousarray(params)
+    assert bodies.flags["C_CONTIGUOUS"]
+    L.slref_settle.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    st = L.slref_settle(_p(srec), len(srec), _p(bodies), _p(hulls), _p(hull_verts), _p(params))
+    if st != 0:
+        raise RuntimeError("slref_settle failed: %d" % st)
+    return bodies
+
+
+def overlap_any(srec, bodies, hulls, hull_verts):
+    L = lib()
+    srec = np.ascontiguousarray(srec)
+    flags = np.zeros(len(bodies), np.uint8)
+    L.slref_overlap_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    st = L.slref_overlap_any(_p(srec), len(srec), _p(np.ascontiguousarray(bodies)), _p(np.ascontiguousarray(hulls)),
+                             _p(np.ascontiguousarray(hull_verts, dtype=np.float32)), _p(flags))
+    if st != 0:
+        raise RuntimeError("slref_overlap_any failed: %d" % st)
+    return flags
+
+
+def debug_contacts(srec, bodies, hulls, hull_verts, params, max_rows=4096):
+    L = lib()
+    out = np.zeros((max_rows, 12), np.float32)
+    L.slref_debug_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    n = L.slref_debug_contacts(_p(np.ascontiguousarray(srec)), _p(np.ascontiguousarray(bodies)),
+                               _p(np.ascontiguousarray(hulls)), _p(np.ascontiguousarray(hull_verts, dtype=np.float32)),
+                               _p(np.ascontiguousarray(params)), _p(out), max_rows)
+    return out[:n]

@@ -1,0 +1,1021 @@
+/*
+ * settle_ref.c -- ORACLE (test infrastructure, not product code).
+ *
+ * Scalar CPU restatement of the rigid-body stepping the reference delegates to PhysX 4.1
+ * (NVIDIAGameWorks/PhysX @ 4050bbfdc2699dfab7edbf0393df8ff96bbe06c5, not vendored in
+ * /root/reference, see contrib/physx/CMakeLists.txt:26-29) as configured by the reference's
+ * call sites:
+ *   Scene::simulateTableTopScene   /root/reference/src/scene.cpp:612-759  (settle loop, redrop)
+ *   Scene::Scene                   src/scene.cpp:134-173                  (gravity, flags)
+ *   Object::loadPhysics            src/object.cpp:142-213                 (shapes, rest offset,
+ *                                                                          4+4 iterations)
+ *   Context                        src/context.cpp:236-252                (tolerances, material)
+ *   SimulationCallback::onContact  src/scene.cpp:73-116                   (min separation)
+ *
+ * PARITY STATUS: "parity unpinned".  PhysX's arithmetic is third-party code that is absent
+ * from the tree and the reference's tests pin only a free-flight step (tests/test_python.py:
+ * 111-130) -- checked in tests/test_oracle_settle.py together with the KATs k1..k7 of
+ * SURVEY.md 8c.  The ALGORITHM below (documented [ext] behaviour of PhysX: speculative
+ * contacts inside contactOffset, rest offset, PGS with 4 biased position + 4 unbiased velocity
+ * iterations, Coulomb friction with static/dynamic coefficients, restitution above the bounce
+ * threshold, semi-implicit Euler, sleeping) is this repository's contract; the HIP kernel must
+ * reproduce it BIT-FOR-BIT, which is possible because
+ *   - only + - * / sqrt and explicit fmaf are used (no libm transcendentals),
+ *   - every reduction has a fixed order (first-maximum argmax, ordered lists),
+ *   - the Gauss-Seidel order is defined by a greedy colouring of the body-pair groups and is
+ *     independent of the number of lanes.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/slhip.h"
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } quat;
+
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 scale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 neg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline float dot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v3 cross(v3 a, v3 b)
+{
+    return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* a + b*s */
+static inline v3 madd(v3 a, v3 b, float s) { return V(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)); }
+
+typedef struct { float m[9]; } m3; /* row-major */
+
+static inline v3 m3_mul(const m3* M, v3 v)
+{
+    return V(fmaf(M->m[2], v.z, fmaf(M->m[1], v.y, M->m[0] * v.x)),
+             fmaf(M->m[5], v.z, fmaf(M->m[4], v.y, M->m[3] * v.x)),
+             fmaf(M->m[8], v.z, fmaf(M->m[7], v.y, M->m[6] * v.x)));
+}
+static inline v3 m3_tmul(const m3* M, v3 v) /* M^T v */
+{
+    return V(fmaf(M->m[6], v.z, fmaf(M->m[3], v.y, M->m[0] * v.x)),
+             fmaf(M->m[7], v.z, fmaf(M->m[4], v.y, M->m[1] * v.x)),
+             fmaf(M->m[8], v.z, fmaf(M->m[5], v.y, M->m[2] * v.x)));
+}
+
+static inline quat quat_normalize(quat q)
+{
+    float n = sqrtf(fmaf(q.w, q.w, fmaf(q.z, q.z, fmaf(q.y, q.y, q.x * q.x))));
+    quat r = {q.x / n, q.y / n, q.z / n, q.w / n};
+    return r;
+}
+
+static inline void quat_to_m3(quat q, m3* R)
+{
+    float x = q.x, y = q.y, z = q.z, w = q.w;
+    R->m[0] = 1.0f - 2.0f * (y * y + z * z); R->m[1] = 2.0f * (x * y - z * w); R->m[2] = 2.0f * (x * z + y * w);
+    R->m[3] = 2.0f * (x * y + z * w); R->m[4] = 1.0f - 2.0f * (x * x + z * z); R->m[5] = 2.0f * (y * z - x * w);
+    R->m[6] = 2.0f * (x * z - y * w); R->m[7] = 2.0f * (y * z + x * w); R->m[8] = 1.0f - 2.0f * (x * x + y * y);
+}
+
+static inline quat m3_to_quat(const m3* R)
+{
+    const float* m = R->m;
+    float t = m[0] + m[4] + m[8];
+    quat q;
+    if (t > 0.0f) {
+        float s = sqrtf(t + 1.0f) * 2.0f;
+        q.w = 0.25f * s; q.x = (m[7] - m[5]) / s; q.y = (m[2] - m[6]) / s; q.z = (m[3] - m[1]) / s;
+    } else if (m[0] > m[4] && m[0] > m[8]) {
+        float s = sqrtf(1.0f + m[0] - m[4] - m[8]) * 2.0f;
+        q.w = (m[7] - m[5]) / s; q.x = 0.25f * s; q.y = (m[1] + m[3]) / s; q.z = (m[2] + m[6]) / s;
+    } else if (m[4] > m[8]) {
+        float s = sqrtf(1.0f + m[4] - m[0] - m[8]) * 2.0f;
+        q.w = (m[2] - m[6]) / s; q.x = (m[1] + m[3]) / s; q.y = 0.25f * s; q.z = (m[5] + m[7]) / s;
+    } else {
+        float s = sqrtf(1.0f + m[8] - m[0] - m[4]) * 2.0f;
+        q.w = (m[3] - m[1]) / s; q.x = (m[2] + m[6]) / s; q.y = (m[5] + m[7]) / s; q.z = 0.25f * s;
+    }
+    return quat_normalize(q);
+}
+
+static inline quat quat_mul(quat a, quat b)
+{
+    quat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* working state                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    v3 x;          /* centre of mass, world */
+    quat q;
+    m3 R;
+    v3 t;          /* object-frame origin in world: x - R com */
+    v3 v, w;
+    m3 Iinv_w;     /* world inverse inertia */
+    float inv_mass;
+    int dynamic;   /* moves this step (not static, not asleep) */
+} wbody;
+
+typedef struct {
+    int a, b;      /* body indices within the scene; b = -1: the plane */
+    v3 ra, rb;     /* contact arms from the COMs */
+    v3 n, t1, t2;  /* n points from B to A */
+    float sep;     /* signed distance, before subtracting the rest offset */
+    float rest;
+    float kn, kt1, kt2;   /* inverse effective masses' reciprocals (i.e. effective masses) */
+    float ln, lt1, lt2;   /* accumulated impulses */
+    float vn0;            /* normal velocity before the solve (restitution) */
+    float mu_s, mu_d, e;
+    int valid;
+} contact;
+
+#define MAX_CONTACTS_PER_HP 4
+#define PLANE_SLOTS 4
+
+typedef struct {
+    /* hull pair list */
+    int n_hp;
+    int hp_ba[SLHIP_MAX_HULL_PAIRS], hp_bb[SLHIP_MAX_HULL_PAIRS]; /* bodies */
+    int hp_ha[SLHIP_MAX_HULL_PAIRS], hp_hb[SLHIP_MAX_HULL_PAIRS]; /* global hull ids */
+    /* constraint groups: contiguous contact ranges sharing a body pair */
+    int n_groups;
+    int g_begin[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES], g_end[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES];
+    int g_a[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES], g_b[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES];
+    int g_color[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES];
+    int n_colors;
+    contact c[(SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES) * MAX_CONTACTS_PER_HP];
+    wbody wb[SLHIP_MAX_BODIES];
+} scene_ws;
+
+/* ------------------------------------------------------------------------------------------ */
+/* support mapping + GJK distance                                                              */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* verts; /* float4 each, object frame */
+    int count;
+    m3 R;
+    v3 t;
+} shape;
+
+static inline v3 support(const shape* s, v3 d)
+{
+    v3 dl = m3_tmul(&s->R, d);
+    int best = 0;
+    float bd = dot(V(s->verts[0], s->verts[1], s->verts[2]), dl);
+    for (int i = 1; i < s->count; ++i) {
+        float dd = dot(V(s->verts[4 * i], s->verts[4 * i + 1], s->verts[4 * i + 2]), dl);
+        if (dd > bd) { bd = dd; best = i; }
+    }
+    v3 p = V(s->verts[4 * best], s->verts[4 * best + 1], s->verts[4 * best + 2]);
+    return add(m3_mul(&s->R, p), s->t);
+}
+
+typedef struct { v3 w, a, b; } sv; /* simplex vertex: w = a - b */
+
+/* closest point to the origin on segment / triangle; returns barycentric weights and the mask
+   of vertices that stay in the simplex (Ericson, Real-Time Collision Detection 5.1.2/5.1.5) */
+static int closest_segment(const sv* s, float* l)
+{
+    v3 a = s[0].w, b = s[1].w;
+    v3 ab = sub(b, a);
+    float t = dot(neg(a), ab);
+    if (t <= 0.0f) { l[0] = 1.0f; l[1] = 0.0f; return 1; }
+    float den = dot(ab, ab);
+    if (t >= den) { l[0] = 0.0f; l[1] = 1.0f; return 2; }
+    t = t / den;
+    l[0] = 1.0f - t; l[1] = t;
+    return 3;
+}
+
+static int closest_triangle(v3 a, v3 b, v3 c, float* l)
+{
+    v3 ab = sub(b, a), ac = sub(c, a), ap = neg(a);
+    float d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0.0f && d2 <= 0.0f) { l[0] = 1; l[1] = 0; l[2] = 0; return 1; }
+    v3 bp = neg(b);
+    float d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0.0f && d4 <= d3) { l[0] = 0; l[1] = 1; l[2] = 0; return 2; }
+    float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+        float v = d1 / (d1 - d3);
+        l[0] = 1.0f - v; l[1] = v; l[2] = 0; return 3;
+    }
+    v3 cp = neg(c);
+    float d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0.0f && d5 <= d6) { l[0] = 0; l[1] = 0; l[2] = 1; return 4; }
+    float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+        float w = d2 / (d2 - d6);
+        l[0] = 1.0f - w; l[1] = 0; l[2] = w; return 5;
+    }
+    float va = d3 * d6 - d5 * d4;
+    if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+        float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        l[0] = 0; l[1] = 1.0f - w; l[2] = w; return 6;
+    }
+    float denom = 1.0f / (va + vb + vc);
+    float v = vb * denom, w = vc * denom;
+    l[0] = 1.0f - v - w; l[1] = v; l[2] = w;
+    return 7;
+}
+
+static inline v3 comb3(v3 a, v3 b, v3 c, const float* l)
+{
+    return madd(madd(scale(a, l[0]), b, l[1]), c, l[2]);
+}
+
+/* origin outside the plane of (a,b,c) on the side opposite to d? */
+static inline int outside_plane(v3 a, v3 b, v3 c, v3 d)
+{
+    v3 n = cross(sub(b, a), sub(c, a));
+    float sp = dot(neg(a), n);
+    float sd = dot(sub(d, a), n);
+    return sp * sd < 0.0f || sd == 0.0f; /* degenerate tetra: treat as outside */
+}
+
+/* Reduces the simplex to the sub-simplex closest to the origin; returns the new size (0 = the
+   origin is inside a tetrahedron, i.e. overlap) and writes the closest point to *v. */
+static int reduce_simplex(sv* s, int n, float* lam, v3* v)
+{
+    if (n == 1) { lam[0] = 1.0f; *v = s[0].w; return 1; }
+    if (n == 2) {
+        float l[2];
+        int mask = closest_segment(s, l);
+        *v = madd(scale(s[0].w, l[0]), s[1].w, l[1]);
+        if (mask == 1) { lam[0] = 1.0f; return 1; }
+        if (mask == 2) { s[0] = s[1]; lam[0] = 1.0f; return 1; }
+        lam[0] = l[0]; lam[1] = l[1];
+        return 2;
+    }
+    if (n == 3) {
+        float l[3];
+        int mask = closest_triangle(s[0].w, s[1].w, s[2].w, l);
+        *v = comb3(s[0].w, s[1].w, s[2].w, l);
+        int k = 0;
+        for (int i = 0; i < 3; ++i)
+            if (mask & (1 << i)) { s[k] = s[i]; lam[k] = l[i]; ++k; }
+        return k;
+    }
+    /* tetrahedron: test the four faces */
+    static const int F[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}};
+    float best = 3.0e38f;
+    int best_mask = 0, best_face = -1;
+    float best_l[3] = {0, 0, 0};
+    v3 best_v = V(0, 0, 0);
+    for (int f = 0; f < 4; ++f) {
+        v3 a = s[F[f][0]].w, b = s[F[f][1]].w, c = s[F[f][2]].w, d = s[F[f][3]].w;
+        if (!outside_plane(a, b, c, d)) continue;
+        float l[3];
+        int mask = closest_triangle(a, b, c, l);
+        v3 q = comb3(a, b, c, l);
+        float dd = dot(q, q);
+        if (dd < best) { best = dd; best_mask = mask; best_face = f; best_l[0] = l[0]; best_l[1] = l[1]; best_l[2] = l[2]; best_v = q; }
+    }
+    if (best_face < 0) return 0; /* origin inside */
+    sv t[3] = {s[F[best_face][0]], s[F[best_face][1]], s[F[best_face][2]]};
+    int k = 0;
+    for (int i = 0; i < 3; ++i)
+        if (best_mask & (1 << i)) { s[k] = t[i]; lam[k] = best_l[i]; ++k; }
+    *v = best_v;
+    return k;
+}
+
+/* GJK distance.  Returns 1 and (pa, pb, dist) if the shapes are separated by more than ~1e-6,
+   0 if they touch/overlap. */
+#define GJK_MAX_ITER 32
+static int gjk_distance(const shape* A, const shape* B, v3 init_dir, v3* pa, v3* pb, float* dist)
+{
+    sv s[4];
+    float lam[4] = {1, 0, 0, 0};
+    int n = 0;
+    v3 v = init_dir;
+    if (dot(v, v) < 1e-12f) v = V(1, 0, 0);
+    float vv = dot(v, v);
+    for (int it = 0; it < GJK_MAX_ITER; ++it) {
+        sv w;
+        w.a = support(A, neg(v));
+        w.b = support(B, v);
+        w.w = sub(w.a, w.b);
+        if (n > 0) {
+            /* no progress towards the origin: v is the closest point */
+            float vw = dot(v, w.w);
+            if (vv - vw <= 1e-6f * vv) break;
+            int dup = 0;
+            for (int i = 0; i < n; ++i)
+                if (s[i].w.x == w.w.x && s[i].w.y == w.w.y && s[i].w.z == w.w.z) dup = 1;
+            if (dup) break;
+        }
+        s[n++] = w;
+        v3 nv;
+        int nn = reduce_simplex(s, n, lam, &nv);
+        if (nn == 0) return 0;
+        float nvv = dot(nv, nv);
+        if (n > 1 && nvv >= vv && it > 0) { /* numerical stall: keep the previous result */
+            n = nn; v = nv; vv = nvv; break;
+        }
+        n = nn; v = nv; vv = nvv;
+        if (vv < 1e-12f) return 0;
+    }
+    if (n == 0) return 0;
+    v3 a = V(0, 0, 0), b = V(0, 0, 0);
+    for (int i = 0; i < n; ++i) { a = madd(a, s[i].a, lam[i]); b = madd(b, s[i].b, lam[i]); }
+    *pa = a; *pb = b;
+    float d = sqrtf(vv);
+    *dist = d;
+    return d > 1e-6f;
+}
+
+/* tangent basis (deterministic) */
+static inline void tangents(v3 n, v3* t1, v3* t2)
+{
+    v3 a;
+    if (fabsf(n.x) > 0.57735f) a = V(n.y, -n.x, 0.0f);
+    else a = V(0.0f, n.z, -n.y);
+    float l = sqrtf(dot(a, a));
+    *t1 = scale(a, 1.0f / l);
+    *t2 = cross(n, *t1);
+}
+
+/* crude penetration fallback when GJK reports overlap: least overlap among 7 fixed axes */
+static void overlap_fallback(const shape* A, const shape* B, v3 ca, v3 cb, v3* n, float* sep, v3* pa, v3* pb)
+{
+    v3 axes[7];
+    v3 c = sub(ca, cb);
+    float cl = sqrtf(dot(c, c));
+    axes[0] = cl > 1e-6f ? scale(c, 1.0f / cl) : V(0, 0, 1);
+    axes[1] = V(1, 0, 0); axes[2] = V(-1, 0, 0); axes[3] = V(0, 1, 0);
+    axes[4] = V(0, -1, 0); axes[5] = V(0, 0, 1); axes[6] = V(0, 0, -1);
+    float best = -3.0e38f;
+    for (int i = 0; i < 7; ++i) {
+        v3 a = support(A, neg(axes[i])); /* lowest point of A along the axis */
+        v3 b = support(B, axes[i]);      /* highest point of B */
+        float s = dot(sub(a, b), axes[i]); /* negative = overlap depth */
+        if (s > best) { best = s; *n = axes[i]; *pa = a; *pb = b; }
+    }
+    *sep = best;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* contact generation                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+static void make_shape(const wbody* wb, const slhip_hull* h, const float* hull_verts, shape* s)
+{
+    s->verts = hull_verts + 4 * (size_t)h->vtx_begin;
+    s->count = (int)h->vtx_count;
+    s->R = wb->R;
+    s->t = wb->t;
+}
+
+/* keeps at most 4 of n candidate points (p on A, separation): the deepest, then the point
+   farthest from it, then the two extremes of the signed area -- where every metre of extra
+   separation costs DEPTH_WEIGHT metres of lateral reach, so that the true support points win
+   over far-away points that merely lie inside the contact band.  First-index tie break. */
+#define DEPTH_WEIGHT 30.0f
+static int reduce4(int n, const v3* p, const float* sep, v3 nrm, int* keep)
+{
+    if (n <= 4) { for (int i = 0; i < n; ++i) keep[i] = i; return n; }
+    int i0 = 0;
+    for (int i = 1; i < n; ++i) if (sep[i] < sep[i0]) i0 = i;
+    int i1 = -1; float best = -3.0e38f;
+    for (int i = 0; i < n; ++i) {
+        if (i == i0) continue;
+        v3 d = sub(p[i], p[i0]);
+        float pen = DEPTH_WEIGHT * (sep[i] - sep[i0]);
+        float score = sqrtf(dot(d, d)) - pen;
+        if (score > best) { best = score; i1 = i; }
+    }
+    int i2 = -1, i3 = -1; float mx = 0.0f, mn = 0.0f;
+    v3 e = sub(p[i1], p[i0]);
+    float el = sqrtf(dot(e, e));
+    for (int i = 0; i < n; ++i) {
+        if (i == i0 || i == i1) continue;
+        float a = dot(cross(e, sub(p[i], p[i0])), nrm);
+        float pen = DEPTH_WEIGHT * (sep[i] - sep[i0]) * el;
+        if (a - pen > mx) { mx = a - pen; i2 = i; }
+        if (a + pen < mn) { mn = a + pen; i3 = i; }
+    }
+    int k = 0;
+    keep[k++] = i0; keep[k++] = i1;
+    if (i2 >= 0) keep[k++] = i2;
+    if (i3 >= 0) keep[k++] = i3;
+    return k;
+}
+
+static void fill_contact(contact* c, int a, int b, const wbody* wa, const wbody* wbb, v3 pa, v3 pb, v3 n,
+                         float sep, float rest, float mu_s, float mu_d, float e)
+{
+    memset(c, 0, sizeof(*c));
+    c->a = a; c->b = b;
+    c->ra = sub(pa, wa->x);
+    c->rb = wbb ? sub(pb, wbb->x) : V(0, 0, 0);
+    c->n = n;
+    tangents(n, &c->t1, &c->t2);
+    c->sep = sep; c->rest = rest;
+    c->mu_s = mu_s; c->mu_d = mu_d; c->e = e;
+    c->valid = 1;
+}
+
+/* hull pair -> up to 4 contacts written to out[0..3]; returns min separation (or +inf) */
+static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int ia, int ib,
+                                const slhip_hull* ha, const slhip_hull* hb, const float* hull_verts,
+                                const slhip_settle_params* prm, float margin, contact* out)
+{
+    for (int i = 0; i < MAX_CONTACTS_PER_HP; ++i) out[i].valid = 0;
+    const wbody* wa = &wbs[ia];
+    const wbody* wb = &wbs[ib];
+    shape A, B;
+    make_shape(wa, ha, hull_verts, &A);
+    make_shape(wb, hb, hull_verts, &B);
+    v3 ca = add(m3_mul(&wa->R, V(ha->sphere[0], ha->sphere[1], ha->sphere[2])), wa->t);
+    v3 cb = add(m3_mul(&wb->R, V(hb->sphere[0], hb->sphere[1], hb->sphere[2])), wb->t);
+    v3 pa, pb, n;
+    float dist;
+    float rest = 2.0f * prm->rest_offset;
+    float mu_s = 0.5f * (bodies[ia].mu_s + bodies[ib].mu_s);
+    float mu_d = 0.5f * (bodies[ia].mu_d + bodies[ib].mu_d);
+    float e = 0.5f * (bodies[ia].restitution + bodies[ib].restitution);
+    if (!gjk_distance(&A, &B, sub(ca, cb), &pa, &pb, &dist)) {
+        float sep;
+        overlap_fallback(&A, &B, ca, cb, &n, &sep, &pa, &pb);
+        if (sep > 0.0f) sep = 0.0f;
+        fill_contact(&out[0], ia, ib, wa, wb, pa, pb, n, sep, rest, mu_s, mu_d, e);
+        return sep;
+    }
+    if (dist > margin) return 3.0e38f;
+    n = scale(sub(pa, pb), 1.0f / dist);
+
+    v3 cp[5], cq[5];
+    float cs[5];
+    int nc = 0;
+    cp[0] = pa; cq[0] = pb; cs[0] = dist; nc = 1;
+
+    /* perturbation manifold: tilt the smaller shape about 4 axes perpendicular to n */
+    int tilt_a = ha->sphere[3] <= hb->sphere[3];
+    float radius = tilt_a ? ha->sphere[3] : hb->sphere[3];
+    float ang = 2.0f * prm->contact_offset / radius; /* lifts the far rim by ~ the contact band */
+    if (ang > 0.2f) ang = 0.2f;
+    float lift = radius * ang;
+    float sh = 0.5f * ang;               /* sin(ang/2) ~ ang/2 */
+    float ch = sqrtf(1.0f - sh * sh);
+    v3 t1, t2;
+    tangents(n, &t1, &t2);
+    const wbody* wt = tilt_a ? wa : wb;
+    for (int k = 0; k < 4; ++k) {
+        v3 ax = (k == 0) ? t1 : (k == 1) ? t2 : (k == 2) ? neg(t1) : neg(t2);
+        quat dq = {ax.x * sh, ax.y * sh, ax.z * sh, ch};
+        quat q2 = quat_normalize(quat_mul(dq, wt->q));
+        shape T = tilt_a ? A : B;
+        quat_to_m3(q2, &T.R);
+        /* rotate about the shape's bounding-sphere centre so that the tilt is local */
+        v3 cl = tilt_a ? V(ha->sphere[0], ha->sphere[1], ha->sphere[2]) : V(hb->sphere[0], hb->sphere[1], hb->sphere[2]);
+        v3 cw = tilt_a ? ca : cb;
+        /* ... and back the tilted shape off along the normal by the rim lift so that the tilt
+           cannot create an overlap; separations are re-measured in the untilted pose below */
+        cw = madd(cw, n, tilt_a ? lift : -lift);
+        T.t = sub(cw, m3_mul(&T.R, cl));
+        v3 qa, qb;
+        float d2;
+        int ok = tilt_a ? gjk_distance(&T, &B, sub(ca, cb), &qa, &qb, &d2)
+                        : gjk_distance(&A, &T, sub(ca, cb), &qa, &qb, &d2);
+        if (!ok) continue;
+        /* map the witness on the tilted shape back to the untilted pose */
+        if (tilt_a) {
+            v3 loc = m3_tmul(&T.R, sub(qa, T.t));
+            qa = add(m3_mul(&A.R, loc), A.t);
+        } else {
+            v3 loc = m3_tmul(&T.R, sub(qb, T.t));
+            qb = add(m3_mul(&B.R, loc), B.t);
+        }
+        float s = dot(sub(qa, qb), n);
+        if (s > margin) continue;
+        /* lateral offset between the two witnesses must be small, else it is not a contact */
+        v3 lat = sub(sub(qa, qb), scale(n, s));
+        if (dot(lat, lat) > 4.0f * margin * margin) continue;
+        int dup = 0;
+        for (int j = 0; j < nc; ++j) {
+            v3 dd = sub(cp[j], qa);
+            if (dot(dd, dd) < 2.5e-3f * radius * radius) dup = 1;
+        }
+        if (dup) continue;
+        cp[nc] = qa; cq[nc] = qb; cs[nc] = s; ++nc;
+    }
+    int keep[4];
+    int nk = reduce4(nc, cp, cs, n, keep);
+    float mins = 3.0e38f;
+    for (int i = 0; i < nk; ++i) {
+        int j = keep[i];
+        fill_contact(&out[i], ia, ib, wa, wb, cp[j], cq[j], n, cs[j], rest, mu_s, mu_d, e);
+        if (cs[j] < mins) mins = cs[j];
+    }
+    return mins;
+}
+
+/* body vs plane (top face of the table box, scene.cpp:629-663): up to 4 contacts */
+static void plane_contacts(const slhip_body* bodies, const wbody* wbs, int ia, const slhip_hull* hulls,
+                           const float* hull_verts, const slhip_settle_params* prm, float plane_z,
+                           float margin, contact* out)
+{
+    for (int i = 0; i < PLANE_SLOTS; ++i) out[i].valid = 0;
+    const slhip_body* b = &bodies[ia];
+    const wbody* w = &wbs[ia];
+    /* candidate = every hull vertex closer than the margin; reduce on the fly to bounded sets:
+       keep deepest and the extreme points by a streaming 4-point reduction over a fixed
+       candidate buffer of 64 (deepest-first replacement) */
+    v3 cand[64];
+    float cs[64];
+    int nc = 0;
+    for (uint32_t h = b->hull_begin; h < b->hull_end; ++h) {
+        const slhip_hull* hh = &hulls[h];
+        v3 c = add(m3_mul(&w->R, V(hh->sphere[0], hh->sphere[1], hh->sphere[2])), w->t);
+        if (c.z - hh->sphere[3] - plane_z > margin) continue;
+        const float* vs = hull_verts + 4 * (size_t)hh->vtx_begin;
+        for (uint32_t i = 0; i < hh->vtx_count; ++i) {
+            v3 p = add(m3_mul(&w->R, V(vs[4 * i], vs[4 * i + 1], vs[4 * i + 2])), w->t);
+            float d = p.z - plane_z;
+            if (d > margin) continue;
+            if (nc < 64) { cand[nc] = p; cs[nc] = d; ++nc; }
+            else {
+                /* replace the shallowest candidate if this one is deeper */
+                int worst = 0;
+                for (int k = 1; k < 64; ++k) if (cs[k] > cs[worst]) worst = k;
+                if (d < cs[worst]) { cand[worst] = p; cs[worst] = d; }
+            }
+        }
+    }
+    if (nc == 0) return;
+    int keep[4];
+    v3 n = V(0, 0, 1);
+    int nk = reduce4(nc, cand, cs, n, keep);
+    float mu_s = 0.5f * (b->mu_s + prm->plane_mu_s);
+    float mu_d = 0.5f * (b->mu_d + prm->plane_mu_d);
+    float e = 0.5f * (b->restitution + prm->plane_restitution);
+    for (int i = 0; i < nk; ++i) {
+        int j = keep[i];
+        v3 pb = V(cand[j].x, cand[j].y, plane_z);
+        fill_contact(&out[i], ia, -1, w, NULL, cand[j], pb, n, cs[j], prm->rest_offset, mu_s, mu_d, e);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* solver                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+static inline v3 vel_at(const wbody* b, v3 r) { return add(b->v, cross(b->w, r)); }
+
+static inline float eff_mass(const wbody* a, const wbody* b, v3 ra, v3 rb, v3 d)
+{
+    float k = 0.0f;
+    if (a->dynamic) {
+        v3 rn = cross(ra, d);
+        k += a->inv_mass + dot(cross(m3_mul(&a->Iinv_w, rn), ra), d);
+    }
+    if (b && b->dynamic) {
+        v3 rn = cross(rb, d);
+        k += b->inv_mass + dot(cross(m3_mul(&b->Iinv_w, rn), rb), d);
+    }
+    return k > 0.0f ? 1.0f / k : 0.0f;
+}
+
+static void prep_contact(contact* c, const wbody* wbs)
+{
+    if (!c->valid) return;
+    const wbody* a = &wbs[c->a];
+    const wbody* b = c->b >= 0 ? &wbs[c->b] : NULL;
+    if (!a->dynamic && !(b && b->dynamic)) { c->valid = 0; return; }
+    c->kn = eff_mass(a, b, c->ra, c->rb, c->n);
+    c->kt1 = eff_mass(a, b, c->ra, c->rb, c->t1);
+    c->kt2 = eff_mass(a, b, c->ra, c->rb, c->t2);
+    v3 rel = vel_at(a, c->ra);
+    if (b) rel = sub(rel, vel_at(b, c->rb));
+    c->vn0 = dot(rel, c->n);
+}
+
+static inline void apply_impulse(wbody* a, wbody* b, const contact* c, v3 J)
+{
+    if (a->dynamic) {
+        a->v = madd(a->v, J, a->inv_mass);
+        a->w = add(a->w, m3_mul(&a->Iinv_w, cross(c->ra, J)));
+    }
+    if (b && b->dynamic) {
+        b->v = madd(b->v, J, -b->inv_mass);
+        b->w = sub(b->w, m3_mul(&b->Iinv_w, cross(c->rb, J)));
+    }
+}
+
+static void solve_contact(contact* c, wbody* wbs, const slhip_settle_params* prm, int biased)
+{
+    if (!c->valid) return;
+    wbody* a = &wbs[c->a];
+    wbody* b = c->b >= 0 ? &wbs[c->b] : NULL;
+    const float inv_dt = 1.0f / prm->dt;
+    /* normal row */
+    v3 rel = vel_at(a, c->ra);
+    if (b) rel = sub(rel, vel_at(b, c->rb));
+    float vn = dot(rel, c->n);
+    float err = c->sep - c->rest;
+    float target; /* required vn >= target */
+    if (err > 0.0f) target = -err * inv_dt;                 /* speculative: may close the gap */
+    else target = biased ? -0.8f * err * inv_dt : 0.0f;     /* push out (position iterations only) */
+    if (c->vn0 < -prm->bounce_threshold && c->e > 0.0f) {
+        float bounce = -c->e * c->vn0;
+        if (bounce > target) target = bounce;
+    }
+    float dl = (target - vn) * c->kn;
+    float ln = c->ln + dl;
+    if (ln < 0.0f) ln = 0.0f;
+    dl = ln - c->ln;
+    c->ln = ln;
+    apply_impulse(a, b, c, scale(c->n, dl));
+    /* friction rows (static/dynamic Coulomb on the tangent impulse vector) */
+    rel = vel_at(a, c->ra);
+    if (b) rel = sub(rel, vel_at(b, c->rb));
+    float l1 = c->lt1 - dot(rel, c->t1) * c->kt1;
+    float l2 = c->lt2 - dot(rel, c->t2) * c->kt2;
+    float mag2 = fmaf(l2, l2, l1 * l1);
+    float lim_s = c->mu_s * c->ln;
+    if (mag2 > lim_s * lim_s) {
+        float mag = sqrtf(mag2);
+        float k = (c->mu_d * c->ln) / mag;
+        l1 *= k; l2 *= k;
+    }
+    float d1 = l1 - c->lt1, d2 = l2 - c->lt2;
+    c->lt1 = l1; c->lt2 = l2;
+    apply_impulse(a, b, c, madd(scale(c->t1, d1), c->t2, d2));
+}
+
+/* greedy colouring in group order: a group gets the smallest colour unused by its bodies */
+static void color_groups(scene_ws* ws, int n_bodies)
+{
+    uint64_t used[SLHIP_MAX_BODIES];
+    for (int i = 0; i < n_bodies; ++i) used[i] = 0;
+    int nc = 0;
+    for (int g = 0; g < ws->n_groups; ++g) {
+        uint64_t m = used[ws->g_a[g]];
+        if (ws->g_b[g] >= 0) m |= used[ws->g_b[g]];
+        int c = 0;
+        while (c < 63 && (m >> c) & 1ull) ++c;
+        ws->g_color[g] = c;
+        used[ws->g_a[g]] |= 1ull << c;
+        if (ws->g_b[g] >= 0) used[ws->g_b[g]] |= 1ull << c;
+        if (c + 1 > nc) nc = c + 1;
+    }
+    ws->n_colors = nc;
+}
+
+static void solve_iteration(scene_ws* ws, const slhip_settle_params* prm, int biased)
+{
+    for (int col = 0; col < ws->n_colors; ++col)
+        for (int g = 0; g < ws->n_groups; ++g) {
+            if (ws->g_color[g] != col) continue;
+            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) solve_contact(&ws->c[i], ws->wb, prm, biased);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* one step                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+static void load_body(const slhip_body* b, wbody* w)
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) w->R.m[3 * r + c] = b->pose[4 * r + c];
+    w->t = V(b->pose[3], b->pose[7], b->pose[11]);
+    w->q = m3_to_quat(&w->R);
+    quat_to_m3(w->q, &w->R); /* re-orthonormalised rotation is what the step uses */
+    w->x = add(m3_mul(&w->R, V(b->com[0], b->com[1], b->com[2])), w->t);
+    w->v = V(b->lin_vel[0], b->lin_vel[1], b->lin_vel[2]);
+    w->w = V(b->ang_vel[0], b->ang_vel[1], b->ang_vel[2]);
+    w->inv_mass = b->inv_mass;
+    w->dynamic = !(b->flags & (SLHIP_BODY_STATIC | SLHIP_BODY_ASLEEP)) && b->inv_mass > 0.0f;
+}
+
+static void update_world_inertia(const slhip_body* b, wbody* w)
+{
+    /* Iinv_w = R Iinv R^T */
+    m3 L, T;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) L.m[3 * r + c] = b->inv_inertia[4 * r + c];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            T.m[3 * r + c] = fmaf(w->R.m[3 * r + 2], L.m[6 + c], fmaf(w->R.m[3 * r + 1], L.m[3 + c], w->R.m[3 * r] * L.m[c]));
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            w->Iinv_w.m[3 * r + c] = fmaf(T.m[3 * r + 2], w->R.m[3 * c + 2], fmaf(T.m[3 * r + 1], w->R.m[3 * c + 1], T.m[3 * r] * w->R.m[3 * c]));
+}
+
+static void store_body(slhip_body* b, const wbody* w)
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) b->pose[4 * r + c] = w->R.m[3 * r + c];
+    b->pose[3] = w->t.x; b->pose[7] = w->t.y; b->pose[11] = w->t.z;
+    b->pose[12] = 0.0f; b->pose[13] = 0.0f; b->pose[14] = 0.0f; b->pose[15] = 1.0f;
+    b->lin_vel[0] = w->v.x; b->lin_vel[1] = w->v.y; b->lin_vel[2] = w->v.z;
+    b->ang_vel[0] = w->w.x; b->ang_vel[1] = w->w.y; b->ang_vel[2] = w->w.z;
+}
+
+static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, const slhip_hull* hulls,
+                       const float* hull_verts, const slhip_settle_params* prm, scene_ws* ws)
+{
+    slhip_body* bodies = bodies_all + sc->body_begin;
+    const int nb = (int)(sc->body_end - sc->body_begin);
+    const float dt = prm->dt;
+    wbody* wb = ws->wb;
+
+    /* (a) load, integrate forces */
+    for (int i = 0; i < nb; ++i) {
+        load_body(&bodies[i], &wb[i]);
+        update_world_inertia(&bodies[i], &wb[i]);
+        bodies[i].separation = 3.0e38f; /* +inf (scene.cpp:732) */
+        if (wb[i].dynamic) {
+            wb[i].v = madd(wb[i].v, V(prm->gravity[0], prm->gravity[1], prm->gravity[2]), dt);
+            float damp = 1.0f - prm->angular_damping * dt;
+            if (damp < 0.0f) damp = 0.0f;
+            wb[i].w = scale(wb[i].w, damp);
+        }
+    }
+
+    /* (b,c) broadphase: body pairs in (i<j) order, then their hull pairs */
+    ws->n_hp = 0;
+    ws->n_groups = 0;
+    for (int i = 0; i < nb; ++i)
+        for (int j = i + 1; j < nb; ++j) {
+            if (!wb[i].dynamic && !wb[j].dynamic) continue;
+            v3 ci = add(m3_mul(&wb[i].R, V(bodies[i].bsphere[0], bodies[i].bsphere[1], bodies[i].bsphere[2])), wb[i].t);
+            v3 cj = add(m3_mul(&wb[j].R, V(bodies[j].bsphere[0], bodies[j].bsphere[1], bodies[j].bsphere[2])), wb[j].t);
+            /* speculative margin: contact offsets + relative motion of this step */
+            v3 dv = sub(wb[i].v, wb[j].v);
+            float spec = sqrtf(dot(dv, dv)) * dt;
+            float margin = 2.0f * prm->contact_offset + spec;
+            v3 d = sub(ci, cj);
+            float rr = bodies[i].bsphere[3] + bodies[j].bsphere[3] + margin;
+            if (dot(d, d) > rr * rr) continue;
+            int first = ws->n_hp;
+            for (uint32_t ha = bodies[i].hull_begin; ha < bodies[i].hull_end; ++ha)
+                for (uint32_t hb = bodies[j].hull_begin; hb < bodies[j].hull_end; ++hb) {
+                    v3 ca = add(m3_mul(&wb[i].R, V(hulls[ha].sphere[0], hulls[ha].sphere[1], hulls[ha].sphere[2])), wb[i].t);
+                    v3 cb = add(m3_mul(&wb[j].R, V(hulls[hb].sphere[0], hulls[hb].sphere[1], hulls[hb].sphere[2])), wb[j].t);
+                    v3 dd = sub(ca, cb);
+                    float r2 = hulls[ha].sphere[3] + hulls[hb].sphere[3] + margin;
+                    if (dot(dd, dd) > r2 * r2) continue;
+                    if (ws->n_hp >= SLHIP_MAX_HULL_PAIRS) continue; /* overflow: dropped (deterministic) */
+                    int k = ws->n_hp++;
+                    ws->hp_ba[k] = i; ws->hp_bb[k] = j; ws->hp_ha[k] = (int)ha; ws->hp_hb[k] = (int)hb;
+                }
+            if (ws->n_hp > first) {
+                int g = ws->n_groups++;
+                ws->g_a[g] = i; ws->g_b[g] = j;
+                ws->g_begin[g] = first * MAX_CONTACTS_PER_HP;
+                ws->g_end[g] = ws->n_hp * MAX_CONTACTS_PER_HP;
+            }
+        }
+    const int n_pair_groups = ws->n_groups;
+
+    /* (d) narrowphase per hull pair */
+    for (int k = 0; k < ws->n_hp; ++k) {
+        int i = ws->hp_ba[k], j = ws->hp_bb[k];
+        v3 dv = sub(wb[i].v, wb[j].v);
+        float margin = 2.0f * prm->contact_offset + sqrtf(dot(dv, dv)) * dt;
+        float s = hull_pair_contacts(bodies, wb, i, j, &hulls[ws->hp_ha[k]], &hulls[ws->hp_hb[k]], hull_verts, prm,
+                                     margin, &ws->c[k * MAX_CONTACTS_PER_HP]);
+        /* min separation per object (scene.cpp:73-116; plane contacts are ignored there) */
+        if (s < bodies[i].separation) bodies[i].separation = s;
+        if (s < bodies[j].separation) bodies[j].separation = s;
+    }
+
+    /* (e) plane contacts: one group per dynamic body, slots after the hull-pair slots */
+    const int plane_base = SLHIP_MAX_HULL_PAIRS * MAX_CONTACTS_PER_HP;
+    if (sc->has_plane) {
+        for (int i = 0; i < nb; ++i) {
+            if (!wb[i].dynamic) continue;
+            v3 ci = add(m3_mul(&wb[i].R, V(bodies[i].bsphere[0], bodies[i].bsphere[1], bodies[i].bsphere[2])), wb[i].t);
+            float vz = wb[i].v.z < 0.0f ? -wb[i].v.z * dt : 0.0f;
+            float margin = prm->contact_offset + vz;
+            if (ci.z - bodies[i].bsphere[3] - sc->plane_z > margin) continue;
+            contact* out = &ws->c[plane_base + i * PLANE_SLOTS];
+            plane_contacts(bodies, wb, i, hulls, hull_verts, prm, sc->plane_z, margin, out);
+            int g = ws->n_groups++;
+            ws->g_a[g] = i; ws->g_b[g] = -1;
+            ws->g_begin[g] = plane_base + i * PLANE_SLOTS;
+            ws->g_end[g] = plane_base + (i + 1) * PLANE_SLOTS;
+        }
+    }
+    (void)n_pair_groups;
+
+    /* wake sleeping bodies touched by a moving body */
+    for (int g = 0; g < ws->n_groups; ++g) {
+        int a = ws->g_a[g], b = ws->g_b[g];
+        if (b < 0) continue;
+        int touching = 0;
+        for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i)
+            if (ws->c[i].valid && ws->c[i].sep < 2.0f * prm->contact_offset) touching = 1;
+        if (!touching) continue;
+        for (int s = 0; s < 2; ++s) {
+            int me = s ? b : a, other = s ? a : b;
+            if ((bodies[me].flags & SLHIP_BODY_ASLEEP) && wb[other].dynamic) {
+                float en = 0.5f * dot(wb[other].v, wb[other].v);
+                if (en > prm->sleep_threshold) {
+                    bodies[me].flags &= ~SLHIP_BODY_ASLEEP;
+                    bodies[me].wake_counter = prm->wake_time;
+                    /* becomes dynamic from the next step on */
+                }
+            }
+        }
+    }
+
+    /* (f) prep */
+    for (int g = 0; g < ws->n_groups; ++g)
+        for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) prep_contact(&ws->c[i], wb);
+
+    /* (g) colouring, (h) position iterations (biased) */
+    color_groups(ws, nb);
+    for (uint32_t it = 0; it < prm->pos_iters; ++it) solve_iteration(ws, prm, 1);
+
+    /* (i) integrate poses with the biased velocities */
+    for (int i = 0; i < nb; ++i) {
+        if (!wb[i].dynamic) continue;
+        float lim = bodies[i].max_lin_vel;
+        float vv = dot(wb[i].v, wb[i].v);
+        if (lim > 0.0f && vv > lim * lim) wb[i].v = scale(wb[i].v, lim / sqrtf(vv));
+        float ww = dot(wb[i].w, wb[i].w);
+        float wl = prm->max_angular_velocity;
+        if (ww > wl * wl) wb[i].w = scale(wb[i].w, wl / sqrtf(ww));
+        wb[i].x = madd(wb[i].x, wb[i].v, dt);
+        quat wq = {wb[i].w.x, wb[i].w.y, wb[i].w.z, 0.0f};
+        quat dq = quat_mul(wq, wb[i].q);
+        quat q = {fmaf(0.5f * dt, dq.x, wb[i].q.x), fmaf(0.5f * dt, dq.y, wb[i].q.y),
+                  fmaf(0.5f * dt, dq.z, wb[i].q.z), fmaf(0.5f * dt, dq.w, wb[i].q.w)};
+        wb[i].q = quat_normalize(q);
+    }
+
+    /* (j) velocity iterations (unbiased): what is left in v,w is carried to the next step */
+    for (uint32_t it = 0; it < prm->vel_iters; ++it) solve_iteration(ws, prm, 0);
+
+    /* (k) store, sleep bookkeeping */
+    for (int i = 0; i < nb; ++i) {
+        if (!wb[i].dynamic) continue;
+        quat_to_m3(wb[i].q, &wb[i].R);
+        wb[i].t = sub(wb[i].x, m3_mul(&wb[i].R, V(bodies[i].com[0], bodies[i].com[1], bodies[i].com[2])));
+        /* mass-normalised kinetic energy; the angular part uses the bounding radius as lever */
+        float r = bodies[i].bsphere[3];
+        float en = 0.5f * (dot(wb[i].v, wb[i].v) + r * r * dot(wb[i].w, wb[i].w));
+        if (en >= prm->sleep_threshold) bodies[i].wake_counter = prm->wake_time;
+        else {
+            bodies[i].wake_counter -= dt;
+            if (bodies[i].wake_counter <= 0.0f) {
+                bodies[i].flags |= SLHIP_BODY_ASLEEP;
+                wb[i].v = V(0, 0, 0);
+                wb[i].w = V(0, 0, 0);
+            }
+        }
+        store_body(&bodies[i], &wb[i]);
+    }
+}
+
+/* redrop (scene.cpp:686-711): bounding-sphere bottom onto the highest top of all others */
+static void redrop(const slhip_settle_scene* sc, slhip_body* bodies, int me, const slhip_settle_params* prm)
+{
+    const int nb = (int)(sc->body_end - sc->body_begin);
+    float max_z = 0.0f;
+    for (int o = 0; o < nb; ++o) {
+        if (o == me || (bodies[o].flags & SLHIP_BODY_STATIC)) continue;
+        const float* P = bodies[o].pose;
+        const float* c = bodies[o].bbox_center;
+        float cz = fmaf(P[10], c[2], fmaf(P[9], c[1], P[8] * c[0])) + P[11];
+        float top = cz + c[3];
+        if (top > max_z) max_z = top;
+    }
+    float* P = bodies[me].pose;
+    const float* c = bodies[me].bbox_center;
+    float off_z = fmaf(P[10], c[2], fmaf(P[9], c[1], P[8] * c[0])) - c[3];
+    P[3] = 0.0f; P[7] = 0.0f; P[11] = max_z - off_z;
+    bodies[me].stuck_counter = 0;
+    for (int k = 0; k < 4; ++k) { bodies[me].lin_vel[k] = 0.0f; bodies[me].ang_vel[k] = 0.0f; }
+    /* a teleport invalidates every resting state */
+    for (int o = 0; o < nb; ++o) {
+        bodies[o].flags &= ~SLHIP_BODY_ASLEEP;
+        bodies[o].wake_counter = prm->wake_time;
+    }
+}
+
+int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body* bodies,
+                 const slhip_hull* hulls, const float* hull_verts, const slhip_settle_params* prm)
+{
+    scene_ws* ws = (scene_ws*)malloc(sizeof(scene_ws));
+    if (!ws) return -1;
+    for (uint32_t s = 0; s < n_scenes; ++s) {
+        const slhip_settle_scene* sc = &scenes[s];
+        const int nb = (int)(sc->body_end - sc->body_begin);
+        if (nb > SLHIP_MAX_BODIES) { free(ws); return -2; }
+        slhip_body* b = bodies + sc->body_begin;
+        for (uint32_t f = 0; f < prm->frames; ++f) {
+            for (uint32_t ss = 0; ss < prm->substeps; ++ss) step_scene(sc, bodies, hulls, hull_verts, prm, ws);
+            if (!prm->tabletop) continue;
+            for (int i = 0; i < nb; ++i) { /* scene.cpp:742-755 */
+                if (b[i].flags & SLHIP_BODY_STATIC) continue;
+                if (b[i].pose[11] < prm->redrop_z) redrop(sc, b, i, prm);
+                else if (b[i].separation < prm->stuck_separation) {
+                    if (++b[i].stuck_counter > prm->stuck_frames) redrop(sc, b, i, prm);
+                } else if (b[i].stuck_counter > 0) b[i].stuck_counter--;
+            }
+        }
+    }
+    free(ws);
+    return 0;
+}
+
+/* boolean overlap of each body against all others (+ the plane); scene.cpp:355-385 */
+int slref_overlap_any(const slhip_settle_scene* scenes, uint32_t n_scenes, const slhip_body* bodies,
+                      const slhip_hull* hulls, const float* hull_verts, uint8_t* flags)
+{
+    for (uint32_t s = 0; s < n_scenes; ++s) {
+        const slhip_settle_scene* sc = &scenes[s];
+        const int nb = (int)(sc->body_end - sc->body_begin);
+        wbody wb[SLHIP_MAX_BODIES];
+        if (nb > SLHIP_MAX_BODIES) return -2;
+        const slhip_body* b = bodies + sc->body_begin;
+        for (int i = 0; i < nb; ++i) load_body(&b[i], &wb[i]);
+        for (int i = 0; i < nb; ++i) {
+            int hit = 0;
+            for (int j = 0; j < nb && !hit; ++j) {
+                if (j == i) continue;
+                v3 ci = add(m3_mul(&wb[i].R, V(b[i].bsphere[0], b[i].bsphere[1], b[i].bsphere[2])), wb[i].t);
+                v3 cj = add(m3_mul(&wb[j].R, V(b[j].bsphere[0], b[j].bsphere[1], b[j].bsphere[2])), wb[j].t);
+                v3 d = sub(ci, cj);
+                float rr = b[i].bsphere[3] + b[j].bsphere[3];
+                if (dot(d, d) > rr * rr) continue;
+                for (uint32_t ha = b[i].hull_begin; ha < b[i].hull_end && !hit; ++ha)
+                    for (uint32_t hb = b[j].hull_begin; hb < b[j].hull_end && !hit; ++hb) {
+                        shape A, B;
+                        make_shape(&wb[i], &hulls[ha], hull_verts, &A);
+                        make_shape(&wb[j], &hulls[hb], hull_verts, &B);
+                        v3 ca = add(m3_mul(&wb[i].R, V(hulls[ha].sphere[0], hulls[ha].sphere[1], hulls[ha].sphere[2])), wb[i].t);
+                        v3 cb = add(m3_mul(&wb[j].R, V(hulls[hb].sphere[0], hulls[hb].sphere[1], hulls[hb].sphere[2])), wb[j].t);
+                        v3 dd = sub(ca, cb);
+                        float r2 = hulls[ha].sphere[3] + hulls[hb].sphere[3];
+                        if (dot(dd, dd) > r2 * r2) continue;
+                        v3 pa, pb; float dist;
+                        if (!gjk_distance(&A, &B, dd, &pa, &pb, &dist)) hit = 1;
+                    }
+            }
+            if (!hit && sc->has_plane) {
+                for (uint32_t h = b[i].hull_begin; h < b[i].hull_end && !hit; ++h) {
+                    const float* vs = hull_verts + 4 * (size_t)hulls[h].vtx_begin;
+                    for (uint32_t k = 0; k < hulls[h].vtx_count; ++k) {
+                        v3 p = add(m3_mul(&wb[i].R, V(vs[4 * k], vs[4 * k + 1], vs[4 * k + 2])), wb[i].t);
+                        if (p.z <= sc->plane_z) { hit = 1; break; }
+                    }
+                }
+            }
+            flags[sc->body_begin + i] = (uint8_t)hit;
+        }
+    }
+    return 0;
+}
+
+/* debug/test hook: contacts of the FIRST scene for the current state (no stepping).
+   out: rows of 12 floats {a, b, pax, pay, paz, nx, ny, nz, sep, pbx, pby, pbz}; returns count */
+int slref_debug_contacts(const slhip_settle_scene* sc, const slhip_body* bodies_all, const slhip_hull* hulls,
+                         const float* hull_verts, const slhip_settle_params* prm, float* out, int max_rows)
+{
+    scene_ws* ws = (scene_ws*)malloc(sizeof(scene_ws));
+    const slhip_body* bodies = bodies_all + sc->body_begin;
+    const int nb = (int)(sc->body_end - sc->body_begin);
+    for (int i = 0; i < nb; ++i) load_body(&bodies[i], &ws->wb[i]);
+    int rows = 0;
+    for (int i = 0; i < nb; ++i)
+        for (int j = i + 1; j < nb; ++j)
+            for (uint32_t ha = bodies[i].hull_begin; ha < bodies[i].hull_end; ++ha)
+                for (uint32_t hb = bodies[j].hull_begin; hb < bodies[j].hull_end; ++hb) {
+                    contact c[MAX_CONTACTS_PER_HP];
+                    hull_pair_contacts(bodies, ws->wb, i, j, &hulls[ha], &hulls[hb], hull_verts, prm,
+                                       2.0f * prm->contact_offset, c);
+                    for (int k = 0; k < MAX_CONTACTS_PER_HP; ++k) {
+                        if (!c[k].valid || rows >= max_rows) continue;
+                        float* o = out + 12 * rows++;
+                        v3 pa = add(c[k].ra, ws->wb[i].x), pb = add(c[k].rb, ws->wb[j].x);
+                        o[0] = (float)i; o[1] = (float)j; o[2] = pa.x; o[3] = pa.y; o[4] = pa.z;
+                        o[5] = c[k].n.x; o[6] = c[k].n.y; o[7] = c[k].n.z; o[8] = c[k].sep;
+                        o[9] = pb.x; o[10] = pb.y; o[11] = pb.z;
+                    }
+                }
+    if (sc->has_plane)
+        for (int i = 0; i < nb; ++i) {
+            contact c[PLANE_SLOTS];
+            plane_contacts(bodies, ws->wb, i, hulls, hull_verts, prm, sc->plane_z, prm->contact_offset, c);
+            for (int k = 0; k < PLANE_SLOTS; ++k) {
+                if (!c[k].valid || rows >= max_rows) continue;
+                float* o = out + 12 * rows++;
+                v3 pa = add(c[k].ra, ws->wb[i].x);
+                o[0] = (float)i; o[1] = -1.0f; o[2] = pa.x; o[3] = pa.y; o[4] = pa.z;
+                o[5] = c[k].n.x; o[6] = c[k].n.y; o[7] = c[k].n.z; o[8] = c[k].sep;
+                o[9] = pa.x; o[10] = pa.y; o[11] = sc->plane_z;
+            }
+        }
+    free(ws);
+    return rows;
+}

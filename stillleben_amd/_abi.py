@@ -158,6 +158,10 @@ def lib():
     L.slhip_render_scratch_bytes.argtypes = [
         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64 * 6)
     ]
+    L.slhip_settle.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_uint64, C.c_void_p]
+    L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.POINTER(C.c_uint64)]
+    L.slhip_overlap_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _LIB = L
     return L
 

@@ -1,0 +1,170 @@
+"""Host-side assembly of the binary settle description (slhip_body / slhip_hull / hull vertex
+pool / slhip_settle_scene) from sl.Scene objects, and write-back of the results."""
+import numpy as np
+
+from . import massprops
+from ._math import f32
+
+BODY_DTYPE = np.dtype([
+    ("pose", np.float32, (16,)),
+    ("lin_vel", np.float32, (4,)),
+    ("ang_vel", np.float32, (4,)),
+    ("com", np.float32, (4,)),
+    ("inv_inertia", np.float32, (12,)),
+    ("inv_mass", np.float32), ("mu_s", np.float32), ("mu_d", np.float32), ("restitution", np.float32),
+    ("bsphere", np.float32, (4,)),
+    ("bbox_center", np.float32, (4,)),
+    ("max_lin_vel", np.float32), ("separation", np.float32), ("wake_counter", np.float32), ("flags", np.uint32),
+    ("hull_begin", np.uint32), ("hull_end", np.uint32), ("stuck_counter", np.int32), ("_pad", np.uint32),
+])
+assert BODY_DTYPE.itemsize == 240
+
+HULL_DTYPE = np.dtype([("vtx_begin", np.uint32), ("vtx_count", np.uint32), ("_pad", np.uint32, (2,)),
+                       ("sphere", np.float32, (4,))])
+assert HULL_DTYPE.itemsize == 32
+
+SETTLE_SCENE_DTYPE = np.dtype([("body_begin", np.uint32), ("body_end", np.uint32), ("has_plane", np.uint32),
+                               ("plane_z", np.float32)])
+
+PARAMS_DTYPE = np.dtype([
+    ("dt", np.float32), ("substeps", np.uint32), ("frames", np.uint32), ("pos_iters", np.uint32),
+    ("vel_iters", np.uint32), ("gravity", np.float32, (3,)), ("contact_offset", np.float32),
+    ("rest_offset", np.float32), ("bounce_threshold", np.float32), ("sleep_threshold", np.float32),
+    ("wake_time", np.float32), ("angular_damping", np.float32), ("max_angular_velocity", np.float32),
+    ("plane_mu_s", np.float32), ("plane_mu_d", np.float32), ("plane_restitution", np.float32),
+    ("redrop_z", np.float32), ("stuck_separation", np.float32), ("stuck_frames", np.int32), ("tabletop", np.uint32),
+])
+assert PARAMS_DTYPE.itemsize == 88
+
+BODY_STATIC = 1
+BODY_ASLEEP = 2
+MAX_BODIES = 64
+
+
+def default_params(tabletop=True, dt=None, frames=None, substeps=None):
+    """Constants of the reference's call sites."""
+    p = np.zeros((), dtype=PARAMS_DTYPE)
+    p["dt"] = (1.0 / 25.0 / 4.0) if dt is None else dt   # scene.cpp:681-684
+    p["substeps"] = 4 if substeps is None else substeps
+    p["frames"] = 100 if frames is None else frames        # scene.cpp:720
+    p["pos_iters"], p["vel_iters"] = 4, 4                  # object.cpp:209
+    p["gravity"] = (0.0, 0.0, -9.81)                       # scene.cpp:157
+    p["contact_offset"] = 0.02 * 0.2                       # tolerance length 0.2 (context.cpp:236-238)
+    p["rest_offset"] = 0.0015                              # object.cpp:201
+    p["bounce_threshold"] = 0.2 * 10.0
+    p["sleep_threshold"] = 5e-5 * 10.0 * 10.0
+    p["wake_time"] = 0.4
+    p["angular_damping"] = 0.05
+    p["max_angular_velocity"] = 100.0
+    p["plane_mu_s"], p["plane_mu_d"], p["plane_restitution"] = 0.5, 0.5, 0.0  # scene.cpp:645
+    p["redrop_z"] = -0.5                                   # scene.cpp:746
+    p["stuck_separation"] = -0.01                          # scene.cpp:748
+    p["stuck_frames"] = 10                                 # 0.4 s * 25 FPS (scene.cpp:750)
+    p["tabletop"] = 1 if tabletop else 0
+    return p
+
+
+class HullPool:
+    """Collision hulls of every mesh in use, object frame, float4 vertices."""
+
+    def __init__(self):
+        self.verts = []
+        self.hulls = []
+        self.n_verts = 0
+        self._ranges = {}
+        self.dirty = True
+
+    def register(self, mesh):
+        key = (id(mesh), float(mesh._scale), mesh._pretransform_rigid.tobytes(), mesh._version)
+        r = self._ranges.get(key)
+        if r is not None:
+            return r
+        begin = len(self.hulls)
+        centers, radii = [], []
+        for v, _t in massprops.object_frame_hulls(mesh):
+            v = v.astype(np.float32)
+            if len(v) > 64:
+                raise RuntimeError("collision hull with more than 64 vertices")
+            c = ((v.min(axis=0) + v.max(axis=0)) / f32(2.0)).astype(np.float32)
+            r_ = f32(np.sqrt(((v - c) ** 2).sum(axis=1).max()))
+            h = np.zeros((), dtype=HULL_DTYPE)
+            h["vtx_begin"], h["vtx_count"] = self.n_verts, len(v)
+            h["sphere"][:3], h["sphere"][3] = c, r_
+            self.hulls.append(h)
+            self.verts.append(np.concatenate([v, np.ones((len(v), 1), np.float32)], axis=1))
+            self.n_verts += len(v)
+            centers.append(c)
+            radii.append(r_)
+        centers = np.array(centers, np.float32)
+        radii = np.array(radii, np.float32)
+        bc = ((centers - radii[:, None]).min(axis=0) + (centers + radii[:, None]).max(axis=0)) / f32(2.0)
+        br = f32((np.sqrt(((centers - bc) ** 2).sum(axis=1)) + radii).max())
+        r = (begin, len(self.hulls), bc.astype(np.float32), br)
+        self._ranges[key] = r
+        self.dirty = True
+        return r
+
+    def arrays(self):
+        hulls = np.array(self.hulls, dtype=HULL_DTYPE) if self.hulls else np.zeros(0, HULL_DTYPE)
+        verts = np.concatenate(self.verts) if self.verts else np.zeros((1, 4), np.float32)
+        return hulls, np.ascontiguousarray(verts, dtype=np.float32)
+
+
+def body_record(obj, pool, rec):
+    mesh = obj._mesh
+    hb, he, bc, br = pool.register(mesh)
+    p = obj._props()
+    rec["pose"] = obj._pose.reshape(-1)
+    rec["lin_vel"][:3] = obj._linear_velocity
+    rec["ang_vel"][:3] = obj._angular_velocity
+    rec["com"][:3] = p.com
+    ii = np.zeros((3, 4), np.float32)
+    ii[:, :3] = p.inv_inertia
+    rec["inv_inertia"] = ii.reshape(-1)
+    rec["inv_mass"] = 0.0 if obj._static else f32(1.0) / p.mass
+    rec["mu_s"], rec["mu_d"], rec["restitution"] = obj._static_friction, obj._dynamic_friction, obj._restitution
+    rec["bsphere"][:3], rec["bsphere"][3] = bc, br
+    bbox = mesh.bbox
+    rec["bbox_center"][:3] = bbox.np_center()
+    rec["bbox_center"][3] = bbox.np_diagonal() / f32(2.0)
+    lim = float(obj._linear_velocity_limit)
+    rec["max_lin_vel"] = lim if lim < 1e15 else 0.0
+    rec["separation"] = obj._separation
+    rec["wake_counter"] = 0.4
+    rec["flags"] = BODY_STATIC if obj._static else 0
+    rec["hull_begin"], rec["hull_end"] = hb, he
+    rec["stuck_counter"] = obj._stuck_counter
+
+
+def build_settle_batch(scenes, pool, with_plane):
+    """with_plane: list of (has_plane, plane_z) per scene."""
+    n_bodies = sum(len(s._objects) for s in scenes)
+    bodies = np.zeros(n_bodies, dtype=BODY_DTYPE)
+    srec = np.zeros(len(scenes), dtype=SETTLE_SCENE_DTYPE)
+    k = 0
+    for si, scene in enumerate(scenes):
+        if len(scene._objects) > MAX_BODIES:
+            raise RuntimeError("at most %d objects per scene are supported by the settle kernel" % MAX_BODIES)
+        srec[si]["body_begin"] = k
+        for obj in scene._objects:
+            body_record(obj, pool, bodies[k])
+            k += 1
+        srec[si]["body_end"] = k
+        srec[si]["has_plane"] = 1 if with_plane[si][0] else 0
+        srec[si]["plane_z"] = with_plane[si][1]
+    return srec, bodies
+
+
+def write_back(scenes, bodies):
+    k = 0
+    for scene in scenes:
+        for obj in scene._objects:
+            b = bodies[k]
+            k += 1
+            if obj._static:
+                continue
+            obj._pose = b["pose"].reshape(4, 4).astype(np.float32).copy()
+            obj._linear_velocity = b["lin_vel"][:3].copy()
+            obj._angular_velocity = b["ang_vel"][:3].copy()
+            obj._separation = f32(b["separation"])
+            obj._stuck_counter = int(b["stuck_counter"])

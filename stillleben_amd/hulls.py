@@ -50,23 +50,30 @@ def _qhull(points):
 
 
 def _reduce(points, max_verts=MAX_HULL_VERTS):
-    """Hull with at most max_verts vertices: keep the extreme points of a fixed direction set."""
+    """Hull with at most max_verts vertices: greedy inside-out construction -- start from the
+    axis extremes and repeatedly add the hull vertex that lies farthest outside the current
+    polytope (the vertex-limited quick-hull PhysX cooking performs, [ext])."""
+    from scipy.spatial import ConvexHull, QhullError
+
     v, t = _qhull(points)
     if len(v) <= max_verts:
         return Hull(v, t)
-    # deterministic Fibonacci directions
-    k = np.arange(4 * max_verts) + 0.5
-    phi = np.arccos(1 - 2 * k / (4 * max_verts))
-    theta = np.pi * (1 + 5 ** 0.5) * k
-    dirs = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1)
     sel = []
-    seen = set()
-    for j in np.argmax(v @ dirs.T, axis=0):
-        if j not in seen:
-            seen.add(int(j))
-            sel.append(int(j))
-        if len(sel) >= max_verts:
+    for ax in range(3):
+        for j in (int(np.argmin(v[:, ax])), int(np.argmax(v[:, ax]))):
+            if j not in sel:
+                sel.append(j)
+    while len(sel) < max_verts:
+        try:
+            h = ConvexHull(v[sel])
+        except QhullError:
+            h = ConvexHull(v[sel], qhull_options="QJ")
+        d = (v @ h.equations[:, :3].T + h.equations[:, 3]).max(axis=1)
+        d[sel] = -np.inf
+        j = int(np.argmax(d))
+        if d[j] <= 1e-12:
             break
+        sel.append(j)
     v2, t2 = _qhull(v[sel])
     return Hull(v2, t2)
 

@@ -1,0 +1,195 @@
+"""Python-side drivers of the settle half: Scene.simulate_tabletop_scene / simulate /
+check_collisions / find_noncolliding_pose (reference src/scene.cpp:612-759, :903-925,
+include/stillleben/scene.h:245-261).  All stepping runs in the HIP kernel behind the C-ABI
+(slhip_settle / slhip_overlap_any); this module only assembles inputs and copies results."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _abi
+from . import _math as M
+from . import _settle_batch as SB
+from . import pose_sampling
+from ._context import engine
+from ._math import f32
+
+PLANE_HALF_Z = 0.04  # BOX_HALF_EXTENTS.z (scene.cpp:638)
+
+
+class SettleEngine:
+    """Device state of the settle half (hull pool in HBM, scratch)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.pool = SB.HullPool()
+        self._dev = None
+        self._scratch = None
+
+    def hulls_dev(self):
+        if self.pool.dirty or self._dev is None:
+            hulls, verts = self.pool.arrays()
+            self._dev = (self.eng.upload_records(hulls), torch.from_numpy(verts).to(self.eng.device))
+            self.pool.dirty = False
+        return self._dev
+
+    def scratch(self, n_scenes):
+        need = C.c_uint64()
+        self.eng.L.slhip_settle_scratch_bytes(n_scenes, C.byref(need))
+        if self._scratch is None or self._scratch.numel() < need.value:
+            self._scratch = torch.empty(int(need.value), dtype=torch.uint8, device=self.eng.device)
+        return self._scratch
+
+    def run(self, srec, bodies, params):
+        """Runs slhip_settle on numpy records; returns the updated bodies (numpy)."""
+        d_bodies = self.run_device(srec, bodies, params)
+        out = np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy()
+        return out
+
+    def run_device(self, srec, bodies, params, d_bodies=None):
+        eng = self.eng
+        d_hulls, d_verts = self.hulls_dev()
+        d_s = eng.upload_records(srec)
+        if d_bodies is None:
+            d_bodies = eng.upload_records(bodies)
+        scratch = self.scratch(len(srec))
+        prm = np.ascontiguousarray(params)
+        stream = torch.cuda.current_stream(eng.device).cuda_stream
+        with torch.cuda.device(eng.device):
+            st = eng.L.slhip_settle(_abi_ptr(d_s), len(srec), _abi_ptr(d_bodies), _abi_ptr(d_hulls), _abi_ptr(d_verts),
+                                    C.c_void_p(prm.ctypes.data), _abi_ptr(scratch), scratch.numel(), C.c_void_p(stream))
+        _abi.check(st, "slhip_settle")
+        self._keep = (d_s, prm)
+        return d_bodies
+
+    def overlap(self, srec, bodies):
+        eng = self.eng
+        d_hulls, d_verts = self.hulls_dev()
+        d_s, d_b = eng.upload_records(srec), eng.upload_records(bodies)
+        flags = torch.zeros(len(bodies), dtype=torch.uint8, device=eng.device)
+        stream = torch.cuda.current_stream(eng.device).cuda_stream
+        with torch.cuda.device(eng.device):
+            st = eng.L.slhip_overlap_any(_abi_ptr(d_s), len(srec), _abi_ptr(d_b), _abi_ptr(d_hulls), _abi_ptr(d_verts),
+                                         _abi_ptr(flags), C.c_void_p(stream))
+        _abi.check(st, "slhip_overlap_any")
+        return flags.cpu().numpy()
+
+
+def _abi_ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def settle_engine():
+    eng = engine()
+    if getattr(eng, "_settle", None) is None:
+        eng._settle = SettleEngine(eng)
+    return eng._settle
+
+
+# ------------------------------------------------------------------------------------------
+def prepare_tabletop(scene):
+    """Host part of simulateTableTopScene before the loop (scene.cpp:612-718): plane decision,
+    background-plane pose, initial stack of randomly oriented objects.  Returns (has_plane, z)."""
+    scene.load_physics()
+    dynamic = [o for o in scene._objects if not o._static]
+    has_plane = len(dynamic) == len(scene._objects)
+    z = f32(0.4)
+    rng = scene._rng
+    if has_plane:
+        yaw = f32(rng.uniform(-math.pi, math.pi))
+        scene._background_plane_pose = (M.rotation_z(yaw) @ M.translation([0.0, 0.0, PLANE_HALF_Z])).astype(np.float32)
+        z = f32(PLANE_HALF_Z)
+    for obj in dynamic:
+        bbox = obj._mesh.bbox
+        diameter = bbox.np_diagonal()
+        z = f32(z + diameter / f32(2.0))
+        pos = np.array([0.0, 0.0, z], dtype=np.float32)
+        z = f32(z + diameter / f32(2.0))
+        q = pose_sampling.random_quaternion(rng)
+        pose = M.from_rt(M.quat_to_matrix(q), pos) @ M.translation(-bbox.np_center())
+        obj._pose = pose.astype(np.float32)
+        obj._linear_velocity = np.zeros(3, np.float32)
+        obj._angular_velocity = np.zeros(3, np.float32)
+        obj._stuck_counter = 0
+        obj._separation = f32(np.inf)
+    return has_plane
+
+
+def simulate_tabletop_scene(scene, vis_cb=None):
+    has_plane = prepare_tabletop(scene)
+    se = settle_engine()
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(has_plane, PLANE_HALF_Z)])
+    if vis_cb is None:
+        bodies = se.run(srec, bodies, SB.default_params(tabletop=True))
+        SB.write_back([scene], bodies)
+    else:
+        # quirk q7: the callback runs BEFORE each frame's sub-steps (scene.cpp:723-724)
+        prm = SB.default_params(tabletop=True, frames=1)
+        for i in range(100):
+            vis_cb(i)
+            bodies = se.run(srec, bodies, prm)
+            SB.write_back([scene], bodies)
+    scene.choose_random_camera_pose()
+
+
+def settle_batch(scenes, frames=None):
+    """Additive batch API (the GPU counterpart of JobQueue): settles many scenes in one launch."""
+    planes = [(prepare_tabletop(s), PLANE_HALF_Z) for s in scenes]
+    se = settle_engine()
+    srec, bodies = SB.build_settle_batch(scenes, se.pool, planes)
+    bodies = se.run(srec, bodies, SB.default_params(tabletop=True, frames=frames))
+    SB.write_back(scenes, bodies)
+    for s in scenes:
+        s.choose_random_camera_pose()
+
+
+def simulate(scene, dt):
+    """One step of dt without a table (scene.cpp:903-912)."""
+    scene.load_physics()
+    se = settle_engine()
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(False, 0.0)])
+    bodies["flags"] &= ~np.uint32(SB.BODY_ASLEEP)
+    bodies = se.run(srec, bodies, SB.default_params(tabletop=False, dt=dt, frames=1, substeps=1))
+    SB.write_back([scene], bodies)
+
+
+def check_collisions(scene):
+    """scene.cpp:914-925: separation = -FLT_MAX for colliding objects, else +inf (sic: 0 in
+    the reference's isObjectColliding==false branch)."""
+    scene.load_physics()
+    se = settle_engine()
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(False, 0.0)])
+    flags = se.overlap(srec, bodies)
+    for obj, f in zip(scene._objects, flags):
+        obj._separation = f32(-np.finfo(np.float32).max) if f else f32(0.0)
+    return flags
+
+
+def is_object_colliding(scene, obj):
+    scene.load_physics()
+    se = settle_engine()
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(False, 0.0)])
+    flags = se.overlap(srec, bodies)
+    return bool(flags[scene._objects.index(obj)])
+
+
+def find_noncolliding_pose(scene, obj, sampler="random", max_iterations=10, **kwargs):
+    """scene.h:245-261: rejection-sample poses until the object does not collide."""
+    if obj not in scene._objects:
+        raise ValueError("object is not part of the scene")
+    diameter = obj._mesh.bbox.np_diagonal()
+    if sampler == "random":
+        pos = pose_sampling.RandomPositionSampler(scene._projection, diameter, kwargs.get("min_size_factor", 0.4))
+    elif sampler in ("viewpoint", "view_corrected"):
+        pos = pose_sampling.RandomPositionSampler(scene._projection, diameter, kwargs.get("min_size_factor", 0.4))
+    else:
+        raise ValueError("unknown sampler '%s'" % sampler)
+    for _ in range(int(max_iterations)):
+        q = pose_sampling.random_quaternion(scene._rng)
+        p = pos(scene._rng)
+        pose_in_cam = M.from_rt(M.quat_to_matrix(q), p)
+        obj._pose = (scene._camera_pose @ pose_in_cam).astype(np.float32)
+        if not is_object_colliding(scene, obj):
+            return True
+    return False
