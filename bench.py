@@ -1,0 +1,321 @@
+#!/usr/bin/env python
+"""Headline benchmark: scenes/sec for {tabletop settle of 20 YCB-like objects + 640x480
+6-channel ground-truth render} (BASELINE.json metric, config C2), one process per GPU.
+
+A "step" = one batch of `--batch` freshly seeded scenes per GPU going through the whole hot
+path: slhip_settle (400 physics steps per scene) -> camera / light / draw-list assembly ->
+slhip_render (shadow pass, visibility raster, deferred shade, SSAO, tone map) -> for N > 1 an
+RCCL all-gather of the rendered batches.  Inputs (mesh pool, hull pool, the initial body
+states of every timed batch) are resident in HBM before the timed region starts.
+
+Prints ONE JSON line (rank 0) -- see the repository brief for the contract."""
+import argparse
+import ctypes as C
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RESOLUTION = (640, 480)
+INTRINSICS = (1066.778, 1067.487, 312.9869, 241.3109)  # reference examples/ycb.py:32
+N_OBJECTS = 20
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024, help="scenes per GPU per step (one settle launch)")
+    ap.add_argument("--render-chunk", type=int, default=128, help="scenes per render launch sequence")
+    ap.add_argument("--no-ssao", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def make_scene(sl, meshes, seed):
+    """BASELINE config C2: 20 of the 21 YCB-like meshes, YCB intrinsics,
+    random metallic/roughness, one directional light (colour 300), 3x3 m background plane."""
+    rnd = random.Random(seed)
+    scene = sl.Scene(RESOLUTION, seed=seed)
+    scene.set_camera_intrinsics(*INTRINSICS)
+    for mesh in rnd.sample(meshes, N_OBJECTS):
+        obj = sl.Object(mesh)
+        obj.metallic = rnd.random()
+        obj.roughness = rnd.random()
+        scene.add_object(obj)
+    scene.background_plane_size = torch.tensor([3.0, 3.0])
+    scene.ambient_light = torch.tensor([0.05, 0.05, 0.05])
+    return scene
+
+
+class Pipeline:
+    def __init__(self, sl, batch, ssao):
+        from stillleben_amd import _abi, physics
+        from stillleben_amd._context import engine
+
+        self.sl, self._abi, self.physics = sl, _abi, physics
+        self.eng = engine()
+        self.se = physics.settle_engine()
+        self.batch = batch
+        self.ssao = ssao
+        self.mask = _abi.OUT_GT6
+        self.buffers = []
+        self.render_chunk = 128
+        self.t_step_host = []
+        self.t_settle = []
+        self.t_host = []
+        self.t_render = []
+        self.phase_ms = []
+
+    def prepare(self, scenes, seed):
+        """Host-side set-up of one batch BEFORE the timed region: initial stacks, static draw
+        records, the random draws of the batch, and the upload of the initial body states."""
+        import math
+
+        from stillleben_amd import _fast_batch as FB
+        from stillleben_amd import _settle_batch as SB
+
+        planes = [(self.physics.prepare_tabletop(s), self.physics.PLANE_HALF_Z) for s in scenes]
+        srec, bodies = SB.build_settle_batch(scenes, self.se.pool, planes)
+        chunks = []
+        for c0 in range(0, len(scenes), self.render_chunk):
+            chunks.append(FB.prepare(scenes[c0:c0 + self.render_chunk], self.eng.pool))
+        rng = np.random.default_rng(seed)
+        item = {
+            "scenes": scenes, "srec": srec, "chunks": chunks,
+            "d_bodies": self.eng.upload_records(bodies),
+            # the random draws of chooseRandomCameraPose / chooseRandomLightDirection
+            "az": rng.uniform(-math.pi, math.pi, len(scenes)).astype(np.float32),
+            "el": rng.uniform(math.radians(30.0), math.radians(60.0), len(scenes)).astype(np.float32),
+            "nrm": rng.standard_normal((len(scenes), 3)).astype(np.float32),
+            "plane_pose": np.stack([s._background_plane_pose for s in scenes]),
+            "obj_off": np.cumsum([0] + [len(s._objects) for s in scenes]),
+        }
+        self.se.hulls_dev()
+        self.eng.pool_abi()
+        return item
+
+    def step(self, item, timed=True):
+        from stillleben_amd import _fast_batch as FB
+        from stillleben_amd import _settle_batch as SB
+
+        dev = self.eng.device
+        W, H = RESOLUTION
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        d_bodies = self.se.run_device(item["srec"], None, self.params, d_bodies=item["d_bodies"])
+        ev[1].record()
+        # ---- host: settled poses back (one 240 B record per object) ----
+        bodies = np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE)
+        t0 = time.perf_counter()
+        poses = bodies["pose"].reshape(-1, 4, 4)
+        t_render, phases = 0.0, np.zeros(8)
+        outs, revs = [], []
+        for ci, t in enumerate(item["chunks"]):
+            s0 = ci * self.render_chunk
+            s1 = s0 + t.n_scenes
+            o0, o1 = item["obj_off"][s0], item["obj_off"][s1]
+            th0 = time.perf_counter()
+            cam = FB.camera_poses(t, poses[o0:o1], item["az"][s0:s1], item["el"][s0:s1])
+            ld = FB.light_directions(cam, item["nrm"][s0:s1])
+            srec, drec = FB.update(t, poses[o0:o1], cam, ld, item["plane_pose"][s0:s1])
+            th1 = time.perf_counter()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            buf = self.eng.render_records(srec, drec, t.crec, W, H, self.mask, ssao=self.ssao, shadows=True,
+                                          buffers=self.buffers[ci] if ci < len(self.buffers) else None)
+            e1.record()
+            if ci >= len(self.buffers):
+                self.buffers.append(buf)
+            outs.append(buf)
+            revs.append((e0, e1))
+            if timed:
+                self.t_host.append((th1 - th0) * 1e3)
+        torch.cuda.synchronize(dev)
+        ms = (C.c_float * 8)()
+        if self.eng.L.slhip_render_timings(C.byref(ms)) == 0:
+            phases += np.array(list(ms))
+        if timed:
+            t_render = sum(a.elapsed_time(b) for a, b in revs)
+            self.t_settle.append(ev[0].elapsed_time(ev[1]))
+            self.t_render.append(t_render)
+            self.phase_ms.append(phases)
+            self.t_step_host.append((time.perf_counter() - t0) * 1e3)
+        return outs
+
+
+def cpu_baseline(sl, meshes, n_scenes, ssao):
+    """The oracle (scalar C restatement, 1 thread) timed on the host cores on a bounded sample
+    of the same workload: n_scenes x {400-step settle + 640x480 render}."""
+    import oracle
+    from stillleben_amd import _abi, physics
+    from stillleben_amd import _settle_batch as SB
+    from stillleben_amd._batch import HostPool, build_batch
+
+    scenes = [make_scene(sl, meshes, 900000 + i) for i in range(n_scenes)]
+    pool_h = SB.HullPool()
+    planes = [(physics.prepare_tabletop(s), physics.PLANE_HALF_Z) for s in scenes]
+    srec, bodies = SB.build_settle_batch(scenes, pool_h, planes)
+    hulls, verts = pool_h.arrays()
+    t0 = time.perf_counter()
+    oracle.settle(srec, bodies, hulls, verts, SB.default_params(tabletop=True))
+    t1 = time.perf_counter()
+    SB.write_back(scenes, bodies)
+    for s in scenes:
+        s.choose_random_camera_pose()
+        s.choose_random_light_direction()
+    pool = HostPool()
+    flags = _abi.OUT_GT6 | _abi.RENDER_SHADOWS | (_abi.RENDER_SSAO if ssao else 0) | _abi.OUT_CAM_COORD
+    rs, rd, _ = build_batch(scenes, pool, with_shadows=True)
+    t2 = time.perf_counter()
+    oracle.render(pool.arrays(), rs, rd, RESOLUTION[0], RESOLUTION[1], flags)
+    t3 = time.perf_counter()
+    total = (t1 - t0) + (t3 - t2)
+    return {
+        "value": n_scenes / total, "unit": "scenes/s", "cores": 1, "kind": "port",
+        "sample": "%d scenes: settle %.2f s + render %.2f s (oracle/, 1 thread, same C2 workload)"
+                  % (n_scenes, t1 - t0, t3 - t2),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import stillleben_amd as sl
+    from stillleben_amd import _settle_batch as SB
+    from stillleben_amd import synthetic
+
+    sl.init_cuda(local_rank)
+    meshes = synthetic.ycb_like_meshes(seed=0)
+    pipe = Pipeline(sl, args.batch, not args.no_ssao)
+    pipe.params = SB.default_params(tabletop=True)
+    pipe.render_chunk = args.render_chunk
+    pipe.eng.L.slhip_timing_enable(1)
+
+    n_items = args.warmup + args.steps
+    items = []
+    for k in range(n_items):
+        base = (rank * n_items + k) * args.batch
+        items.append(pipe.prepare([make_scene(sl, meshes, base + i) for i in range(args.batch)], seed=base))
+    torch.cuda.synchronize()
+
+    gather_bufs = None
+
+    def gather(outs):
+        # RCCL all-gather of the rendered batches, one collective per dtype buffer and chunk
+        nonlocal gather_bufs
+        if dist is None:
+            return
+        tensors = [t for b in outs for t in (b.rgb, b.coord, b.cls, b.instance, b.normals) if t is not None]
+        if gather_bufs is None:
+            gather_bufs = [torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in tensors]
+        for t, g in zip(tensors, gather_bufs):
+            dist.all_gather_into_tensor(g, t)
+
+    for k in range(args.warmup):
+        gather(pipe.step(items[k], timed=False))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, n_items):
+        gather(pipe.step(items[k]))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_scenes = args.batch * world * args.steps
+        value = total_scenes / elapsed
+        ms_step = elapsed / args.steps * 1e3
+        # ---- roofline of the dominant kernels ----
+        W, H = RESOLUTION
+        P = W * H
+        t_settle = float(np.mean(pipe.t_settle))
+        t_render = float(np.mean(pipe.t_render))
+        phases = np.mean(np.array(pipe.phase_ms), axis=0) if pipe.phase_ms else np.zeros(8)
+        names = ["shadow_raster", "shadow_large", "vis_raster", "vis_large", "shade", "ssao", "ssao_apply", "tonemap"]
+        # algorithmic bytes of the deferred shade pass per launch (DESIGN.md "roofline"):
+        #   read the 8 B visibility key, write the selected targets + HDR colour, per pixel,
+        #   plus the winning triangle's 3 vertices (pos 16 B, normal 16 B, uv 8 B) + 12 B indices
+        out_bytes = 16 + 2 + 2 + 16 + 16 + 16  # coord, class, instance, normals, cam_coord(SSAO input), hdr
+        n_chunks = (args.batch + args.render_chunk - 1) // args.render_chunk
+        shade_bytes = args.batch * P * (8 + out_bytes + 3 * 40 + 12)  # all chunks of one step
+        k_dom = int(np.argmax(phases)) if phases.sum() > 0 else 4
+        settle_dominant = t_settle > t_render
+        roof_render = {
+            "bound": "hbm", "kernel": "k_shade",
+            "achieved": shade_bytes / (phases[4] * 1e-3) / 1e9 if phases[4] > 0 else None,
+            "peak": 8000.0, "unit": "GB/s", "traffic": None,
+        }
+        if roof_render["achieved"]:
+            roof_render["frac"] = roof_render["achieved"] / roof_render["peak"]
+        # settle: hull vertices + body state are read once and written once per scene (HBM),
+        # everything else lives in LDS/L2: an HBM fraction is reported for completeness only
+        settle_bytes = args.batch * (N_OBJECTS * 240 * 2 + 20 * 64 * 16)
+        roof_settle = {
+            "bound": "hbm", "kernel": "k_settle", "achieved": settle_bytes / (t_settle * 1e-3) / 1e9, "peak": 8000.0,
+            "unit": "GB/s", "traffic": None,
+            "note": "latency-bound persistent kernel (400 dependent steps/scene in LDS); HBM fraction is not "
+                    "meaningful -- see steps_scenes_per_s",
+            "steps_scenes_per_s": args.batch * 400 / (t_settle * 1e-3),
+        }
+        roof_settle["frac"] = roof_settle["achieved"] / roof_settle["peak"]
+        roofline = dict(roof_settle if settle_dominant else roof_render)
+        out = {
+            "metric": "scenes/sec (settle + 640x480 6-ch GT render), 20-obj YCB-like",
+            "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "C2: 20 procedural YCB-like objects (8k verts/16k tris, 1024^2 texture each), tabletop "
+                            "settle 100 frames x 4 substeps + 640x480 render of rgb/coord+depth/class/instance/normals, "
+                            "shadows on, SSAO %s" % ("off" if args.no_ssao else "on"),
+                "scenes_per_gpu_per_step": args.batch, "resolution": list(RESOLUTION), "objects": N_OBJECTS,
+                "parallelism": "scenes sharded 1 batch/GPU, RCCL all-gather of rendered batches" if world > 1 else "1 GPU",
+            },
+            "roofline": roofline,
+            "roofline_render": roof_render,
+            "roofline_settle": roof_settle,
+            "breakdown_ms": {
+                "settle": t_settle, "host_assembly_per_chunk": float(np.mean(pipe.t_host)),
+                "post_settle_wall": float(np.mean(pipe.t_step_host)), "render_total": t_render, "render_chunks": n_chunks,
+                **{n: float(v) for n, v in zip(names, phases)},
+            },
+            "dominant_render_phase": names[k_dom],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sl, meshes, args.cpu_scenes, not args.no_ssao)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

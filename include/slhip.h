@@ -159,6 +159,13 @@ int slhip_render(const slhip_mesh_pool* pool,
                  const slhip_render_out* out, const slhip_render_scratch* scratch,
                  void* stream);
 
+/* Optional per-phase timing of slhip_render with HIP events recorded on the render stream
+ * (used by bench.py for the roofline figures).  Phases: 0 shadow raster, 1 shadow large
+ * triangles, 2 visibility raster, 3 large triangles, 4 deferred shade, 5 SSAO, 6 SSAO apply,
+ * 7 tone map.  slhip_render_timings synchronises on the last render and fills ms_out[8].    */
+int slhip_timing_enable(int on);
+int slhip_render_timings(float* ms_out);
+
 /* Bytes of each scratch buffer for a batch (host helper, no GPU needed).                    */
 int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uint32_t height,
                                uint32_t shadow_res, uint32_t queue_capacity,

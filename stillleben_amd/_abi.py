@@ -158,6 +158,8 @@ def lib():
     L.slhip_render_scratch_bytes.argtypes = [
         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64 * 6)
     ]
+    L.slhip_timing_enable.argtypes = [C.c_int]
+    L.slhip_render_timings.argtypes = [C.POINTER(C.c_float * 8)]
     L.slhip_settle.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint64, C.c_void_p]
     L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.POINTER(C.c_uint64)]

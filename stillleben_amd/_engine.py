@@ -9,7 +9,7 @@ from . import _abi
 from ._batch import HostPool, build_batch
 
 SHADOW_RES = 2048  # render_pass.cpp:271
-QUEUE_CAPACITY = 1 << 20
+QUEUE_ITEMS_PER_SCENE = 1 << 14  # (triangle, 8x8 tile) work items; 4800 tiles cover 640x480 once
 
 
 def _ptr(t):
@@ -77,7 +77,8 @@ class Engine:
         s = self._scratch.get(key)
         if s is None:
             sizes = (C.c_uint64 * 6)()
-            self.L.slhip_render_scratch_bytes(B, W, H, SHADOW_RES if shadows else 0, QUEUE_CAPACITY, C.byref(sizes))
+            qcap = max(1 << 20, B * QUEUE_ITEMS_PER_SCENE)
+            self.L.slhip_render_scratch_bytes(B, W, H, SHADOW_RES if shadows else 0, qcap, C.byref(sizes))
 
             def buf(n, need=True):
                 return torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device) if need else None
@@ -85,6 +86,7 @@ class Engine:
             s = {
                 "vis": buf(sizes[0]), "hdr": buf(sizes[1], want_rgb), "ao": buf(sizes[2], ssao),
                 "shadow": buf(sizes[3], shadows), "queue": buf(sizes[4]), "lum": buf(sizes[5], want_rgb),
+                "qcap": qcap,
             }
             if len(self._scratch) > 4:
                 self._scratch.clear()
@@ -92,7 +94,7 @@ class Engine:
         a = _abi.RenderScratch()
         a.d_vis, a.d_hdr, a.d_ao, a.d_shadow, a.d_queue, a.d_lum = (
             _ptr(s["vis"]), _ptr(s["hdr"]), _ptr(s["ao"]), _ptr(s["shadow"]), _ptr(s["queue"]), _ptr(s["lum"]))
-        a.queue_capacity = QUEUE_CAPACITY
+        a.queue_capacity = s["qcap"]
         a.shadow_res = SHADOW_RES
         return a, s
 
@@ -107,13 +109,19 @@ class Engine:
         for s in scenes:
             if s._viewport != (W, H):
                 raise ValueError("all scenes of a batch must share one viewport")
-        B = len(scenes)
+        want_rgb = bool(mask & _abi.OUT_RGB)
+        srec, drec, crec = build_batch(scenes, self.pool, predicate, with_shadows=shadows and want_rgb)
+        return self.render_records(srec, drec, crec, W, H, mask, ssao, shadows, depth_peel, buffers)
+
+    def render_records(self, srec, drec, crec, W, H, mask=_abi.OUT_ALL, ssao=True, shadows=True, depth_peel=None,
+                       buffers=None):
+        """Renders a batch described by prebuilt slhip_scene / slhip_draw / slhip_chunk records."""
+        B = len(srec)
         want_rgb = bool(mask & _abi.OUT_RGB)
         ssao = ssao and want_rgb
         shadows = shadows and want_rgb
         if ssao:
             mask |= _abi.OUT_CAM_COORD | _abi.OUT_NORMALS
-        srec, drec, crec = build_batch(scenes, self.pool, predicate, with_shadows=shadows)
         pool = self.pool_abi()
         d_s, d_d, d_c = self.upload_records(srec), self.upload_records(drec), self.upload_records(crec)
         if buffers is None or (buffers.B, buffers.H, buffers.W, buffers.mask) != (B, H, W, mask):

@@ -1091,7 +1091,63 @@ __global__ void k_fill_u32(unsigned* p, unsigned v, size_t n)
 
 bool g_ssao_tables_uploaded[16] = {};
 
+// optional per-phase HIP-event timing (bench.py's roofline leg)
+constexpr int kNumPhases = 8;
+bool g_timing = false;
+hipEvent_t g_ev[kNumPhases + 1];
+bool g_ev_created = false;
+bool g_ev_recorded[kNumPhases + 1];
+bool g_pending = false;
+double g_acc_ms[kNumPhases] = {};
+
+inline void mark(int i, hipStream_t stream)
+{
+    if (!g_timing) return;
+    (void)hipEventRecord(g_ev[i], stream);
+    g_ev_recorded[i] = true;
+}
+
 }  // namespace
+
+// phases: 0 shadow clear+raster, 1 shadow large, 2 vis clear + raster, 3 large, 4 shade, 5 ssao,
+//         6 ssao apply, 7 tone map
+extern "C" int slhip_timing_enable(int on)
+{
+    if (on && !g_ev_created) {
+        for (int i = 0; i <= kNumPhases; ++i) SLHIP_CHECK(hipEventCreate(&g_ev[i]));
+        g_ev_created = true;
+    }
+    g_timing = on != 0;
+    return 0;
+}
+
+static int flush_timings()
+{
+    if (!g_ev_created || !g_pending) return 0;
+    SLHIP_CHECK(hipEventSynchronize(g_ev[kNumPhases]));
+    int prev = -1;
+    for (int i = 0; i <= kNumPhases; ++i) {
+        if (!g_ev_recorded[i]) continue;
+        if (prev >= 0) {
+            float ms = 0.0f;
+            SLHIP_CHECK(hipEventElapsedTime(&ms, g_ev[prev], g_ev[i]));
+            g_acc_ms[prev] += ms;
+        }
+        prev = i;
+    }
+    g_pending = false;
+    return 0;
+}
+
+// returns the per-phase totals accumulated over all slhip_render calls since the last query
+extern "C" int slhip_render_timings(float* ms_out)
+{
+    if (!g_ev_created) { slhip::set_error("timing not enabled"); return -1; }
+    const int st = flush_timings();
+    if (st != 0) return st;
+    for (int i = 0; i < kNumPhases; ++i) { ms_out[i] = (float)g_acc_ms[i]; g_acc_ms[i] = 0.0; }
+    return 0;
+}
 
 // SSAO tables (generated at build time by tools/gen_ssao_tables.py from the recipe of
 // ssao_shader.cpp:72-112)
@@ -1155,14 +1211,21 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
         }
     }
 
+    if (g_timing) {
+        const int fst = flush_timings();  // previous call's events (normally already complete)
+        if (fst != 0) return fst;
+        for (int i = 0; i <= kNumPhases; ++i) g_ev_recorded[i] = false;
+    }
     // shadow pass
     if (shadows && n_chunks > 0) {
+        mark(0, stream);
         const size_t n = (size_t)n_scenes * SLHIP_NUM_LIGHTS * S * S;
         k_fill_u32<<<2048, 256, 0, stream>>>(reinterpret_cast<unsigned*>(scratch->d_shadow), 0x3F800000u, n);
         SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
         k_shadow_raster<<<dim3(n_chunks, SLHIP_NUM_LIGHTS), 256, 0, stream>>>(
             *pool, d_scenes, d_draws, d_chunks, S, reinterpret_cast<unsigned*>(scratch->d_shadow),
             scratch->d_queue, scratch->queue_capacity);
+        mark(1, stream);
         k_shadow_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, S,
                                                  reinterpret_cast<unsigned*>(scratch->d_shadow), scratch->d_queue,
                                                  scratch->queue_capacity);
@@ -1170,12 +1233,14 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     }
 
     // main pass: visibility
+    mark(2, stream);
     SLHIP_CHECK(hipMemsetAsync(scratch->d_vis, 0xFF, (size_t)n_scenes * P * 8, stream));
     SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
     if (n_chunks > 0) {
         k_raster<<<n_chunks, 256, 0, stream>>>(*pool, d_scenes, d_draws, d_chunks, W, H, d_depth_peel,
                                                reinterpret_cast<unsigned long long*>(scratch->d_vis),
                                                scratch->d_queue, scratch->queue_capacity);
+        mark(3, stream);
         k_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, W, H,
                                           reinterpret_cast<unsigned long long*>(scratch->d_vis), scratch->d_queue,
                                           scratch->queue_capacity);
@@ -1191,6 +1256,7 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     prm.want_lum = want_rgb ? 1 : 0;
     float* hdr0 = want_rgb ? scratch->d_hdr : nullptr;
     float* hdr1 = want_rgb ? scratch->d_hdr + 4 * (size_t)n_scenes * P : nullptr;
+    mark(4, stream);
     k_shade<<<pix_blocks, 256, 0, stream>>>(*pool, d_scenes, d_draws, prm,
                                             reinterpret_cast<const unsigned long long*>(scratch->d_vis), *out, hdr0,
                                             shadows ? scratch->d_shadow : nullptr, scratch->d_lum);
@@ -1199,12 +1265,17 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     if (want_rgb) {
         const float* tm_in = hdr0;
         if (ssao) {
+            mark(5, stream);
             k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, W, H, out->d_cam_coord, out->d_normals, scratch->d_ao);
+            mark(6, stream);
             k_ssao_apply<<<pix_blocks, 256, 0, stream>>>(W, H, hdr0, scratch->d_ao, out->d_cam_coord, hdr1);
             tm_in = hdr1;
         }
+        mark(7, stream);
         k_tonemap<<<pix_blocks, 256, 0, stream>>>(d_scenes, W, H, tm_in, scratch->d_lum, out->d_rgb);
         SLHIP_LAUNCH_CHECK();
     }
+    mark(kNumPhases, stream);
+    if (g_timing) g_pending = true;
     return 0;
 }

@@ -121,7 +121,21 @@ struct Contact {
 struct SceneScratch {
     Contact c[kMaxContacts];
     float hp_sep[SLHIP_MAX_HULL_PAIRS];
+#ifdef SLHIP_SETTLE_PROFILE
+    unsigned long long cycles[16];
+    unsigned long long counts[16];
+#endif
 };
+
+#ifdef SLHIP_SETTLE_PROFILE
+#define PROF_T0() unsigned long long _pt = wall_clock64()
+#define PROF(i) do { unsigned long long _n = wall_clock64(); if (threadIdx.x == 0) X.cycles[i] += _n - _pt; _pt = _n; } while (0)
+#define PROF_COUNT(i, v) do { if (threadIdx.x == 0) X.counts[i] += (v); } while (0)
+#else
+#define PROF_T0()
+#define PROF(i)
+#define PROF_COUNT(i, v)
+#endif
 
 struct Shape {
     const float* verts;
@@ -694,6 +708,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
 
     for (unsigned frame = 0; frame < prm.frames; ++frame) {
         for (unsigned sub_ = 0; sub_ < prm.substeps; ++sub_) {
+            PROF_T0();
             // (a) load, integrate forces
             for (int i = lane; i < nb; i += 64) {
                 load_body(bodies[i], wb[i]);
@@ -710,6 +725,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             if (lane == 0) { S.n_hp = 0; S.n_groups = 0; S.n_bp = 0; }
             __syncthreads();
 
+            PROF(0);
             // (b) body-pair broadphase in (i<j) order, ballot-compacted in order
             {
                 const int n_pairs = nb * (nb - 1) / 2;
@@ -744,6 +760,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             }
             __syncthreads();
 
+            PROF(1);
             // (c) hull pairs of every surviving body pair (pairs sequential, combos across lanes)
             {
                 int n_hp = 0, n_groups = 0;
@@ -791,6 +808,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             }
             __syncthreads();
 
+            PROF(2);
             // (d) narrowphase: one lane per hull pair
             {
                 const int n_hp = S.n_hp;
@@ -814,6 +832,8 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                 }
             }
 
+            PROF(3);
+            PROF_COUNT(0, S.n_hp); PROF_COUNT(1, S.n_bp);
             // (e) plane contacts, groups appended in body order
             if (sc.has_plane) {
                 int n_groups = S.n_groups;
@@ -840,6 +860,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             }
             __syncthreads();
 
+            PROF(4);
             // wake sleeping bodies touched by a moving body
             {
                 const int ng = S.n_groups;
@@ -866,6 +887,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     bodies[i].wake_counter = prm.wake_time;
                 }
 
+            PROF(5);
             // (f) prep: every slot of every group
             {
                 const int ng = S.n_groups;
@@ -874,6 +896,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     for (int i = b0 + lane; i < b1; i += 64) prep_contact(&X.c[i], wb);
                 }
             }
+            PROF(6);
             // (g) greedy colouring in group order (serial by definition)
             if (lane == 0) {
                 for (int i = 0; i < nb; ++i) S.used[i] = 0ull;
@@ -893,6 +916,8 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             }
             __syncthreads();
 
+            PROF(7);
+            PROF_COUNT(2, S.n_groups); PROF_COUNT(3, S.n_colors);
             // (h) position iterations
             const int ng = S.n_groups, ncol = S.n_colors;
             for (unsigned it = 0; it < prm.pos_iters; ++it)
@@ -904,6 +929,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     __syncthreads();
                 }
 
+            PROF(8);
             // (i) integrate poses
             for (int i = lane; i < nb; i += 64) {
                 if (!wb[i].dynamic) continue;
@@ -923,6 +949,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             }
             __syncthreads();
 
+            PROF(9);
             // (j) velocity iterations
             for (unsigned it = 0; it < prm.vel_iters; ++it)
                 for (int col = 0; col < ncol; ++col) {
@@ -933,6 +960,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     __syncthreads();
                 }
 
+            PROF(10);
             // (k) store + sleep bookkeeping
             for (int i = lane; i < nb; i += 64) {
                 if (!wb[i].dynamic) continue;
@@ -953,6 +981,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             }
             __threadfence_block();
             __syncthreads();
+            PROF(11);
         }
         // redrop heuristic of simulateTableTopScene (scene.cpp:742-755), serial
         if (prm.tabletop) {

@@ -86,6 +86,27 @@ class Mesh:
         if physics:
             self._load_physics()
 
+    @classmethod
+    def from_data(cls, data, hulls=None, filename="memory://mesh"):
+        """Additive API: wraps an in-memory consolidated mesh (and optionally its convex hulls);
+        used by stillleben_amd.synthetic."""
+        from ._context import require_context
+
+        require_context()
+        self = cls.__new__(cls)
+        self._filename = filename
+        self._flags = Mesh.Flag.NONE
+        self._data = data
+        self._class_index = 1
+        self._scale = f32(1.0)
+        self._pretransform_rigid = np.eye(4, dtype=np.float32)
+        self._pretransform = np.eye(4, dtype=np.float32)
+        self._hulls = list(hulls) if hulls is not None else None
+        self._slot = None
+        self._version = 0
+        self._update_bounding_box()
+        return self
+
     @staticmethod
     def load_threaded(filenames, visual=True, physics=True, flags=()):
         flags = list(flags)

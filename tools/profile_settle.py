@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Developer tool: cycle breakdown of the settle kernel's phases.  Build the library with
+SLHIP_SETTLE_PROFILE=1 (adds wall_clock64 counters), then run this on a GPU box."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import stillleben_amd as sl  # noqa: E402
+from stillleben_amd import _settle_batch as SB, physics, synthetic  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+sl.init_cuda(0)
+meshes = synthetic.ycb_like_meshes(seed=0, tex_size=64)
+scenes = [bench.make_scene(sl, meshes, i) for i in range(B)]
+se = physics.settle_engine()
+planes = [(physics.prepare_tabletop(s), physics.PLANE_HALF_Z) for s in scenes]
+srec, bodies = SB.build_settle_batch(scenes, se.pool, planes)
+prm = SB.default_params(tabletop=True, frames=FRAMES)
+se.scratch(B).zero_()
+d = se.eng.upload_records(bodies)
+torch.cuda.synchronize()
+t = time.perf_counter()
+se.run_device(srec, None, prm, d_bodies=d)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t
+print("B=%d frames=%d: %.1f ms  (%.3f ms per scene-step-batch, %.0f scene-steps/s)" % (B, FRAMES, dt * 1e3, dt * 1e3 / (FRAMES * 4), B * FRAMES * 4 / dt))
+sc = se._scratch.cpu().numpy()
+per = sc.size // B if sc.size % B == 0 else None
+stride = 120 * 2304 + 4 * 512 + 256
+if os.environ.get("SLHIP_SETTLE_PROFILE"):
+    names = ["a load", "b bodypairs", "c hullpairs", "d narrow", "minsep", "e plane", "wake", "f prep", "g color", "h pos it", "i integ", "j vel it", "k store"]
+    tot = np.zeros(16)
+    cnt = np.zeros(16)
+    for b in range(B):
+        off = b * stride + 120 * 2304 + 4 * 512
+        tot += np.frombuffer(sc[off:off + 128].tobytes(), dtype=np.uint64).astype(np.float64)
+        cnt += np.frombuffer(sc[off + 128:off + 256].tobytes(), dtype=np.uint64).astype(np.float64)
+    steps = FRAMES * 4 * B
+    # wall_clock64 ticks at 100 MHz
+    for i, n in enumerate(["a load", "b bodypairs", "c hullpairs", "d narrow", "d2 minsep", "e plane+wake", "f prep", "g color", "h pos", "i integ", "j vel", "k store"]):
+        print("  %-14s %8.2f us/step" % (n, tot[i] / steps / 100.0))
+    print("  avg hull pairs %.1f, body pairs %.1f, groups %.1f, colours %.1f" % tuple(cnt[:4] / steps))
