@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="scenes per GPU per step (one settle launch)")
+    ap.add_argument("--batch", type=int, default=768, help="scenes per GPU per step (one settle launch; 768 = 256 CUs x 3 resident scenes)")
     ap.add_argument("--render-chunk", type=int, default=128, help="scenes per render launch sequence")
     ap.add_argument("--no-ssao", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,6 +91,7 @@ class Pipeline:
             chunks.append(FB.prepare(scenes[c0:c0 + self.render_chunk], self.eng.pool))
         rng = np.random.default_rng(seed)
         item = {
+            "params": SB.sizing_hints(self.params, srec, bodies, self.se.pool.arrays()[0]),
             "scenes": scenes, "srec": srec, "chunks": chunks,
             "d_bodies": self.eng.upload_records(bodies),
             # the random draws of chooseRandomCameraPose / chooseRandomLightDirection
@@ -112,7 +113,7 @@ class Pipeline:
         W, H = RESOLUTION
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         ev[0].record()
-        d_bodies = self.se.run_device(item["srec"], None, self.params, d_bodies=item["d_bodies"])
+        d_bodies = self.se.run_device(item["srec"], None, item["params"], d_bodies=item["d_bodies"])
         ev[1].record()
         # ---- host: settled poses back (one 240 B record per object) ----
         bodies = np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE)

@@ -184,7 +184,9 @@ typedef struct {
     uint32_t vtx_count;
     uint32_t _pad[2];
     float sphere[4];         /* bounding sphere: centre (object frame), radius                */
-} slhip_hull;                /* 32 bytes */
+    float aabb_center[4];    /* object-frame AABB (broadphase: |R| * half is its world box)   */
+    float aabb_half[4];
+} slhip_hull;                /* 64 bytes */
 
 #define SLHIP_BODY_STATIC   1u   /* Object::isStatic -> eKINEMATIC (object.cpp:515-520)       */
 #define SLHIP_BODY_ASLEEP   2u
@@ -235,11 +237,18 @@ typedef struct {
     float stuck_separation;      /* -0.01 (scene.cpp:748)                                     */
     int32_t stuck_frames;        /* 10 = 0.4 s * 25 FPS (scene.cpp:750)                       */
     uint32_t tabletop;           /* 1: run the redrop logic of simulateTableTopScene          */
+    /* LDS sizing hints for the kernel (0 = worst case / hull vertices stay in global memory):
+       maxima over the scenes of the batch                                                   */
+    uint32_t max_bodies_per_scene;
+    uint32_t max_hull_verts_per_scene;   /* sum over a scene's bodies of their hull vertices  */
+    uint32_t max_hulls_per_scene;
 } slhip_settle_params;
 
 /* per-scene scratch (device), sized by slhip_settle_scratch_bytes */
 #define SLHIP_MAX_BODIES     64   /* bodies per scene                                          */
 #define SLHIP_MAX_HULL_PAIRS 512  /* candidate hull pairs per scene and step                   */
+#define SLHIP_MAX_ACTIVE_CONTACTS 160 /* solver contacts per scene and step: plane contacts first,
+                                         then hull-pair contacts in pair order; later ones are dropped */
 
 /* Steps every scene of the batch `frames * substeps` times (one persistent workgroup per
  * scene, no host round trip), including the redrop heuristic when params->tabletop.

@@ -288,9 +288,11 @@ static int reduce_simplex(sv* s, int n, float* lam, v3* v)
 }
 
 /* GJK distance.  Returns 1 and (pa, pb, dist) if the shapes are separated by more than ~1e-6,
-   0 if they touch/overlap. */
+   0 if they touch/overlap, 2 if a separating plane farther than `margin` was found (early out:
+   for any direction v, min over the Minkowski difference of v.x = v.w bounds the distance from
+   below by v.w/|v|). */
 #define GJK_MAX_ITER 32
-static int gjk_distance(const shape* A, const shape* B, v3 init_dir, v3* pa, v3* pb, float* dist)
+static int gjk_distance(const shape* A, const shape* B, v3 init_dir, float margin, v3* pa, v3* pb, float* dist)
 {
     sv s[4];
     float lam[4] = {1, 0, 0, 0};
@@ -298,14 +300,16 @@ static int gjk_distance(const shape* A, const shape* B, v3 init_dir, v3* pa, v3*
     v3 v = init_dir;
     if (dot(v, v) < 1e-12f) v = V(1, 0, 0);
     float vv = dot(v, v);
+    const float m2 = margin * margin;
     for (int it = 0; it < GJK_MAX_ITER; ++it) {
         sv w;
         w.a = support(A, neg(v));
         w.b = support(B, v);
         w.w = sub(w.a, w.b);
+        float vw = dot(v, w.w);
+        if (vw > 0.0f && vw * vw > m2 * vv) return 2;
         if (n > 0) {
             /* no progress towards the origin: v is the closest point */
-            float vw = dot(v, w.w);
             if (vv - vw <= 1e-6f * vv) break;
             int dup = 0;
             for (int i = 0; i < n; ++i)
@@ -329,7 +333,7 @@ static int gjk_distance(const shape* A, const shape* B, v3 init_dir, v3* pa, v3*
     *pa = a; *pb = b;
     float d = sqrtf(vv);
     *dist = d;
-    return d > 1e-6f;
+    return d > 1e-6f ? 1 : 0;
 }
 
 /* tangent basis (deterministic) */
@@ -441,7 +445,9 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     float mu_s = 0.5f * (bodies[ia].mu_s + bodies[ib].mu_s);
     float mu_d = 0.5f * (bodies[ia].mu_d + bodies[ib].mu_d);
     float e = 0.5f * (bodies[ia].restitution + bodies[ib].restitution);
-    if (!gjk_distance(&A, &B, sub(ca, cb), &pa, &pb, &dist)) {
+    int code = gjk_distance(&A, &B, sub(ca, cb), margin, &pa, &pb, &dist);
+    if (code == 2) return 3.0e38f;
+    if (code == 0) {
         float sep;
         overlap_fallback(&A, &B, ca, cb, &n, &sep, &pa, &pb);
         if (sep > 0.0f) sep = 0.0f;
@@ -482,9 +488,9 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
         T.t = sub(cw, m3_mul(&T.R, cl));
         v3 qa, qb;
         float d2;
-        int ok = tilt_a ? gjk_distance(&T, &B, sub(ca, cb), &qa, &qb, &d2)
-                        : gjk_distance(&A, &T, sub(ca, cb), &qa, &qb, &d2);
-        if (!ok) continue;
+        int ok = tilt_a ? gjk_distance(&T, &B, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2)
+                        : gjk_distance(&A, &T, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2);
+        if (ok != 1) continue;
         /* map the witness on the tilted shape back to the untilted pose */
         if (tilt_a) {
             v3 loc = m3_tmul(&T.R, sub(qa, T.t));
@@ -517,7 +523,23 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     return mins;
 }
 
-/* body vs plane (top face of the table box, scene.cpp:629-663): up to 4 contacts */
+/* body vs plane (top face of the table box, scene.cpp:629-663): up to 4 contacts chosen from ALL
+   hull vertices inside the contact band by four order-independent reductions with first-index
+   tie breaks (the same selection rule as reduce4, without a candidate buffer):
+     i0 = argmin sep;  i1 = argmax |p - p0| - W (sep - sep0);
+     i2 = argmax  area(p0,p1,p) - W (sep - sep0) |p1 - p0|   (only if > 0)
+     i3 = argmin  area(p0,p1,p) + W (sep - sep0) |p1 - p0|   (only if < 0)                    */
+typedef struct { const wbody* w; const slhip_body* b; const slhip_hull* hulls; const float* verts; float plane_z, margin; } plane_it;
+
+static int plane_vertex(const plane_it* it, uint32_t h, uint32_t i, v3* p, float* d)
+{
+    const slhip_hull* hh = &it->hulls[h];
+    const float* vs = it->verts + 4 * (size_t)hh->vtx_begin;
+    *p = add(m3_mul(&it->w->R, V(vs[4 * i], vs[4 * i + 1], vs[4 * i + 2])), it->w->t);
+    *d = p->z - it->plane_z;
+    return *d <= it->margin;
+}
+
 static void plane_contacts(const slhip_body* bodies, const wbody* wbs, int ia, const slhip_hull* hulls,
                            const float* hull_verts, const slhip_settle_params* prm, float plane_z,
                            float margin, contact* out)
@@ -525,41 +547,53 @@ static void plane_contacts(const slhip_body* bodies, const wbody* wbs, int ia, c
     for (int i = 0; i < PLANE_SLOTS; ++i) out[i].valid = 0;
     const slhip_body* b = &bodies[ia];
     const wbody* w = &wbs[ia];
-    /* candidate = every hull vertex closer than the margin; reduce on the fly to bounded sets:
-       keep deepest and the extreme points by a streaming 4-point reduction over a fixed
-       candidate buffer of 64 (deepest-first replacement) */
-    v3 cand[64];
-    float cs[64];
-    int nc = 0;
-    for (uint32_t h = b->hull_begin; h < b->hull_end; ++h) {
-        const slhip_hull* hh = &hulls[h];
-        v3 c = add(m3_mul(&w->R, V(hh->sphere[0], hh->sphere[1], hh->sphere[2])), w->t);
-        if (c.z - hh->sphere[3] - plane_z > margin) continue;
-        const float* vs = hull_verts + 4 * (size_t)hh->vtx_begin;
-        for (uint32_t i = 0; i < hh->vtx_count; ++i) {
-            v3 p = add(m3_mul(&w->R, V(vs[4 * i], vs[4 * i + 1], vs[4 * i + 2])), w->t);
-            float d = p.z - plane_z;
-            if (d > margin) continue;
-            if (nc < 64) { cand[nc] = p; cs[nc] = d; ++nc; }
-            else {
-                /* replace the shallowest candidate if this one is deeper */
-                int worst = 0;
-                for (int k = 1; k < 64; ++k) if (cs[k] > cs[worst]) worst = k;
-                if (d < cs[worst]) { cand[worst] = p; cs[worst] = d; }
-            }
+    plane_it it = {w, b, hulls, hull_verts, plane_z, margin};
+    /* pass 0: deepest */
+    int have0 = 0; v3 p0 = V(0, 0, 0); float s0 = 0.0f;
+    for (uint32_t h = b->hull_begin; h < b->hull_end; ++h)
+        for (uint32_t i = 0; i < hulls[h].vtx_count; ++i) {
+            v3 p; float d;
+            if (!plane_vertex(&it, h, i, &p, &d)) continue;
+            if (!have0 || d < s0) { have0 = 1; p0 = p; s0 = d; }
         }
-    }
-    if (nc == 0) return;
-    int keep[4];
+    if (!have0) return;
+    /* pass 1: farthest (depth-penalised) */
+    int have1 = 0; v3 p1 = V(0, 0, 0); float s1 = 0.0f, best = 0.0f;
+    for (uint32_t h = b->hull_begin; h < b->hull_end; ++h)
+        for (uint32_t i = 0; i < hulls[h].vtx_count; ++i) {
+            v3 p; float d;
+            if (!plane_vertex(&it, h, i, &p, &d)) continue;
+            v3 dd = sub(p, p0);
+            float score = sqrtf(dot(dd, dd)) - DEPTH_WEIGHT * (d - s0);
+            if (score > 0.0f && (!have1 || score > best)) { have1 = 1; best = score; p1 = p; s1 = d; }
+        }
     v3 n = V(0, 0, 1);
-    int nk = reduce4(nc, cand, cs, n, keep);
+    v3 sel[4]; float ss[4]; int nk = 0;
+    sel[nk] = p0; ss[nk++] = s0;
+    if (have1) {
+        sel[nk] = p1; ss[nk++] = s1;
+        /* pass 2+3: area extremes */
+        v3 e = sub(p1, p0);
+        float el = sqrtf(dot(e, e));
+        int have2 = 0, have3 = 0; v3 p2 = V(0, 0, 0), p3 = V(0, 0, 0); float s2 = 0, s3 = 0, mx = 0.0f, mn = 0.0f;
+        for (uint32_t h = b->hull_begin; h < b->hull_end; ++h)
+            for (uint32_t i = 0; i < hulls[h].vtx_count; ++i) {
+                v3 p; float d;
+                if (!plane_vertex(&it, h, i, &p, &d)) continue;
+                float a = dot(cross(e, sub(p, p0)), n);
+                float pen = DEPTH_WEIGHT * (d - s0) * el;
+                if (a - pen > mx) { mx = a - pen; have2 = 1; p2 = p; s2 = d; }
+                if (a + pen < mn) { mn = a + pen; have3 = 1; p3 = p; s3 = d; }
+            }
+        if (have2) { sel[nk] = p2; ss[nk++] = s2; }
+        if (have3) { sel[nk] = p3; ss[nk++] = s3; }
+    }
     float mu_s = 0.5f * (b->mu_s + prm->plane_mu_s);
     float mu_d = 0.5f * (b->mu_d + prm->plane_mu_d);
-    float e = 0.5f * (b->restitution + prm->plane_restitution);
+    float e_ = 0.5f * (b->restitution + prm->plane_restitution);
     for (int i = 0; i < nk; ++i) {
-        int j = keep[i];
-        v3 pb = V(cand[j].x, cand[j].y, plane_z);
-        fill_contact(&out[i], ia, -1, w, NULL, cand[j], pb, n, cs[j], prm->rest_offset, mu_s, mu_d, e);
+        v3 pb = V(sel[i].x, sel[i].y, plane_z);
+        fill_contact(&out[i], ia, -1, w, NULL, sel[i], pb, n, ss[i], prm->rest_offset, mu_s, mu_d, e_);
     }
 }
 
@@ -677,6 +711,22 @@ static void solve_iteration(scene_ws* ws, const slhip_settle_params* prm, int bi
         }
 }
 
+/* world AABB of a hull = |R| * local half extents around R c + t; boxes must overlap within margin */
+static int aabb_overlap(const wbody* wa, const slhip_hull* ha, const wbody* wb_, const slhip_hull* hb, float margin)
+{
+    v3 ca = add(m3_mul(&wa->R, V(ha->aabb_center[0], ha->aabb_center[1], ha->aabb_center[2])), wa->t);
+    v3 cb = add(m3_mul(&wb_->R, V(hb->aabb_center[0], hb->aabb_center[1], hb->aabb_center[2])), wb_->t);
+    float ea[3], eb[3];
+    for (int r = 0; r < 3; ++r) {
+        ea[r] = fmaf(fabsf(wa->R.m[3 * r + 2]), ha->aabb_half[2], fmaf(fabsf(wa->R.m[3 * r + 1]), ha->aabb_half[1], fabsf(wa->R.m[3 * r]) * ha->aabb_half[0]));
+        eb[r] = fmaf(fabsf(wb_->R.m[3 * r + 2]), hb->aabb_half[2], fmaf(fabsf(wb_->R.m[3 * r + 1]), hb->aabb_half[1], fabsf(wb_->R.m[3 * r]) * hb->aabb_half[0]));
+    }
+    if (fabsf(ca.x - cb.x) > ea[0] + eb[0] + margin) return 0;
+    if (fabsf(ca.y - cb.y) > ea[1] + eb[1] + margin) return 0;
+    if (fabsf(ca.z - cb.z) > ea[2] + eb[2] + margin) return 0;
+    return 1;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* one step                                                                                    */
 /* ------------------------------------------------------------------------------------------ */
@@ -739,9 +789,28 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         }
     }
 
-    /* (b,c) broadphase: body pairs in (i<j) order, then their hull pairs */
     ws->n_hp = 0;
     ws->n_groups = 0;
+    /* (b) plane contacts FIRST: one group per dynamic body near the table (their contacts have
+       priority under the active-contact cap); slots live after the hull-pair slots */
+    const int plane_base = SLHIP_MAX_HULL_PAIRS * MAX_CONTACTS_PER_HP;
+    if (sc->has_plane) {
+        for (int i = 0; i < nb; ++i) {
+            if (!wb[i].dynamic) continue;
+            v3 ci = add(m3_mul(&wb[i].R, V(bodies[i].bsphere[0], bodies[i].bsphere[1], bodies[i].bsphere[2])), wb[i].t);
+            float vz = wb[i].v.z < 0.0f ? -wb[i].v.z * dt : 0.0f;
+            float margin = prm->contact_offset + vz;
+            if (ci.z - bodies[i].bsphere[3] - sc->plane_z > margin) continue;
+            contact* out = &ws->c[plane_base + i * PLANE_SLOTS];
+            plane_contacts(bodies, wb, i, hulls, hull_verts, prm, sc->plane_z, margin, out);
+            int g = ws->n_groups++;
+            ws->g_a[g] = i; ws->g_b[g] = -1;
+            ws->g_begin[g] = plane_base + i * PLANE_SLOTS;
+            ws->g_end[g] = plane_base + (i + 1) * PLANE_SLOTS;
+        }
+    }
+
+    /* (c) broadphase: body pairs in (i<j) order, then their hull pairs */
     for (int i = 0; i < nb; ++i)
         for (int j = i + 1; j < nb; ++j) {
             if (!wb[i].dynamic && !wb[j].dynamic) continue;
@@ -762,6 +831,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
                     v3 dd = sub(ca, cb);
                     float r2 = hulls[ha].sphere[3] + hulls[hb].sphere[3] + margin;
                     if (dot(dd, dd) > r2 * r2) continue;
+                    if (!aabb_overlap(&wb[i], &hulls[ha], &wb[j], &hulls[hb], margin)) continue;
                     if (ws->n_hp >= SLHIP_MAX_HULL_PAIRS) continue; /* overflow: dropped (deterministic) */
                     int k = ws->n_hp++;
                     ws->hp_ba[k] = i; ws->hp_bb[k] = j; ws->hp_ha[k] = (int)ha; ws->hp_hb[k] = (int)hb;
@@ -773,7 +843,6 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
                 ws->g_end[g] = ws->n_hp * MAX_CONTACTS_PER_HP;
             }
         }
-    const int n_pair_groups = ws->n_groups;
 
     /* (d) narrowphase per hull pair */
     for (int k = 0; k < ws->n_hp; ++k) {
@@ -787,24 +856,16 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         if (s < bodies[j].separation) bodies[j].separation = s;
     }
 
-    /* (e) plane contacts: one group per dynamic body, slots after the hull-pair slots */
-    const int plane_base = SLHIP_MAX_HULL_PAIRS * MAX_CONTACTS_PER_HP;
-    if (sc->has_plane) {
-        for (int i = 0; i < nb; ++i) {
-            if (!wb[i].dynamic) continue;
-            v3 ci = add(m3_mul(&wb[i].R, V(bodies[i].bsphere[0], bodies[i].bsphere[1], bodies[i].bsphere[2])), wb[i].t);
-            float vz = wb[i].v.z < 0.0f ? -wb[i].v.z * dt : 0.0f;
-            float margin = prm->contact_offset + vz;
-            if (ci.z - bodies[i].bsphere[3] - sc->plane_z > margin) continue;
-            contact* out = &ws->c[plane_base + i * PLANE_SLOTS];
-            plane_contacts(bodies, wb, i, hulls, hull_verts, prm, sc->plane_z, margin, out);
-            int g = ws->n_groups++;
-            ws->g_a[g] = i; ws->g_b[g] = -1;
-            ws->g_begin[g] = plane_base + i * PLANE_SLOTS;
-            ws->g_end[g] = plane_base + (i + 1) * PLANE_SLOTS;
-        }
+    /* active-contact cap (SLHIP_MAX_ACTIVE_CONTACTS): walk the groups in order, drop the rest */
+    {
+        int active = 0;
+        for (int g = 0; g < ws->n_groups; ++g)
+            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) {
+                if (!ws->c[i].valid) continue;
+                if (active >= SLHIP_MAX_ACTIVE_CONTACTS) ws->c[i].valid = 0;
+                else ++active;
+            }
     }
-    (void)n_pair_groups;
 
     /* wake sleeping bodies touched by a moving body */
     for (int g = 0; g < ws->n_groups; ++g) {
@@ -959,7 +1020,7 @@ int slref_overlap_any(const slhip_settle_scene* scenes, uint32_t n_scenes, const
                         float r2 = hulls[ha].sphere[3] + hulls[hb].sphere[3];
                         if (dot(dd, dd) > r2 * r2) continue;
                         v3 pa, pb; float dist;
-                        if (!gjk_distance(&A, &B, dd, &pa, &pb, &dist)) hit = 1;
+                        if (gjk_distance(&A, &B, dd, 0.0f, &pa, &pb, &dist) == 0) hit = 1;
                     }
             }
             if (!hit && sc->has_plane) {

@@ -20,8 +20,8 @@ BODY_DTYPE = np.dtype([
 assert BODY_DTYPE.itemsize == 240
 
 HULL_DTYPE = np.dtype([("vtx_begin", np.uint32), ("vtx_count", np.uint32), ("_pad", np.uint32, (2,)),
-                       ("sphere", np.float32, (4,))])
-assert HULL_DTYPE.itemsize == 32
+                       ("sphere", np.float32, (4,)), ("aabb_center", np.float32, (4,)), ("aabb_half", np.float32, (4,))])
+assert HULL_DTYPE.itemsize == 64
 
 SETTLE_SCENE_DTYPE = np.dtype([("body_begin", np.uint32), ("body_end", np.uint32), ("has_plane", np.uint32),
                                ("plane_z", np.float32)])
@@ -33,8 +33,9 @@ PARAMS_DTYPE = np.dtype([
     ("wake_time", np.float32), ("angular_damping", np.float32), ("max_angular_velocity", np.float32),
     ("plane_mu_s", np.float32), ("plane_mu_d", np.float32), ("plane_restitution", np.float32),
     ("redrop_z", np.float32), ("stuck_separation", np.float32), ("stuck_frames", np.int32), ("tabletop", np.uint32),
+    ("max_bodies_per_scene", np.uint32), ("max_hull_verts_per_scene", np.uint32), ("max_hulls_per_scene", np.uint32),
 ])
-assert PARAMS_DTYPE.itemsize == 88
+assert PARAMS_DTYPE.itemsize == 100
 
 BODY_STATIC = 1
 BODY_ASLEEP = 2
@@ -90,6 +91,8 @@ class HullPool:
             h = np.zeros((), dtype=HULL_DTYPE)
             h["vtx_begin"], h["vtx_count"] = self.n_verts, len(v)
             h["sphere"][:3], h["sphere"][3] = c, r_
+            h["aabb_center"][:3] = c
+            h["aabb_half"][:3] = ((v.max(axis=0) - v.min(axis=0)) / f32(2.0)).astype(np.float32)
             self.hulls.append(h)
             self.verts.append(np.concatenate([v, np.ones((len(v), 1), np.float32)], axis=1))
             self.n_verts += len(v)
@@ -153,6 +156,25 @@ def build_settle_batch(scenes, pool, with_plane):
         srec[si]["has_plane"] = 1 if with_plane[si][0] else 0
         srec[si]["plane_z"] = with_plane[si][1]
     return srec, bodies
+
+
+def sizing_hints(params, srec, bodies, hulls):
+    """Fills the LDS sizing hints of slhip_settle_params from a built batch."""
+    mb, mv, mh = 0, 0, 0
+    cnt = hulls["vtx_count"].astype(np.int64)
+    csum = np.concatenate([[0], np.cumsum(cnt)])
+    per_body_v = csum[bodies["hull_end"]] - csum[bodies["hull_begin"]]
+    per_body_h = bodies["hull_end"].astype(np.int64) - bodies["hull_begin"].astype(np.int64)
+    bv = np.concatenate([[0], np.cumsum(per_body_v)])
+    bh = np.concatenate([[0], np.cumsum(per_body_h)])
+    b0, b1 = srec["body_begin"].astype(np.int64), srec["body_end"].astype(np.int64)
+    if len(srec):
+        mb = int((b1 - b0).max())
+        mv = int((bv[b1] - bv[b0]).max())
+        mh = int((bh[b1] - bh[b0]).max())
+    params = params.copy()
+    params["max_bodies_per_scene"], params["max_hull_verts_per_scene"], params["max_hulls_per_scene"] = mb, mv, mh
+    return params
 
 
 def write_back(scenes, bodies):

@@ -20,14 +20,12 @@
 namespace {
 
 static_assert(sizeof(slhip_body) == 240, "slhip_body layout");
-static_assert(sizeof(slhip_hull) == 32, "slhip_hull layout");
-static_assert(sizeof(slhip_settle_params) == 88, "slhip_settle_params layout");
+static_assert(sizeof(slhip_hull) == 64, "slhip_hull layout");
+static_assert(sizeof(slhip_settle_params) == 100, "slhip_settle_params layout");
 
 constexpr int kMaxContactsPerHP = 4;
-constexpr int kPlaneSlots = 4;
 constexpr int kMaxGroups = SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES;
-constexpr int kMaxContacts = kMaxGroups * kMaxContactsPerHP;
-constexpr int kPlaneBase = SLHIP_MAX_HULL_PAIRS * kMaxContactsPerHP;
+constexpr int kMaxActive = SLHIP_MAX_ACTIVE_CONTACTS;
 constexpr float kInf = 3.0e38f;
 constexpr float kDepthWeight = 30.0f;
 
@@ -110,54 +108,69 @@ struct WBody {
     float inv_mass; int dynamic;
 };
 
+// solver contact, compacted in LDS (plane contacts first, then hull-pair contacts in pair order)
 struct Contact {
-    int a, b;
+    short a, b;
     v3 ra, rb, n, t1, t2;
-    float sep, rest, kn, kt1, kt2, ln, lt1, lt2, vn0, mu_s, mu_d, e;
-    int valid;
+    float err;            // sep - rest
+    float kn, kt1, kt2, ln, lt1, lt2, vn0, mu_s, mu_d, e;
 };
 
-// per-scene scratch in global memory (L2 resident)
-struct SceneScratch {
-    Contact c[kMaxContacts];
-    float hp_sep[SLHIP_MAX_HULL_PAIRS];
-#ifdef SLHIP_SETTLE_PROFILE
-    unsigned long long cycles[16];
-    unsigned long long counts[16];
-#endif
+// raw narrowphase result of one hull pair / one body-vs-plane test (registers)
+struct RawContacts {
+    v3 pa[4], pb[4];
+    float sep[4];
+    v3 n;
+    int count;
 };
 
 #ifdef SLHIP_SETTLE_PROFILE
+struct ProfScratch { unsigned long long cycles[16]; unsigned long long counts[16]; };
 #define PROF_T0() unsigned long long _pt = wall_clock64()
 #define PROF(i) do { unsigned long long _n = wall_clock64(); if (threadIdx.x == 0) X.cycles[i] += _n - _pt; _pt = _n; } while (0)
 #define PROF_COUNT(i, v) do { if (threadIdx.x == 0) X.counts[i] += (v); } while (0)
 #else
+struct ProfScratch { unsigned long long unused; };
 #define PROF_T0()
 #define PROF(i)
 #define PROF_COUNT(i, v)
 #endif
 
+// hull vertices: either in the scene's LDS copy (index into hv) or in the global pool
 struct Shape {
-    const float* verts;
+    const float4* g;   // global vertices (valid when lds < 0)
+    int lds;           // first vertex in the LDS copy, or -1
     int count;
     m3 R;
     v3 t;
 };
 
-__device__ __forceinline__ v3 support(const Shape& s, v3 d)
+// argmax_i dot(v_i, d) with first-maximum tie break.  Vertices are fetched eight at a time so
+// that the (LDS or L1) latency of the batch overlaps; the compare chain stays in index order.
+__device__ __forceinline__ v3 support(const Shape& s, const float4* __restrict__ hv, v3 d)
 {
     const v3 dl = m3_tmul(s.R, d);
     int best = 0;
-    const float4* vp = reinterpret_cast<const float4*>(s.verts);
-    float4 p0 = vp[0];
-    float bd = dot(V(p0.x, p0.y, p0.z), dl);
-    for (int i = 1; i < s.count; ++i) {
-        const float4 p = vp[i];
-        const float dd = dot(V(p.x, p.y, p.z), dl);
-        if (dd > bd) { bd = dd; best = i; }
+    float bd = -3.0e38f;
+    float4 bp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int n = s.count;
+    for (int base = 0; base < n; base += 8) {
+        float4 p[8];
+        if (s.lds >= 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = hv[s.lds + min(base + j, n - 1)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = s.g[min(base + j, n - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float dd = dot(V(p[j].x, p[j].y, p[j].z), dl);
+            if (base + j < n && dd > bd) { bd = dd; best = base + j; bp = p[j]; }
+        }
     }
-    const float4 p = vp[best];
-    return add(m3_mul(s.R, V(p.x, p.y, p.z)), s.t);
+    (void)best;
+    return add(m3_mul(s.R, V(bp.x, bp.y, bp.z)), s.t);
 }
 
 struct SV { v3 w, a, b; };
@@ -220,89 +233,135 @@ __device__ __forceinline__ bool outside_plane(v3 a, v3 b, v3 c, v3 d)
     return sp * sd < 0.0f || sd == 0.0f;
 }
 
-__device__ int reduce_simplex(SV* s, int n, float* lam, v3* v)
+// The simplex lives in four named registers sets (no runtime-indexed arrays: those would be
+// placed in scratch memory, cdna_hip_programming.md rule 20).  Same arithmetic as the oracle's
+// array version.
+struct Simplex {
+    SV p0, p1, p2, p3;
+    float l0, l1, l2, l3;
+    int n;
+};
+
+__device__ __forceinline__ SV sel3(const SV& a, const SV& b, const SV& c, int i) { return i == 0 ? a : (i == 1 ? b : c); }
+__device__ __forceinline__ float self3(float a, float b, float c, int i) { return i == 0 ? a : (i == 1 ? b : c); }
+
+// keeps the vertices of (a,b,c) whose bit is set in mask, in order, with their weights
+__device__ __forceinline__ void keep_masked(Simplex& S, const SV& a, const SV& b, const SV& c, float la, float lb, float lc,
+                                            int mask)
 {
-    if (n == 1) { lam[0] = 1.0f; *v = s[0].w; return 1; }
-    if (n == 2) {
+    // index of the k-th set bit among bits 0..2
+    const int b0 = mask & 1, b1 = (mask >> 1) & 1, b2 = (mask >> 2) & 1;
+    const int first = b0 ? 0 : (b1 ? 1 : 2);
+    const int second = (b0 && b1) ? 1 : 2;  // valid when popcount >= 2
+    const int cnt = b0 + b1 + b2;
+    S.p0 = sel3(a, b, c, first); S.l0 = self3(la, lb, lc, first);
+    if (cnt >= 2) { S.p1 = sel3(a, b, c, second); S.l1 = self3(la, lb, lc, second); }
+    if (cnt >= 3) { S.p2 = c; S.l2 = lc; }
+    S.n = cnt;
+}
+
+// returns the new size (0 = origin inside a tetrahedron) and the closest point in *v
+__device__ int reduce_simplex(Simplex& S, v3* v)
+{
+    if (S.n == 1) { S.l0 = 1.0f; *v = S.p0.w; return 1; }
+    if (S.n == 2) {
         float l[2];
-        const int mask = closest_segment(s, l);
-        *v = madd(scale(s[0].w, l[0]), s[1].w, l[1]);
-        if (mask == 1) { lam[0] = 1.0f; return 1; }
-        if (mask == 2) { s[0] = s[1]; lam[0] = 1.0f; return 1; }
-        lam[0] = l[0]; lam[1] = l[1];
+        SV two[2] = {S.p0, S.p1};
+        const int mask = closest_segment(two, l);
+        *v = madd(scale(S.p0.w, l[0]), S.p1.w, l[1]);
+        if (mask == 1) { S.l0 = 1.0f; S.n = 1; return 1; }
+        if (mask == 2) { S.p0 = S.p1; S.l0 = 1.0f; S.n = 1; return 1; }
+        S.l0 = l[0]; S.l1 = l[1];
         return 2;
     }
-    if (n == 3) {
+    if (S.n == 3) {
         float l[3];
-        const int mask = closest_triangle(s[0].w, s[1].w, s[2].w, l);
-        *v = comb3(s[0].w, s[1].w, s[2].w, l);
-        int k = 0;
-        for (int i = 0; i < 3; ++i)
-            if (mask & (1 << i)) { s[k] = s[i]; lam[k] = l[i]; ++k; }
-        return k;
+        const int mask = closest_triangle(S.p0.w, S.p1.w, S.p2.w, l);
+        *v = comb3(S.p0.w, S.p1.w, S.p2.w, l);
+        const SV a = S.p0, b = S.p1, c = S.p2;
+        keep_masked(S, a, b, c, l[0], l[1], l[2], mask);
+        return S.n;
     }
-    const int F[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}};
+    // tetrahedron: faces (0,1,2|3) (0,2,3|1) (0,3,1|2) (1,3,2|0), first-best wins
     float best = 3.0e38f;
     int best_mask = 0, best_face = -1;
-    float best_l[3] = {0, 0, 0};
+    float bl0 = 0, bl1 = 0, bl2 = 0;
     v3 best_v = V(0, 0, 0);
+#pragma unroll
     for (int f = 0; f < 4; ++f) {
-        const v3 a = s[F[f][0]].w, b = s[F[f][1]].w, c = s[F[f][2]].w, d = s[F[f][3]].w;
-        if (!outside_plane(a, b, c, d)) continue;
+        const SV& A = (f == 3) ? S.p1 : S.p0;
+        const SV& B = (f == 0) ? S.p1 : (f == 1 ? S.p2 : S.p3);
+        const SV& C = (f == 0) ? S.p2 : (f == 1 ? S.p3 : (f == 2 ? S.p1 : S.p2));
+        const SV& D = (f == 0) ? S.p3 : (f == 1 ? S.p1 : (f == 2 ? S.p2 : S.p0));
+        if (!outside_plane(A.w, B.w, C.w, D.w)) continue;
         float l[3];
-        const int mask = closest_triangle(a, b, c, l);
-        const v3 q = comb3(a, b, c, l);
+        const int mask = closest_triangle(A.w, B.w, C.w, l);
+        const v3 q = comb3(A.w, B.w, C.w, l);
         const float dd = dot(q, q);
-        if (dd < best) { best = dd; best_mask = mask; best_face = f; best_l[0] = l[0]; best_l[1] = l[1]; best_l[2] = l[2]; best_v = q; }
+        if (dd < best) { best = dd; best_mask = mask; best_face = f; bl0 = l[0]; bl1 = l[1]; bl2 = l[2]; best_v = q; }
     }
     if (best_face < 0) return 0;
-    const SV t[3] = {s[F[best_face][0]], s[F[best_face][1]], s[F[best_face][2]]};
-    int k = 0;
-    for (int i = 0; i < 3; ++i)
-        if (best_mask & (1 << i)) { s[k] = t[i]; lam[k] = best_l[i]; ++k; }
+    const SV q0 = S.p0, q1 = S.p1, q2 = S.p2, q3 = S.p3;
+    const SV A = (best_face == 3) ? q1 : q0;
+    const SV B = (best_face == 0) ? q1 : (best_face == 1 ? q2 : q3);
+    const SV C = (best_face == 0) ? q2 : (best_face == 1 ? q3 : (best_face == 2 ? q1 : q2));
+    keep_masked(S, A, B, C, bl0, bl1, bl2, best_mask);
     *v = best_v;
-    return k;
+    return S.n;
 }
 
 constexpr int kGjkMaxIter = 32;
 
-__device__ int gjk_distance(const Shape& A, const Shape& B, v3 init_dir, v3* pa, v3* pb, float* dist)
+__device__ __forceinline__ bool same_w(const SV& a, const SV& b)
 {
-    SV s[4];
-    float lam[4] = {1, 0, 0, 0};
-    int n = 0;
+    return a.w.x == b.w.x && a.w.y == b.w.y && a.w.z == b.w.z;
+}
+
+// returns 1 (separated, witnesses valid), 0 (touching / overlapping), 2 (farther than margin)
+__device__ int gjk_distance(const Shape& A, const Shape& B, const float4* __restrict__ hv, v3 init_dir, float margin,
+                            v3* pa, v3* pb, float* dist)
+{
+    Simplex S;
+    S.n = 0;
+    S.l0 = 1.0f; S.l1 = S.l2 = S.l3 = 0.0f;
     v3 v = init_dir;
     if (dot(v, v) < 1e-12f) v = V(1, 0, 0);
     float vv = dot(v, v);
+    const float m2 = margin * margin;
     for (int it = 0; it < kGjkMaxIter; ++it) {
         SV w;
-        w.a = support(A, neg(v));
-        w.b = support(B, v);
+        w.a = support(A, hv, neg(v));
+        w.b = support(B, hv, v);
         w.w = sub(w.a, w.b);
+        const float vw = dot(v, w.w);
+        if (vw > 0.0f && vw * vw > m2 * vv) return 2;
+        const int n = S.n;
         if (n > 0) {
-            const float vw = dot(v, w.w);
             if (vv - vw <= 1e-6f * vv) break;
-            bool dup = false;
-            for (int i = 0; i < n; ++i)
-                if (s[i].w.x == w.w.x && s[i].w.y == w.w.y && s[i].w.z == w.w.z) dup = true;
+            bool dup = same_w(S.p0, w);
+            if (n > 1) dup = dup || same_w(S.p1, w);
+            if (n > 2) dup = dup || same_w(S.p2, w);
             if (dup) break;
         }
-        s[n++] = w;
+        if (n == 0) S.p0 = w; else if (n == 1) S.p1 = w; else if (n == 2) S.p2 = w; else S.p3 = w;
+        S.n = n + 1;
         v3 nv;
-        const int nn = reduce_simplex(s, n, lam, &nv);
+        const int nn = reduce_simplex(S, &nv);
         if (nn == 0) return 0;
         const float nvv = dot(nv, nv);
-        if (n > 1 && nvv >= vv && it > 0) { n = nn; v = nv; vv = nvv; break; }
-        n = nn; v = nv; vv = nvv;
+        if (n + 1 > 1 && nvv >= vv && it > 0) { v = nv; vv = nvv; break; }
+        v = nv; vv = nvv;
         if (vv < 1e-12f) return 0;
     }
-    if (n == 0) return 0;
+    if (S.n == 0) return 0;
     v3 a = V(0, 0, 0), b = V(0, 0, 0);
-    for (int i = 0; i < n; ++i) { a = madd(a, s[i].a, lam[i]); b = madd(b, s[i].b, lam[i]); }
+    a = madd(a, S.p0.a, S.l0); b = madd(b, S.p0.b, S.l0);
+    if (S.n > 1) { a = madd(a, S.p1.a, S.l1); b = madd(b, S.p1.b, S.l1); }
+    if (S.n > 2) { a = madd(a, S.p2.a, S.l2); b = madd(b, S.p2.b, S.l2); }
     *pa = a; *pb = b;
     const float d = sqrtf(vv);
     *dist = d;
-    return d > 1e-6f;
+    return d > 1e-6f ? 1 : 0;
 }
 
 __device__ __forceinline__ void tangents(v3 n, v3* t1, v3* t2)
@@ -315,7 +374,8 @@ __device__ __forceinline__ void tangents(v3 n, v3* t1, v3* t2)
     *t2 = cross(n, *t1);
 }
 
-__device__ void overlap_fallback(const Shape& A, const Shape& B, v3 ca, v3 cb, v3* n, float* sep, v3* pa, v3* pb)
+__device__ void overlap_fallback(const Shape& A, const Shape& B, const float4* __restrict__ hv, v3 ca, v3 cb, v3* n,
+                                 float* sep, v3* pa, v3* pb)
 {
     v3 axes[7];
     const v3 c = sub(ca, cb);
@@ -324,106 +384,149 @@ __device__ void overlap_fallback(const Shape& A, const Shape& B, v3 ca, v3 cb, v
     axes[1] = V(1, 0, 0); axes[2] = V(-1, 0, 0); axes[3] = V(0, 1, 0);
     axes[4] = V(0, -1, 0); axes[5] = V(0, 0, 1); axes[6] = V(0, 0, -1);
     float best = -3.0e38f;
+#pragma unroll
     for (int i = 0; i < 7; ++i) {
-        const v3 a = support(A, neg(axes[i]));
-        const v3 b = support(B, axes[i]);
+        const v3 a = support(A, hv, neg(axes[i]));
+        const v3 b = support(B, hv, axes[i]);
         const float s = dot(sub(a, b), axes[i]);
         if (s > best) { best = s; *n = axes[i]; *pa = a; *pb = b; }
     }
     *sep = best;
 }
 
-__device__ __forceinline__ void make_shape(const WBody& wb, const slhip_hull& h, const float* hull_verts, Shape& s)
+// hull description resolved for this scene: vertices either in LDS (copied once per settle) or
+// in the global pool
+struct HullRef {
+    const float4* g;
+    int lds;
+    int count;
+    v3 sc;          // bounding sphere centre (object frame)
+    float sr;
+};
+
+__device__ __forceinline__ void make_shape(const WBody& wb, const HullRef& h, Shape& s)
 {
-    s.verts = hull_verts + 4 * (size_t)h.vtx_begin;
-    s.count = (int)h.vtx_count;
+    s.g = h.g;
+    s.lds = h.lds;
+    s.count = h.count;
     s.R = wb.R;
     s.t = wb.t;
 }
 
-__device__ int reduce4(int n, const v3* p, const float* sep, v3 nrm, int* keep)
+// Manifold reduction over five FIXED candidate slots (slot 0 = the GJK witness pair, slots 1..4 =
+// the four tilt runs, in order) with a validity mask -- the register-resident equivalent of the
+// oracle's reduce4 over its compacted candidate list (same order, same first-index tie breaks).
+struct Cand5 {
+    v3 p[5], q[5];
+    float s[5];
+    bool ok[5];
+};
+
+__device__ __forceinline__ void emit(RawContacts& out, int& k, const Cand5& c, int i)
 {
-    if (n <= 4) { for (int i = 0; i < n; ++i) keep[i] = i; return n; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+        if (j == i) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t == k) { out.pa[t] = c.p[j]; out.pb[t] = c.q[j]; out.sep[t] = c.s[j]; }
+        }
+    ++k;
+}
+
+__device__ __forceinline__ v3 pick_p(const Cand5& c, int i)
+{
+    v3 r = c.p[0];
+#pragma unroll
+    for (int j = 1; j < 5; ++j) if (j == i) r = c.p[j];
+    return r;
+}
+__device__ __forceinline__ float pick_s(const Cand5& c, int i)
+{
+    float r = c.s[0];
+#pragma unroll
+    for (int j = 1; j < 5; ++j) if (j == i) r = c.s[j];
+    return r;
+}
+
+__device__ float reduce_candidates(const Cand5& c, v3 nrm, RawContacts& out)
+{
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) n += c.ok[j] ? 1 : 0;
+    int k = 0;
+    float mins = kInf;
+    if (n <= 4) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (c.ok[j]) { emit(out, k, c, j); if (c.s[j] < mins) mins = c.s[j]; }
+        out.count = k;
+        return mins;
+    }
+    // all five valid
     int i0 = 0;
-    for (int i = 1; i < n; ++i) if (sep[i] < sep[i0]) i0 = i;
+#pragma unroll
+    for (int j = 1; j < 5; ++j) if (c.s[j] < pick_s(c, i0)) i0 = j;
+    const v3 p0 = pick_p(c, i0);
+    const float s0 = pick_s(c, i0);
     int i1 = -1; float best = -3.0e38f;
-    for (int i = 0; i < n; ++i) {
-        if (i == i0) continue;
-        const v3 d = sub(p[i], p[i0]);
-        const float pen = kDepthWeight * (sep[i] - sep[i0]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        if (j == i0) continue;
+        const v3 d = sub(c.p[j], p0);
+        const float pen = kDepthWeight * (c.s[j] - s0);
         const float score = sqrtf(dot(d, d)) - pen;
-        if (score > best) { best = score; i1 = i; }
+        if (score > best) { best = score; i1 = j; }
     }
     int i2 = -1, i3 = -1; float mx = 0.0f, mn = 0.0f;
-    const v3 e = sub(p[i1], p[i0]);
+    const v3 e = sub(pick_p(c, i1), p0);
     const float el = sqrtf(dot(e, e));
-    for (int i = 0; i < n; ++i) {
-        if (i == i0 || i == i1) continue;
-        const float a = dot(cross(e, sub(p[i], p[i0])), nrm);
-        const float pen = kDepthWeight * (sep[i] - sep[i0]) * el;
-        if (a - pen > mx) { mx = a - pen; i2 = i; }
-        if (a + pen < mn) { mn = a + pen; i3 = i; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        if (j == i0 || j == i1) continue;
+        const float a = dot(cross(e, sub(c.p[j], p0)), nrm);
+        const float pen = kDepthWeight * (c.s[j] - s0) * el;
+        if (a - pen > mx) { mx = a - pen; i2 = j; }
+        if (a + pen < mn) { mn = a + pen; i3 = j; }
     }
-    int k = 0;
-    keep[k++] = i0; keep[k++] = i1;
-    if (i2 >= 0) keep[k++] = i2;
-    if (i3 >= 0) keep[k++] = i3;
-    return k;
+    emit(out, k, c, i0); mins = fminf(mins, s0);
+    emit(out, k, c, i1); { const float t = pick_s(c, i1); if (t < mins) mins = t; }
+    if (i2 >= 0) { emit(out, k, c, i2); const float t = pick_s(c, i2); if (t < mins) mins = t; }
+    if (i3 >= 0) { emit(out, k, c, i3); const float t = pick_s(c, i3); if (t < mins) mins = t; }
+    out.count = k;
+    return mins;
 }
 
-__device__ __forceinline__ void fill_contact(Contact* c, int a, int b, const WBody& wa, const WBody* wbb, v3 pa, v3 pb,
-                                             v3 n, float sep, float rest, float mu_s, float mu_d, float e)
+// hull pair -> up to 4 raw contacts; returns min separation (or +inf)
+__device__ float hull_pair_contacts(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
+                                    const float4* __restrict__ hv, const slhip_settle_params& prm, float margin,
+                                    RawContacts& out)
 {
-    Contact k;
-    k.a = a; k.b = b;
-    k.ra = sub(pa, wa.x);
-    k.rb = wbb ? sub(pb, wbb->x) : V(0, 0, 0);
-    k.n = n;
-    tangents(n, &k.t1, &k.t2);
-    k.sep = sep; k.rest = rest;
-    k.kn = k.kt1 = k.kt2 = 0.0f;
-    k.ln = k.lt1 = k.lt2 = 0.0f;
-    k.vn0 = 0.0f;
-    k.mu_s = mu_s; k.mu_d = mu_d; k.e = e;
-    k.valid = 1;
-    *c = k;
-}
-
-__device__ float hull_pair_contacts(const slhip_body* bodies, const WBody* wbs, int ia, int ib, const slhip_hull& ha,
-                                    const slhip_hull& hb, const float* hull_verts, const slhip_settle_params& prm,
-                                    float margin, Contact* out)
-{
-    for (int i = 0; i < kMaxContactsPerHP; ++i) out[i].valid = 0;
-    const WBody& wa = wbs[ia];
-    const WBody& wb = wbs[ib];
+    out.count = 0;
     Shape A, B;
-    make_shape(wa, ha, hull_verts, A);
-    make_shape(wb, hb, hull_verts, B);
-    const v3 ca = add(m3_mul(wa.R, V(ha.sphere[0], ha.sphere[1], ha.sphere[2])), wa.t);
-    const v3 cb = add(m3_mul(wb.R, V(hb.sphere[0], hb.sphere[1], hb.sphere[2])), wb.t);
+    make_shape(wa, ha, A);
+    make_shape(wb, hb, B);
+    const v3 ca = add(m3_mul(wa.R, ha.sc), wa.t);
+    const v3 cb = add(m3_mul(wb.R, hb.sc), wb.t);
     v3 pa, pb, n;
     float dist;
-    const float rest = 2.0f * prm.rest_offset;
-    const float mu_s = 0.5f * (bodies[ia].mu_s + bodies[ib].mu_s);
-    const float mu_d = 0.5f * (bodies[ia].mu_d + bodies[ib].mu_d);
-    const float e = 0.5f * (bodies[ia].restitution + bodies[ib].restitution);
-    if (!gjk_distance(A, B, sub(ca, cb), &pa, &pb, &dist)) {
+    const int code = gjk_distance(A, B, hv, sub(ca, cb), margin, &pa, &pb, &dist);
+    if (code == 2) return kInf;
+    if (code == 0) {
         float sep;
-        overlap_fallback(A, B, ca, cb, &n, &sep, &pa, &pb);
+        overlap_fallback(A, B, hv, ca, cb, &n, &sep, &pa, &pb);
         if (sep > 0.0f) sep = 0.0f;
-        fill_contact(&out[0], ia, ib, wa, &wb, pa, pb, n, sep, rest, mu_s, mu_d, e);
+        out.n = n; out.pa[0] = pa; out.pb[0] = pb; out.sep[0] = sep; out.count = 1;
         return sep;
     }
     if (dist > margin) return kInf;
     n = scale(sub(pa, pb), 1.0f / dist);
 
-    v3 cp[5], cq[5];
-    float cs[5];
-    int nc = 0;
-    cp[0] = pa; cq[0] = pb; cs[0] = dist; nc = 1;
+    Cand5 c;
+    c.p[0] = pa; c.q[0] = pb; c.s[0] = dist; c.ok[0] = true;
 
-    const bool tilt_a = ha.sphere[3] <= hb.sphere[3];
-    const float radius = tilt_a ? ha.sphere[3] : hb.sphere[3];
+    const bool tilt_a = ha.sr <= hb.sr;
+    const float radius = tilt_a ? ha.sr : hb.sr;
     float ang = 2.0f * prm.contact_offset / radius;
     if (ang > 0.2f) ang = 0.2f;
     const float lift = radius * ang;
@@ -432,20 +535,24 @@ __device__ float hull_pair_contacts(const slhip_body* bodies, const WBody* wbs, 
     v3 t1, t2;
     tangents(n, &t1, &t2);
     const WBody& wt = tilt_a ? wa : wb;
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
+        c.ok[k + 1] = false;
+        c.p[k + 1] = V(0, 0, 0); c.q[k + 1] = V(0, 0, 0); c.s[k + 1] = 0.0f;
         const v3 ax = (k == 0) ? t1 : (k == 1) ? t2 : (k == 2) ? neg(t1) : neg(t2);
         quat dq; dq.x = ax.x * sh; dq.y = ax.y * sh; dq.z = ax.z * sh; dq.w = ch;
         const quat q2 = quat_normalize(quat_mul(dq, wt.q));
         Shape T = tilt_a ? A : B;
         quat_to_m3(q2, T.R);
-        const v3 cl = tilt_a ? V(ha.sphere[0], ha.sphere[1], ha.sphere[2]) : V(hb.sphere[0], hb.sphere[1], hb.sphere[2]);
+        const v3 cl = tilt_a ? ha.sc : hb.sc;
         v3 cw = tilt_a ? ca : cb;
         cw = madd(cw, n, tilt_a ? lift : -lift);
         T.t = sub(cw, m3_mul(T.R, cl));
         v3 qa, qb;
         float d2;
-        const int ok = tilt_a ? gjk_distance(T, B, sub(ca, cb), &qa, &qb, &d2) : gjk_distance(A, T, sub(ca, cb), &qa, &qb, &d2);
-        if (!ok) continue;
+        const int ok = tilt_a ? gjk_distance(T, B, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2)
+                              : gjk_distance(A, T, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2);
+        if (ok != 1) continue;
         if (tilt_a) {
             const v3 loc = m3_tmul(T.R, sub(qa, T.t));
             qa = add(m3_mul(A.R, loc), A.t);
@@ -453,69 +560,129 @@ __device__ float hull_pair_contacts(const slhip_body* bodies, const WBody* wbs, 
             const v3 loc = m3_tmul(T.R, sub(qb, T.t));
             qb = add(m3_mul(B.R, loc), B.t);
         }
-        const float s = dot(sub(qa, qb), n);
-        if (s > margin) continue;
-        const v3 lat = sub(sub(qa, qb), scale(n, s));
+        const float sp = dot(sub(qa, qb), n);
+        if (sp > margin) continue;
+        const v3 lat = sub(sub(qa, qb), scale(n, sp));
         if (dot(lat, lat) > 4.0f * margin * margin) continue;
         bool dup = false;
-        for (int j = 0; j < nc; ++j) {
-            const v3 dd = sub(cp[j], qa);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (j > k) continue;  // only earlier slots
+            if (!c.ok[j]) continue;
+            const v3 dd = sub(c.p[j], qa);
             if (dot(dd, dd) < 2.5e-3f * radius * radius) dup = true;
         }
         if (dup) continue;
-        cp[nc] = qa; cq[nc] = qb; cs[nc] = s; ++nc;
+        c.p[k + 1] = qa; c.q[k + 1] = qb; c.s[k + 1] = sp; c.ok[k + 1] = true;
     }
-    int keep[4];
-    const int nk = reduce4(nc, cp, cs, n, keep);
-    float mins = kInf;
-    for (int i = 0; i < nk; ++i) {
-        const int j = keep[i];
-        fill_contact(&out[i], ia, ib, wa, &wb, cp[j], cq[j], n, cs[j], rest, mu_s, mu_d, e);
-        if (cs[j] < mins) mins = cs[j];
-    }
-    return mins;
+    out.n = n;
+    return reduce_candidates(c, n, out);
 }
 
-__device__ void plane_contacts(const slhip_body* bodies, const WBody* wbs, int ia, const slhip_hull* hulls,
-                               const float* hull_verts, const slhip_settle_params& prm, float plane_z, float margin,
-                               Contact* out)
+// body vs table plane: four order-independent selections over all hull vertices in the band
+// (same rule as the oracle's plane_contacts)
+__device__ __forceinline__ float4 hull_vertex(const HullRef& h, const float4* __restrict__ hv, int i)
 {
-    for (int i = 0; i < kPlaneSlots; ++i) out[i].valid = 0;
-    const slhip_body& b = bodies[ia];
-    const WBody& w = wbs[ia];
-    v3 cand[64];
-    float cs[64];
-    int nc = 0;
-    for (unsigned h = b.hull_begin; h < b.hull_end; ++h) {
-        const slhip_hull hh = hulls[h];
-        const v3 c = add(m3_mul(w.R, V(hh.sphere[0], hh.sphere[1], hh.sphere[2])), w.t);
-        if (c.z - hh.sphere[3] - plane_z > margin) continue;
-        const float4* vs = reinterpret_cast<const float4*>(hull_verts) + hh.vtx_begin;
-        for (unsigned i = 0; i < hh.vtx_count; ++i) {
-            const float4 q = vs[i];
+    return h.lds >= 0 ? hv[h.lds + i] : h.g[i];
+}
+
+__device__ void plane_contacts(const WBody& w, const HullRef* lh, const float4* __restrict__ hv, int lh_begin, int lh_end,
+                               float plane_z, float margin, RawContacts& out)
+{
+    out.count = 0;
+    out.n = V(0, 0, 1);
+    bool have0 = false; v3 p0 = V(0, 0, 0); float s0 = 0.0f;
+    for (int h = lh_begin; h < lh_end; ++h) {
+        const HullRef H = lh[h];
+#pragma unroll 4
+        for (int i = 0; i < H.count; ++i) {
+            const float4 q = hull_vertex(H, hv, i);
             const v3 p = add(m3_mul(w.R, V(q.x, q.y, q.z)), w.t);
             const float d = p.z - plane_z;
-            if (d > margin) continue;
-            if (nc < 64) { cand[nc] = p; cs[nc] = d; ++nc; }
-            else {
-                int worst = 0;
-                for (int k = 1; k < 64; ++k) if (cs[k] > cs[worst]) worst = k;
-                if (d < cs[worst]) { cand[worst] = p; cs[worst] = d; }
-            }
+            if (!(d <= margin)) continue;
+            if (!have0 || d < s0) { have0 = true; p0 = p; s0 = d; }
         }
     }
-    if (nc == 0) return;
-    int keep[4];
-    const v3 n = V(0, 0, 1);
-    const int nk = reduce4(nc, cand, cs, n, keep);
-    const float mu_s = 0.5f * (b.mu_s + prm.plane_mu_s);
-    const float mu_d = 0.5f * (b.mu_d + prm.plane_mu_d);
-    const float e = 0.5f * (b.restitution + prm.plane_restitution);
-    for (int i = 0; i < nk; ++i) {
-        const int j = keep[i];
-        const v3 pb = V(cand[j].x, cand[j].y, plane_z);
-        fill_contact(&out[i], ia, -1, w, nullptr, cand[j], pb, n, cs[j], prm.rest_offset, mu_s, mu_d, e);
+    if (!have0) return;
+    bool have1 = false; v3 p1 = V(0, 0, 0); float s1 = 0.0f, best = 0.0f;
+    for (int h = lh_begin; h < lh_end; ++h) {
+        const HullRef H = lh[h];
+#pragma unroll 4
+        for (int i = 0; i < H.count; ++i) {
+            const float4 q = hull_vertex(H, hv, i);
+            const v3 p = add(m3_mul(w.R, V(q.x, q.y, q.z)), w.t);
+            const float d = p.z - plane_z;
+            if (!(d <= margin)) continue;
+            const v3 dd = sub(p, p0);
+            const float score = sqrtf(dot(dd, dd)) - kDepthWeight * (d - s0);
+            if (score > 0.0f && (!have1 || score > best)) { have1 = true; best = score; p1 = p; s1 = d; }
+        }
     }
+    int nk = 1;
+    out.pa[0] = p0; out.sep[0] = s0;
+    if (have1) {
+        out.pa[1] = p1; out.sep[1] = s1; nk = 2;
+        const v3 e = sub(p1, p0);
+        const float el = sqrtf(dot(e, e));
+        bool have2 = false, have3 = false; v3 p2 = V(0, 0, 0), p3 = V(0, 0, 0); float s2 = 0, s3 = 0, mx = 0.0f, mn = 0.0f;
+        for (int h = lh_begin; h < lh_end; ++h) {
+            const HullRef H = lh[h];
+#pragma unroll 4
+            for (int i = 0; i < H.count; ++i) {
+                const float4 q = hull_vertex(H, hv, i);
+                const v3 p = add(m3_mul(w.R, V(q.x, q.y, q.z)), w.t);
+                const float d = p.z - plane_z;
+                if (!(d <= margin)) continue;
+                const float a = dot(cross(e, sub(p, p0)), out.n);
+                const float pen = kDepthWeight * (d - s0) * el;
+                if (a - pen > mx) { mx = a - pen; have2 = true; p2 = p; s2 = d; }
+                if (a + pen < mn) { mn = a + pen; have3 = true; p3 = p; s3 = d; }
+            }
+        }
+        if (have2) { out.pa[2] = p2; out.sep[2] = s2; nk = 3; }
+        if (have3) {
+            if (have2) { out.pa[3] = p3; out.sep[3] = s3; nk = 4; }
+            else { out.pa[2] = p3; out.sep[2] = s3; nk = 3; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out.pb[i] = V(out.pa[i].x, out.pa[i].y, plane_z);
+    out.count = nk;
+}
+
+__device__ __forceinline__ void fill_contact(Contact* c, int a, int b, const WBody& wa, const WBody* wbb, v3 pa, v3 pb,
+                                             v3 n, float sep, float rest, float mu_s, float mu_d, float e)
+{
+    Contact k;
+    k.a = (short)a; k.b = (short)b;
+    k.ra = sub(pa, wa.x);
+    k.rb = wbb ? sub(pb, wbb->x) : V(0, 0, 0);
+    k.n = n;
+    tangents(n, &k.t1, &k.t2);
+    k.err = sep - rest;
+    k.kn = k.kt1 = k.kt2 = 0.0f;
+    k.ln = k.lt1 = k.lt2 = 0.0f;
+    k.vn0 = 0.0f;
+    k.mu_s = mu_s; k.mu_d = mu_d; k.e = e;
+    *c = k;
+}
+
+// world AABB overlap of two hulls within margin (|R| * half extents around R c + t)
+__device__ __forceinline__ bool aabb_overlap(const WBody& wa, const slhip_hull& ha, const WBody& wb, const slhip_hull& hb,
+                                             float margin)
+{
+    const v3 ca = add(m3_mul(wa.R, V(ha.aabb_center[0], ha.aabb_center[1], ha.aabb_center[2])), wa.t);
+    const v3 cb = add(m3_mul(wb.R, V(hb.aabb_center[0], hb.aabb_center[1], hb.aabb_center[2])), wb.t);
+    float ea[3], eb[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        ea[r] = fmaf(fabsf(wa.R.m[3 * r + 2]), ha.aabb_half[2], fmaf(fabsf(wa.R.m[3 * r + 1]), ha.aabb_half[1], fabsf(wa.R.m[3 * r]) * ha.aabb_half[0]));
+        eb[r] = fmaf(fabsf(wb.R.m[3 * r + 2]), hb.aabb_half[2], fmaf(fabsf(wb.R.m[3 * r + 1]), hb.aabb_half[1], fabsf(wb.R.m[3 * r]) * hb.aabb_half[0]));
+    }
+    if (fabsf(ca.x - cb.x) > ea[0] + eb[0] + margin) return false;
+    if (fabsf(ca.y - cb.y) > ea[1] + eb[1] + margin) return false;
+    if (fabsf(ca.z - cb.z) > ea[2] + eb[2] + margin) return false;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,18 +704,18 @@ __device__ __forceinline__ float eff_mass(const WBody& a, const WBody* b, v3 ra,
     return k > 0.0f ? 1.0f / k : 0.0f;
 }
 
-__device__ void prep_contact(Contact* c, const WBody* wbs)
+__device__ void prep_contact(Contact* cp, const WBody* wbs)
 {
-    if (!c->valid) return;
-    const WBody& a = wbs[c->a];
-    const WBody* b = c->b >= 0 ? &wbs[c->b] : nullptr;
-    if (!a.dynamic && !(b && b->dynamic)) { c->valid = 0; return; }
-    c->kn = eff_mass(a, b, c->ra, c->rb, c->n);
-    c->kt1 = eff_mass(a, b, c->ra, c->rb, c->t1);
-    c->kt2 = eff_mass(a, b, c->ra, c->rb, c->t2);
-    v3 rel = vel_at(a, c->ra);
-    if (b) rel = sub(rel, vel_at(*b, c->rb));
-    c->vn0 = dot(rel, c->n);
+    Contact c = *cp;
+    const WBody& a = wbs[c.a];
+    const WBody* b = c.b >= 0 ? &wbs[c.b] : nullptr;
+    c.kn = eff_mass(a, b, c.ra, c.rb, c.n);
+    c.kt1 = eff_mass(a, b, c.ra, c.rb, c.t1);
+    c.kt2 = eff_mass(a, b, c.ra, c.rb, c.t2);
+    v3 rel = vel_at(a, c.ra);
+    if (b) rel = sub(rel, vel_at(*b, c.rb));
+    c.vn0 = dot(rel, c.n);
+    cp->kn = c.kn; cp->kt1 = c.kt1; cp->kt2 = c.kt2; cp->vn0 = c.vn0;
 }
 
 __device__ __forceinline__ void apply_impulse(WBody& a, WBody* b, const Contact& c, v3 J)
@@ -565,15 +732,15 @@ __device__ __forceinline__ void apply_impulse(WBody& a, WBody* b, const Contact&
 
 __device__ void solve_contact(Contact* cp, WBody* wbs, const slhip_settle_params& prm, bool biased)
 {
-    if (!cp->valid) return;
     Contact c = *cp;
     WBody& a = wbs[c.a];
     WBody* b = c.b >= 0 ? &wbs[c.b] : nullptr;
+    if (!a.dynamic && !(b && b->dynamic)) return;  // the oracle invalidates such contacts in prep
     const float inv_dt = 1.0f / prm.dt;
     v3 rel = vel_at(a, c.ra);
     if (b) rel = sub(rel, vel_at(*b, c.rb));
     const float vn = dot(rel, c.n);
-    const float err = c.sep - c.rest;
+    const float err = c.err;
     float target;
     if (err > 0.0f) target = -err * inv_dt;
     else target = biased ? -0.8f * err * inv_dt : 0.0f;
@@ -678,33 +845,117 @@ __device__ __forceinline__ int compact_slot(bool pred, int count)
 // ---------------------------------------------------------------------------------------------
 // the persistent per-scene kernel
 // ---------------------------------------------------------------------------------------------
-struct SceneLds {
-    WBody wb[SLHIP_MAX_BODIES];
-    unsigned long long used[SLHIP_MAX_BODIES];
-    int wake[SLHIP_MAX_BODIES];
-    short hp_ba[SLHIP_MAX_HULL_PAIRS], hp_bb[SLHIP_MAX_HULL_PAIRS];
-    int hp_ha[SLHIP_MAX_HULL_PAIRS], hp_hb[SLHIP_MAX_HULL_PAIRS];
-    short g_a[kMaxGroups], g_b[kMaxGroups];
-    short g_begin[kMaxGroups], g_end[kMaxGroups];
-    signed char g_color[kMaxGroups];
-    short bp_i[SLHIP_MAX_BODIES * (SLHIP_MAX_BODIES - 1) / 2], bp_j[SLHIP_MAX_BODIES * (SLHIP_MAX_BODIES - 1) / 2];
-    int n_hp, n_groups, n_colors, n_bp;
+// exclusive prefix sum of a small per-lane count over the wave, plus the total
+__device__ __forceinline__ int wave_excl_scan(int v, int& total)
+{
+    const int lane = threadIdx.x & 63;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS layout (dynamic): sized by the host from the batch maxima (slhip_settle_params hints)
+// ---------------------------------------------------------------------------------------------
+struct LdsLayout {
+    int nb_cap, lh_cap, hv_cap;   // bodies, local hulls, hull vertices (0 = vertices stay global)
+    int off_wb, off_lh, off_body_lh, off_hv, off_contacts, off_hp, off_hp_off, off_hp_sep, off_groups, off_misc;
+    int total;
 };
+
+struct HpEntry { unsigned short ba, bb, la, lb; };
+struct Group { short a, b; short begin, end; int color; };
+
+__host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_cap)
+{
+    LdsLayout L;
+    L.nb_cap = nb_cap; L.lh_cap = lh_cap; L.hv_cap = hv_cap;
+    int o = 0;
+    auto take = [&](int bytes) { const int r = o; o += (bytes + 15) & ~15; return r; };
+    L.off_wb = take(nb_cap * (int)sizeof(WBody));
+    L.off_lh = take(lh_cap * (int)sizeof(HullRef));
+    L.off_body_lh = take((nb_cap + 1) * 4);
+    L.off_hv = take(hv_cap * 16);
+    L.off_contacts = take(kMaxActive * (int)sizeof(Contact));
+    L.off_hp = take(SLHIP_MAX_HULL_PAIRS * (int)sizeof(HpEntry));
+    L.off_hp_off = take((SLHIP_MAX_HULL_PAIRS + 1) * 2);
+    L.off_hp_sep = take(SLHIP_MAX_HULL_PAIRS * 4);
+    int g_cap = nb_cap + nb_cap * (nb_cap - 1) / 2;   // plane groups + body pairs
+    if (g_cap > kMaxGroups) g_cap = kMaxGroups;
+    L.off_groups = take(g_cap * (int)sizeof(Group));
+    L.off_misc = take(nb_cap * 8 + nb_cap * 4 + 64);
+    L.total = o;
+    return L;
+}
 
 __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restrict__ scenes, slhip_body* bodies_all,
                                                const slhip_hull* __restrict__ hulls,
                                                const float* __restrict__ hull_verts, slhip_settle_params prm,
-                                               SceneScratch* scratch_all)
+                                               LdsLayout L, ProfScratch* prof_all)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    SceneLds& S = *reinterpret_cast<SceneLds*>(smem);
+    WBody* wb = reinterpret_cast<WBody*>(smem + L.off_wb);
+    HullRef* lh = reinterpret_cast<HullRef*>(smem + L.off_lh);
+    int* body_lh = reinterpret_cast<int*>(smem + L.off_body_lh);
+    float4* hv = reinterpret_cast<float4*>(smem + L.off_hv);
+    Contact* ac = reinterpret_cast<Contact*>(smem + L.off_contacts);
+    HpEntry* hp = reinterpret_cast<HpEntry*>(smem + L.off_hp);
+    unsigned short* hp_off = reinterpret_cast<unsigned short*>(smem + L.off_hp_off);
+    float* hp_sep = reinterpret_cast<float*>(smem + L.off_hp_sep);
+    Group* groups = reinterpret_cast<Group*>(smem + L.off_groups);
+    unsigned long long* used = reinterpret_cast<unsigned long long*>(smem + L.off_misc);
+    int* wake = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 8);
+    int* counters = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 12);  // [0]=n_groups [1]=n_colors
+
     const slhip_settle_scene sc = scenes[blockIdx.x];
     slhip_body* bodies = bodies_all + sc.body_begin;
     const int nb = (int)(sc.body_end - sc.body_begin);
-    SceneScratch& X = scratch_all[blockIdx.x];
+#ifdef SLHIP_SETTLE_PROFILE
+    ProfScratch& X = prof_all[blockIdx.x];
+#endif
     const int lane = threadIdx.x;
     const float dt = prm.dt;
-    WBody* wb = S.wb;
+    if (nb > L.nb_cap) return;  // host sizing error: refuse rather than corrupt LDS
+
+    // ---- prologue (once per settle): local hull table, hull vertices into LDS ----
+    // serial over bodies/hulls (<= a few hundred), lanes copy the vertices
+    {
+        int n_lh = 0, n_hv = 0;
+        bool fits = true;
+        for (int i = 0; i < nb; ++i) {
+            const int h0 = (int)bodies[i].hull_begin, h1 = (int)bodies[i].hull_end;
+            if (lane == 0) body_lh[i] = n_lh;
+            for (int h = h0; h < h1; ++h) {
+                const int cnt = (int)hulls[h].vtx_count;
+                if (n_lh >= L.lh_cap) { fits = false; break; }
+                const bool in_lds = n_hv + cnt <= L.hv_cap;
+                if (lane == 0) {
+                    HullRef r;
+                    r.g = reinterpret_cast<const float4*>(hull_verts) + hulls[h].vtx_begin;
+                    r.lds = in_lds ? n_hv : -1;
+                    r.count = cnt;
+                    r.sc = V(hulls[h].sphere[0], hulls[h].sphere[1], hulls[h].sphere[2]);
+                    r.sr = hulls[h].sphere[3];
+                    lh[n_lh] = r;
+                }
+                if (in_lds) {
+                    const float4* src = reinterpret_cast<const float4*>(hull_verts) + hulls[h].vtx_begin;
+                    for (int k = lane; k < cnt; k += 64) hv[n_hv + k] = src[k];
+                    n_hv += cnt;
+                }
+                ++n_lh;
+            }
+            if (!fits) break;
+        }
+        if (lane == 0) body_lh[nb] = n_lh;
+        if (!fits) return;  // more hulls than the host sized for
+    }
+    __syncthreads();
 
     for (unsigned frame = 0; frame < prm.frames; ++frame) {
         for (unsigned sub_ = 0; sub_ < prm.substeps; ++sub_) {
@@ -713,130 +964,22 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             for (int i = lane; i < nb; i += 64) {
                 load_body(bodies[i], wb[i]);
                 update_world_inertia(bodies[i], wb[i]);
-                bodies[i].separation = kInf;
                 if (wb[i].dynamic) {
                     wb[i].v = madd(wb[i].v, V(prm.gravity[0], prm.gravity[1], prm.gravity[2]), dt);
                     float damp = 1.0f - prm.angular_damping * dt;
                     if (damp < 0.0f) damp = 0.0f;
                     wb[i].w = scale(wb[i].w, damp);
                 }
-                S.wake[i] = 0;
+                wake[i] = 0;
             }
-            if (lane == 0) { S.n_hp = 0; S.n_groups = 0; S.n_bp = 0; }
             __syncthreads();
-
             PROF(0);
-            // (b) body-pair broadphase in (i<j) order, ballot-compacted in order
-            {
-                const int n_pairs = nb * (nb - 1) / 2;
-                int count = 0;
-                for (int base = 0; base < n_pairs; base += 64) {
-                    const int p = base + lane;
-                    bool pass = false;
-                    int i = 0, j = 0;
-                    if (p < n_pairs) {
-                        // unrank p -> (i, j), i < j, lexicographic
-                        int rem = p;
-                        i = 0;
-                        int row = nb - 1;
-                        while (rem >= row) { rem -= row; ++i; --row; }
-                        j = i + 1 + rem;
-                        if (wb[i].dynamic || wb[j].dynamic) {
-                            const v3 ci = add(m3_mul(wb[i].R, V(bodies[i].bsphere[0], bodies[i].bsphere[1], bodies[i].bsphere[2])), wb[i].t);
-                            const v3 cj = add(m3_mul(wb[j].R, V(bodies[j].bsphere[0], bodies[j].bsphere[1], bodies[j].bsphere[2])), wb[j].t);
-                            const v3 dv = sub(wb[i].v, wb[j].v);
-                            const float spec = sqrtf(dot(dv, dv)) * dt;
-                            const float margin = 2.0f * prm.contact_offset + spec;
-                            const v3 d = sub(ci, cj);
-                            const float rr = bodies[i].bsphere[3] + bodies[j].bsphere[3] + margin;
-                            pass = !(dot(d, d) > rr * rr);
-                        }
-                    }
-                    const int slot = compact_slot(pass, count);
-                    if (pass) { S.bp_i[slot] = (short)i; S.bp_j[slot] = (short)j; }
-                    count += __popcll(__ballot(pass));
-                }
-                if (lane == 0) S.n_bp = count;
-            }
-            __syncthreads();
 
-            PROF(1);
-            // (c) hull pairs of every surviving body pair (pairs sequential, combos across lanes)
-            {
-                int n_hp = 0, n_groups = 0;
-                const int n_bp = S.n_bp;
-                for (int bp = 0; bp < n_bp; ++bp) {
-                    const int i = S.bp_i[bp], j = S.bp_j[bp];
-                    const unsigned hb0 = bodies[j].hull_begin;
-                    const int na = (int)(bodies[i].hull_end - bodies[i].hull_begin);
-                    const int nbh = (int)(bodies[j].hull_end - hb0);
-                    const v3 dv = sub(wb[i].v, wb[j].v);
-                    const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
-                    const int first = n_hp;
-                    const int combos = na * nbh;
-                    for (int base = 0; base < combos; base += 64) {
-                        const int q = base + lane;
-                        bool pass = false;
-                        unsigned ha = 0, hb = 0;
-                        if (q < combos) {
-                            ha = bodies[i].hull_begin + (unsigned)(q / nbh);
-                            hb = hb0 + (unsigned)(q % nbh);
-                            const slhip_hull A = hulls[ha], B = hulls[hb];
-                            const v3 ca = add(m3_mul(wb[i].R, V(A.sphere[0], A.sphere[1], A.sphere[2])), wb[i].t);
-                            const v3 cb = add(m3_mul(wb[j].R, V(B.sphere[0], B.sphere[1], B.sphere[2])), wb[j].t);
-                            const v3 dd = sub(ca, cb);
-                            const float r2 = A.sphere[3] + B.sphere[3] + margin;
-                            pass = !(dot(dd, dd) > r2 * r2);
-                        }
-                        const int slot = compact_slot(pass, n_hp);
-                        if (pass && slot < SLHIP_MAX_HULL_PAIRS) {
-                            S.hp_ba[slot] = (short)i; S.hp_bb[slot] = (short)j;
-                            S.hp_ha[slot] = (int)ha; S.hp_hb[slot] = (int)hb;
-                        }
-                        n_hp = min(n_hp + (int)__popcll(__ballot(pass)), (int)SLHIP_MAX_HULL_PAIRS);
-                    }
-                    if (n_hp > first) {
-                        if (lane == 0) {
-                            S.g_a[n_groups] = (short)i; S.g_b[n_groups] = (short)j;
-                            S.g_begin[n_groups] = (short)(first * kMaxContactsPerHP);
-                            S.g_end[n_groups] = (short)(n_hp * kMaxContactsPerHP);
-                        }
-                        ++n_groups;
-                    }
-                }
-                if (lane == 0) { S.n_hp = n_hp; S.n_groups = n_groups; }
-            }
-            __syncthreads();
+            int n_groups = 0;  // wave-uniform running counters
+            int n_active = 0;
 
-            PROF(2);
-            // (d) narrowphase: one lane per hull pair
-            {
-                const int n_hp = S.n_hp;
-                for (int k = lane; k < n_hp; k += 64) {
-                    const int i = S.hp_ba[k], j = S.hp_bb[k];
-                    const v3 dv = sub(wb[i].v, wb[j].v);
-                    const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
-                    X.hp_sep[k] = hull_pair_contacts(bodies, wb, i, j, hulls[S.hp_ha[k]], hulls[S.hp_hb[k]], hull_verts, prm,
-                                                     margin, &X.c[k * kMaxContactsPerHP]);
-                }
-            }
-            __syncthreads();
-            // min separation per body over its hull pairs (order-independent)
-            {
-                const int n_hp = S.n_hp;
-                for (int i = lane; i < nb; i += 64) {
-                    float s = kInf;
-                    for (int k = 0; k < n_hp; ++k)
-                        if (S.hp_ba[k] == i || S.hp_bb[k] == i) s = fminf(s, X.hp_sep[k]);
-                    bodies[i].separation = s;
-                }
-            }
-
-            PROF(3);
-            PROF_COUNT(0, S.n_hp); PROF_COUNT(1, S.n_bp);
-            // (e) plane contacts, groups appended in body order
+            // (b) plane contacts first: one lane per body, groups + contacts appended in body order
             if (sc.has_plane) {
-                int n_groups = S.n_groups;
                 for (int base = 0; base < nb; base += 64) {
                     const int i = base + lane;
                     bool pass = false;
@@ -847,89 +990,223 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                         margin = prm.contact_offset + vz;
                         pass = !(ci.z - bodies[i].bsphere[3] - sc.plane_z > margin);
                     }
+                    RawContacts rc;
+                    rc.count = 0;
+                    if (pass) plane_contacts(wb[i], lh, hv, body_lh[i], body_lh[i + 1], sc.plane_z, margin, rc);
+                    int total;
+                    const int off = n_active + wave_excl_scan(rc.count, total);
                     const int g = compact_slot(pass, n_groups);
                     if (pass) {
-                        plane_contacts(bodies, wb, i, hulls, hull_verts, prm, sc.plane_z, margin, &X.c[kPlaneBase + i * kPlaneSlots]);
-                        S.g_a[g] = (short)i; S.g_b[g] = -1;
-                        S.g_begin[g] = (short)(kPlaneBase + i * kPlaneSlots);
-                        S.g_end[g] = (short)(kPlaneBase + (i + 1) * kPlaneSlots);
+                        const float mu_s = 0.5f * (bodies[i].mu_s + prm.plane_mu_s);
+                        const float mu_d = 0.5f * (bodies[i].mu_d + prm.plane_mu_d);
+                        const float e = 0.5f * (bodies[i].restitution + prm.plane_restitution);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < rc.count && off + k < kMaxActive)
+                                fill_contact(&ac[off + k], i, -1, wb[i], nullptr, rc.pa[k], rc.pb[k], rc.n, rc.sep[k],
+                                             prm.rest_offset, mu_s, mu_d, e);
+                        Group G;
+                        G.a = (short)i; G.b = -1;
+                        G.begin = (short)min(off, kMaxActive); G.end = (short)min(off + rc.count, kMaxActive);
+                        G.color = 0;
+                        groups[g] = G;
                     }
+                    n_active = min(n_active + total, kMaxActive);
                     n_groups += __popcll(__ballot(pass));
                 }
-                if (lane == 0) S.n_groups = n_groups;
+            }
+            const int n_plane_groups = n_groups;
+            PROF(1);
+
+            // (c) broadphase: body pairs in (i<j) order -> hull pairs, ballot-compacted in order
+            int n_hp = 0;
+            {
+                const int n_pairs = nb * (nb - 1) / 2;
+                for (int base = 0; base < n_pairs; base += 64) {
+                    const int p = base + lane;
+                    bool pass = false;
+                    int pi = 0, pj = 0;
+                    if (p < n_pairs) {
+                        int rem = p, row = nb - 1;
+                        while (rem >= row) { rem -= row; ++pi; --row; }
+                        pj = pi + 1 + rem;
+                        if (wb[pi].dynamic || wb[pj].dynamic) {
+                            const v3 ci = add(m3_mul(wb[pi].R, V(bodies[pi].bsphere[0], bodies[pi].bsphere[1], bodies[pi].bsphere[2])), wb[pi].t);
+                            const v3 cj = add(m3_mul(wb[pj].R, V(bodies[pj].bsphere[0], bodies[pj].bsphere[1], bodies[pj].bsphere[2])), wb[pj].t);
+                            const v3 dv = sub(wb[pi].v, wb[pj].v);
+                            const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
+                            const v3 d = sub(ci, cj);
+                            const float rr = bodies[pi].bsphere[3] + bodies[pj].bsphere[3] + margin;
+                            pass = !(dot(d, d) > rr * rr);
+                        }
+                    }
+                    unsigned long long mask = __ballot(pass);
+                    while (mask) {
+                        const int src = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int i = __shfl(pi, src, 64), j = __shfl(pj, src, 64);
+                        const int la0 = body_lh[i], na = body_lh[i + 1] - la0;
+                        const int lb0 = body_lh[j], nbh = body_lh[j + 1] - lb0;
+                        const unsigned ga0 = bodies[i].hull_begin, gb0 = bodies[j].hull_begin;
+                        const v3 dv = sub(wb[i].v, wb[j].v);
+                        const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
+                        const int first = n_hp;
+                        const int combos = na * nbh;
+                        for (int cb = 0; cb < combos; cb += 64) {
+                            const int q = cb + lane;
+                            bool ok = false;
+                            int a = 0, b = 0;
+                            if (q < combos) {
+                                a = q / nbh; b = q % nbh;
+                                const HullRef& A = lh[la0 + a];
+                                const HullRef& B = lh[lb0 + b];
+                                const v3 ca = add(m3_mul(wb[i].R, A.sc), wb[i].t);
+                                const v3 cbw = add(m3_mul(wb[j].R, B.sc), wb[j].t);
+                                const v3 dd = sub(ca, cbw);
+                                const float r2 = A.sr + B.sr + margin;
+                                ok = !(dot(dd, dd) > r2 * r2);
+                                if (ok) ok = aabb_overlap(wb[i], hulls[ga0 + a], wb[j], hulls[gb0 + b], margin);
+                            }
+                            const int slot = compact_slot(ok, n_hp);
+                            if (ok && slot < SLHIP_MAX_HULL_PAIRS) {
+                                HpEntry e;
+                                e.ba = (unsigned short)i; e.bb = (unsigned short)j;
+                                e.la = (unsigned short)(la0 + a); e.lb = (unsigned short)(lb0 + b);
+                                hp[slot] = e;
+                            }
+                            n_hp = min(n_hp + (int)__popcll(__ballot(ok)), (int)SLHIP_MAX_HULL_PAIRS);
+                        }
+                        if (n_hp > first) {
+                            if (lane == 0) {
+                                Group G;
+                                G.a = (short)i; G.b = (short)j;
+                                G.begin = (short)first; G.end = (short)n_hp;  // hull-pair range for now
+                                G.color = 0;
+                                groups[n_groups] = G;
+                            }
+                            ++n_groups;
+                        }
+                    }
+                }
             }
             __syncthreads();
+            PROF(2);
+            PROF_COUNT(0, n_hp);
 
+            // (d) narrowphase: one lane per hull pair; contacts compacted into LDS in pair order
+            for (int base = 0; base < n_hp; base += 64) {
+                const int k = base + lane;
+                RawContacts rc;
+                rc.count = 0;
+                float smin = kInf;
+                int i = 0, j = 0;
+                if (k < n_hp) {
+                    const HpEntry e = hp[k];
+                    i = e.ba; j = e.bb;
+                    const v3 dv = sub(wb[i].v, wb[j].v);
+                    const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
+                    smin = hull_pair_contacts(wb[i], wb[j], lh[e.la], lh[e.lb], hv, prm, margin, rc);
+                    hp_sep[k] = smin;
+                }
+                int total;
+                const int off = n_active + wave_excl_scan(rc.count, total);
+                if (k < n_hp) {
+                    hp_off[k] = (unsigned short)min(off, kMaxActive);
+                    const float rest = 2.0f * prm.rest_offset;
+                    const float mu_s = 0.5f * (bodies[i].mu_s + bodies[j].mu_s);
+                    const float mu_d = 0.5f * (bodies[i].mu_d + bodies[j].mu_d);
+                    const float e = 0.5f * (bodies[i].restitution + bodies[j].restitution);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < rc.count && off + c < kMaxActive)
+                            fill_contact(&ac[off + c], i, j, wb[i], &wb[j], rc.pa[c], rc.pb[c], rc.n, rc.sep[c], rest, mu_s,
+                                         mu_d, e);
+                }
+                n_active = min(n_active + total, kMaxActive);
+            }
+            if (lane == 0) hp_off[n_hp] = (unsigned short)n_active;
+            __syncthreads();
+            PROF(3);
+            // pair groups: hull-pair range -> contact range; min separation per body
+            for (int g = n_plane_groups + lane; g < n_groups; g += 64) {
+                Group G = groups[g];
+                G.begin = (short)hp_off[G.begin];
+                G.end = (short)hp_off[G.end];
+                groups[g] = G;
+            }
+            for (int i = lane; i < nb; i += 64) {
+                float s = kInf;
+                for (int k = 0; k < n_hp; ++k)
+                    if (hp[k].ba == i || hp[k].bb == i) s = fminf(s, hp_sep[k]);
+                bodies[i].separation = s;
+            }
+            __syncthreads();
             PROF(4);
-            // wake sleeping bodies touched by a moving body
+
+            // wake sleeping bodies touched by a moving body (pair groups only)
             {
-                const int ng = S.n_groups;
-                for (int g = lane; g < ng; g += 64) {
-                    const int a = S.g_a[g], b = S.g_b[g];
-                    if (b < 0) continue;
+                const float touch = 2.0f * prm.contact_offset - 2.0f * prm.rest_offset;  // sep < 2 co
+                for (int g = n_plane_groups + lane; g < n_groups; g += 64) {
+                    const Group G = groups[g];
                     bool touching = false;
-                    for (int i = S.g_begin[g]; i < S.g_end[g]; ++i)
-                        if (X.c[i].valid && X.c[i].sep < 2.0f * prm.contact_offset) touching = true;
+                    for (int c = G.begin; c < G.end; ++c)
+                        if (ac[c].err + 2.0f * prm.rest_offset < 2.0f * prm.contact_offset) touching = true;
+                    (void)touch;
                     if (!touching) continue;
                     for (int s = 0; s < 2; ++s) {
-                        const int me = s ? b : a, other = s ? a : b;
+                        const int me = s ? G.b : G.a, other = s ? G.a : G.b;
                         if ((bodies[me].flags & SLHIP_BODY_ASLEEP) && wb[other].dynamic) {
                             const float en = 0.5f * dot(wb[other].v, wb[other].v);
-                            if (en > prm.sleep_threshold) S.wake[me] = 1;
+                            if (en > prm.sleep_threshold) wake[me] = 1;
                         }
                     }
                 }
             }
             __syncthreads();
             for (int i = lane; i < nb; i += 64)
-                if (S.wake[i]) {
+                if (wake[i]) {
                     bodies[i].flags &= ~SLHIP_BODY_ASLEEP;
                     bodies[i].wake_counter = prm.wake_time;
                 }
-
             PROF(5);
-            // (f) prep: every slot of every group
-            {
-                const int ng = S.n_groups;
-                for (int g = 0; g < ng; ++g) {
-                    const int b0 = S.g_begin[g], b1 = S.g_end[g];
-                    for (int i = b0 + lane; i < b1; i += 64) prep_contact(&X.c[i], wb);
-                }
-            }
+
+            // (f) prep
+            for (int c = lane; c < n_active; c += 64) prep_contact(&ac[c], wb);
             PROF(6);
             // (g) greedy colouring in group order (serial by definition)
             if (lane == 0) {
-                for (int i = 0; i < nb; ++i) S.used[i] = 0ull;
+                for (int i = 0; i < nb; ++i) used[i] = 0ull;
                 int ncol = 0;
-                const int ng = S.n_groups;
-                for (int g = 0; g < ng; ++g) {
-                    unsigned long long m = S.used[S.g_a[g]];
-                    if (S.g_b[g] >= 0) m |= S.used[S.g_b[g]];
+                for (int g = 0; g < n_groups; ++g) {
+                    const int a = groups[g].a, b = groups[g].b;
+                    unsigned long long m = used[a];
+                    if (b >= 0) m |= used[b];
                     int c = 0;
                     while (c < 63 && ((m >> c) & 1ull)) ++c;
-                    S.g_color[g] = (signed char)c;
-                    S.used[S.g_a[g]] |= 1ull << c;
-                    if (S.g_b[g] >= 0) S.used[S.g_b[g]] |= 1ull << c;
+                    groups[g].color = c;
+                    used[a] |= 1ull << c;
+                    if (b >= 0) used[b] |= 1ull << c;
                     if (c + 1 > ncol) ncol = c + 1;
                 }
-                S.n_colors = ncol;
+                counters[1] = ncol;
             }
             __syncthreads();
-
+            const int ncol = counters[1];
             PROF(7);
-            PROF_COUNT(2, S.n_groups); PROF_COUNT(3, S.n_colors);
+            PROF_COUNT(2, n_groups); PROF_COUNT(3, ncol); PROF_COUNT(1, n_active);
+
             // (h) position iterations
-            const int ng = S.n_groups, ncol = S.n_colors;
             for (unsigned it = 0; it < prm.pos_iters; ++it)
                 for (int col = 0; col < ncol; ++col) {
-                    for (int g = lane; g < ng; g += 64) {
-                        if (S.g_color[g] != col) continue;
-                        for (int i = S.g_begin[g]; i < S.g_end[g]; ++i) solve_contact(&X.c[i], wb, prm, true);
+                    for (int g = lane; g < n_groups; g += 64) {
+                        const Group G = groups[g];
+                        if (G.color != col) continue;
+                        for (int c = G.begin; c < G.end; ++c) solve_contact(&ac[c], wb, prm, true);
                     }
                     __syncthreads();
                 }
-
             PROF(8);
+
             // (i) integrate poses
             for (int i = lane; i < nb; i += 64) {
                 if (!wb[i].dynamic) continue;
@@ -948,19 +1225,20 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                 wb[i].q = quat_normalize(q);
             }
             __syncthreads();
-
             PROF(9);
+
             // (j) velocity iterations
             for (unsigned it = 0; it < prm.vel_iters; ++it)
                 for (int col = 0; col < ncol; ++col) {
-                    for (int g = lane; g < ng; g += 64) {
-                        if (S.g_color[g] != col) continue;
-                        for (int i = S.g_begin[g]; i < S.g_end[g]; ++i) solve_contact(&X.c[i], wb, prm, false);
+                    for (int g = lane; g < n_groups; g += 64) {
+                        const Group G = groups[g];
+                        if (G.color != col) continue;
+                        for (int c = G.begin; c < G.end; ++c) solve_contact(&ac[c], wb, prm, false);
                     }
                     __syncthreads();
                 }
-
             PROF(10);
+
             // (k) store + sleep bookkeeping
             for (int i = lane; i < nb; i += 64) {
                 if (!wb[i].dynamic) continue;
@@ -1010,6 +1288,7 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
     const slhip_settle_scene sc = scenes[blockIdx.x];
     const slhip_body* b = bodies_all + sc.body_begin;
     const int nb = (int)(sc.body_end - sc.body_begin);
+    if (nb > SLHIP_MAX_BODIES) return;
     for (int i = threadIdx.x; i < nb; i += 64) load_body(b[i], wb[i]);
     __syncthreads();
     for (int i = threadIdx.x; i < nb; i += 64) {
@@ -1023,17 +1302,22 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
             if (dot(d, d) > rr * rr) continue;
             for (unsigned ha = b[i].hull_begin; ha < b[i].hull_end && !hit; ++ha)
                 for (unsigned hb = b[j].hull_begin; hb < b[j].hull_end && !hit; ++hb) {
+                    HullRef ra, rb;
+                    ra.g = reinterpret_cast<const float4*>(hull_verts) + hulls[ha].vtx_begin; ra.lds = -1; ra.count = (int)hulls[ha].vtx_count;
+                    ra.sc = V(hulls[ha].sphere[0], hulls[ha].sphere[1], hulls[ha].sphere[2]); ra.sr = hulls[ha].sphere[3];
+                    rb.g = reinterpret_cast<const float4*>(hull_verts) + hulls[hb].vtx_begin; rb.lds = -1; rb.count = (int)hulls[hb].vtx_count;
+                    rb.sc = V(hulls[hb].sphere[0], hulls[hb].sphere[1], hulls[hb].sphere[2]); rb.sr = hulls[hb].sphere[3];
                     Shape A, B;
-                    make_shape(wb[i], hulls[ha], hull_verts, A);
-                    make_shape(wb[j], hulls[hb], hull_verts, B);
-                    const v3 ca = add(m3_mul(wb[i].R, V(hulls[ha].sphere[0], hulls[ha].sphere[1], hulls[ha].sphere[2])), wb[i].t);
-                    const v3 cb = add(m3_mul(wb[j].R, V(hulls[hb].sphere[0], hulls[hb].sphere[1], hulls[hb].sphere[2])), wb[j].t);
+                    make_shape(wb[i], ra, A);
+                    make_shape(wb[j], rb, B);
+                    const v3 ca = add(m3_mul(wb[i].R, ra.sc), wb[i].t);
+                    const v3 cb = add(m3_mul(wb[j].R, rb.sc), wb[j].t);
                     const v3 dd = sub(ca, cb);
-                    const float r2 = hulls[ha].sphere[3] + hulls[hb].sphere[3];
+                    const float r2 = ra.sr + rb.sr;
                     if (dot(dd, dd) > r2 * r2) continue;
                     v3 pa, pb;
                     float dist;
-                    if (!gjk_distance(A, B, dd, &pa, &pb, &dist)) hit = true;
+                    if (gjk_distance(A, B, nullptr, dd, 0.0f, &pa, &pb, &dist) == 0) hit = true;
                 }
         }
         if (!hit && sc.has_plane) {
@@ -1054,7 +1338,7 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
 
 extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, uint64_t* bytes_out)
 {
-    *bytes_out = (uint64_t)n_scenes * sizeof(SceneScratch);
+    *bytes_out = (uint64_t)n_scenes * sizeof(ProfScratch) + 256;
     return 0;
 }
 
@@ -1068,19 +1352,35 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         return -1;
     }
     if (n_scenes == 0) return 0;
-    if (scratch_bytes < (uint64_t)n_scenes * sizeof(SceneScratch)) {
-        slhip::set_error("slhip_settle: scratch too small (%llu < %llu)", (unsigned long long)scratch_bytes,
-                         (unsigned long long)((uint64_t)n_scenes * sizeof(SceneScratch)));
+    if (scratch_bytes < (uint64_t)n_scenes * sizeof(ProfScratch)) {
+        slhip::set_error("slhip_settle: scratch too small");
         return -1;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_settle), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)sizeof(SceneLds)));
-        attr_set = true;
+    // LDS layout from the batch maxima; hull vertices go to LDS when the whole working set
+    // stays <= 52 KB (3 scenes per CU), otherwise they are read from the global pool
+    int nb_cap = params->max_bodies_per_scene ? (int)params->max_bodies_per_scene : SLHIP_MAX_BODIES;
+    if (nb_cap > SLHIP_MAX_BODIES) {
+        slhip::set_error("slhip_settle: at most %d bodies per scene", SLHIP_MAX_BODIES);
+        return -1;
     }
-    k_settle<<<n_scenes, 64, sizeof(SceneLds), stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params,
-                                                         reinterpret_cast<SceneScratch*>(d_scratch));
+    int lh_cap = params->max_hulls_per_scene ? (int)params->max_hulls_per_scene : 1024;
+    int hv_cap = (int)params->max_hull_verts_per_scene;
+    LdsLayout L = make_layout(nb_cap, lh_cap, hv_cap);
+    const int kLdsBudget = 53 * 1024;  // 3 scenes per CU (160 KiB LDS)
+    if (L.total > kLdsBudget) {
+        const int over = L.total - kLdsBudget;
+        hv_cap = hv_cap - (over + 15) / 16;
+        if (hv_cap < 0) hv_cap = 0;
+        L = make_layout(nb_cap, lh_cap, hv_cap);
+    }
+    if (L.total > 160 * 1024) {
+        slhip::set_error("slhip_settle: scene too large for LDS (%d bytes)", L.total);
+        return -1;
+    }
+    SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_settle), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    L.total));
+    k_settle<<<n_scenes, 64, L.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, L,
+                                                reinterpret_cast<ProfScratch*>(d_scratch));
     SLHIP_LAUNCH_CHECK();
     return 0;
 }

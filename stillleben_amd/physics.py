@@ -54,6 +54,8 @@ class SettleEngine:
         if d_bodies is None:
             d_bodies = eng.upload_records(bodies)
         scratch = self.scratch(len(srec))
+        if bodies is not None:
+            params = SB.sizing_hints(params, srec, bodies, self.pool.arrays()[0])
         prm = np.ascontiguousarray(params)
         stream = torch.cuda.current_stream(eng.device).cuda_stream
         with torch.cuda.device(eng.device):

@@ -22,7 +22,8 @@ scenes = [bench.make_scene(sl, meshes, i) for i in range(B)]
 se = physics.settle_engine()
 planes = [(physics.prepare_tabletop(s), physics.PLANE_HALF_Z) for s in scenes]
 srec, bodies = SB.build_settle_batch(scenes, se.pool, planes)
-prm = SB.default_params(tabletop=True, frames=FRAMES)
+prm = SB.sizing_hints(SB.default_params(tabletop=True, frames=FRAMES), srec, bodies, se.pool.arrays()[0])
+print("hints: bodies %d hull verts %d hulls %d" % (prm["max_bodies_per_scene"], prm["max_hull_verts_per_scene"], prm["max_hulls_per_scene"]))
 se.scratch(B).zero_()
 d = se.eng.upload_records(bodies)
 torch.cuda.synchronize()
@@ -32,18 +33,17 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t
 print("B=%d frames=%d: %.1f ms  (%.3f ms per scene-step-batch, %.0f scene-steps/s)" % (B, FRAMES, dt * 1e3, dt * 1e3 / (FRAMES * 4), B * FRAMES * 4 / dt))
 sc = se._scratch.cpu().numpy()
-per = sc.size // B if sc.size % B == 0 else None
-stride = 120 * 2304 + 4 * 512 + 256
 if os.environ.get("SLHIP_SETTLE_PROFILE"):
-    names = ["a load", "b bodypairs", "c hullpairs", "d narrow", "minsep", "e plane", "wake", "f prep", "g color", "h pos it", "i integ", "j vel it", "k store"]
     tot = np.zeros(16)
     cnt = np.zeros(16)
     for b in range(B):
-        off = b * stride + 120 * 2304 + 4 * 512
+        off = b * 256
         tot += np.frombuffer(sc[off:off + 128].tobytes(), dtype=np.uint64).astype(np.float64)
         cnt += np.frombuffer(sc[off + 128:off + 256].tobytes(), dtype=np.uint64).astype(np.float64)
     steps = FRAMES * 4 * B
     # wall_clock64 ticks at 100 MHz
-    for i, n in enumerate(["a load", "b bodypairs", "c hullpairs", "d narrow", "d2 minsep", "e plane+wake", "f prep", "g color", "h pos", "i integ", "j vel", "k store"]):
-        print("  %-14s %8.2f us/step" % (n, tot[i] / steps / 100.0))
-    print("  avg hull pairs %.1f, body pairs %.1f, groups %.1f, colours %.1f" % tuple(cnt[:4] / steps))
+    for i, n in enumerate(["a load", "b plane", "c broadphase", "d narrow", "d2 ranges+minsep", "wake", "f prep",
+                           "g color", "h pos iters", "i integrate", "j vel iters", "k store"]):
+        print("  %-18s %8.2f us/step" % (n, tot[i] / steps / 100.0))
+    print("  total %.2f us/step" % (tot[:12].sum() / steps / 100.0))
+    print("  avg hull pairs %.1f, active contacts %.1f, groups %.1f, colours %.1f" % tuple(cnt[:4] / steps))
