@@ -269,6 +269,35 @@ int slhip_overlap_any(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
                       const float* d_hull_verts, uint8_t* d_flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * sl.diff half (replaces python/src/diff.cu + bridge_diff.cpp and fuses diff.py:355-523)
+ * ------------------------------------------------------------------------------------------- */
+
+/* generate_sobel_valid_mask (bridge_diff.cpp:13-69, CPU-loop semantics: the 1-px border stays
+ * valid).  d_inst i16[H,W]; d_depth f32 with `depth_stride` floats between pixels (1 for a
+ * dense [H,W] image, 4 to read channel 3 of the coordinate target in place); d_valid u8[H,W].  */
+int slhip_diff_sobel_valid(const int16_t* d_inst, const float* d_depth, int depth_stride, int H, int W,
+                           uint8_t* d_valid, void* stream);
+
+/* dilate_object_mask (bridge_diff.cpp:71-157).  d_coords f32 xyz with `coord_stride` floats
+ * between pixels (3 or 4); outputs u8[H,W] and f32[H,W,3]; the 1-px border reads 0.            */
+int slhip_diff_dilate(const uint8_t* d_mask, const uint8_t* d_valid, const float* d_coords, int coord_stride,
+                      int H, int W, uint8_t* d_out_mask, float* d_out_coords, void* stream);
+
+/* compute_image_space_gradients (diff.py:73-127): d_rgb u8[H,W,4] -> grad_x, grad_y f32[3,H,W],
+ * zero where !valid.                                                                           */
+int slhip_diff_image_gradients(const uint8_t* d_rgb, const uint8_t* d_valid, int H, int W, float* d_grad_x,
+                               float* d_grad_y, void* stream);
+
+/* backpropagate_gradient_to_poses (diff.py:355-523), fused.  d_coord f32[H,W,4] (object xyz,
+ * depth), d_inst i16[H,W], d_grad_img f32[3,H,W], h_proj HOST float[16] (row-major projection),
+ * d_poses f32[n_obj,16], d_obj_inst i32[n_obj]; scratch d_valid u8[H,W], d_acc f64[n_obj*6];
+ * d_out f32[n_obj,6].                                                                          */
+int slhip_diff_pose_backward(const uint8_t* d_rgb, const float* d_coord, const int16_t* d_inst,
+                             const float* d_grad_img, const float* h_proj, const float* d_poses,
+                             const int32_t* d_obj_inst, int n_obj, int H, int W, uint8_t* d_valid,
+                             double* d_acc, float* d_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Library
  * ------------------------------------------------------------------------------------------- */
 int slhip_abi_version(void);

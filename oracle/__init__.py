@@ -120,3 +120,74 @@ def debug_contacts(srec, bodies, hulls, hull_verts, params, max_rows=4096):
                                _p(np.ascontiguousarray(hulls)), _p(np.ascontiguousarray(hull_verts, dtype=np.float32)),
                                _p(np.ascontiguousarray(params)), _p(out), max_rows)
     return out[:n]
+
+
+# ---- sl.diff oracle (oracle/diff_ref.c) ------------------------------------------------------
+def sobel_valid(inst, depth):
+    L = lib()
+    H, W = inst.shape
+    inst = np.ascontiguousarray(inst, dtype=np.int16)
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    out = np.zeros((H, W), np.uint8)
+    L.slref_sobel_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.slref_sobel_valid(_p(inst), _p(depth), H, W, _p(out))
+    return out.astype(bool)
+
+
+def dilate(mask, valid, coords):
+    L = lib()
+    H, W = mask.shape
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    v = np.ascontiguousarray(valid, dtype=np.uint8)
+    c = np.ascontiguousarray(coords, dtype=np.float32)
+    om = np.zeros((H, W), np.uint8)
+    oc = np.zeros((H, W, 3), np.float32)
+    L.slref_dilate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.slref_dilate(_p(m), _p(v), _p(c), H, W, _p(om), _p(oc))
+    return om.astype(bool), oc
+
+
+def image_gradients(rgb, valid):
+    L = lib()
+    H, W = valid.shape
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    v = np.ascontiguousarray(valid, dtype=np.uint8)
+    gx = np.zeros((3, H, W), np.float32)
+    gy = np.zeros((3, H, W), np.float32)
+    L.slref_image_gradients.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.slref_image_gradients(_p(rgb), _p(v), H, W, _p(gx), _p(gy))
+    return gx, gy
+
+
+def pose_backward(rgb, coord, inst, grad_img, P, poses, obj_inst):
+    L = lib()
+    H, W = inst.shape
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    coord = np.ascontiguousarray(coord, dtype=np.float32)
+    inst = np.ascontiguousarray(inst, dtype=np.int16)
+    grad_img = np.ascontiguousarray(grad_img, dtype=np.float32)
+    P = np.ascontiguousarray(P, dtype=np.float32)
+    poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
+    obj_inst = np.ascontiguousarray(obj_inst, dtype=np.int32)
+    out = np.zeros((len(poses), 6), np.float32)
+    L.slref_pose_backward.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.slref_pose_backward(_p(rgb), _p(coord), _p(inst), _p(grad_img), _p(P), _p(poses), _p(obj_inst), len(poses), H, W, _p(out))
+    return out
+
+
+def apply_pose_delta(pose, delta, orthonormalize=True):
+    """D5 (diff.py:525-590), numpy restatement."""
+    pose = np.asarray(pose, dtype=np.float32).reshape(-1, 4, 4)
+    delta = np.asarray(delta, dtype=np.float32).reshape(-1, 6)
+    D = np.zeros((len(pose), 4, 4), np.float32)
+    D[:, 0, 0] = D[:, 1, 1] = D[:, 2, 2] = D[:, 3, 3] = 1.0
+    D[:, 0, 1], D[:, 0, 2] = -delta[:, 2], delta[:, 1]
+    D[:, 1, 0], D[:, 1, 2] = delta[:, 2], -delta[:, 0]
+    D[:, 2, 0], D[:, 2, 1] = -delta[:, 1], delta[:, 0]
+    D[:, :3, 3] = delta[:, 3:]
+    out = np.matmul(pose, D)
+    if orthonormalize:
+        for b in range(len(out)):
+            u, _, vt = np.linalg.svd(out[b, :3, :3].astype(np.float64))
+            out[b, :3, :3] = (u @ vt).astype(np.float32)
+    return out

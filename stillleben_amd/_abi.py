@@ -160,6 +160,10 @@ def lib():
     ]
     L.slhip_timing_enable.argtypes = [C.c_int]
     L.slhip_render_timings.argtypes = [C.POINTER(C.c_float * 8)]
+    L.slhip_diff_sobel_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.slhip_diff_dilate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slhip_diff_image_gradients.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slhip_diff_pose_backward.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     L.slhip_settle.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint64, C.c_void_p]
     L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.POINTER(C.c_uint64)]

@@ -1,0 +1,252 @@
+// slhip_diff.hip -- sl.diff hot path for gfx950: the two 3x3 stencils of the reference's diff.cu /
+// bridge_diff.cpp (CPU-loop semantics, python/src/bridge_diff.cpp:13-157), the image-space
+// gradients (python/stillleben/diff.py:73-127) and a FUSED pose backward
+// (diff.py:355-523): one pass over the G-buffer computes, per pixel, the central-difference
+// image gradient, the dilated object membership and the 1x3 . 3x2 . 2x3 . 3x6 chain, and
+// accumulates [n_obj, 6] through LDS atomics (one global atomic per object and block).
+// All of it is HBM-streaming work: ~35 B/pixel read once (rgb 4, coord+depth 16, instance 2,
+// grad 12, valid 1), nothing written but the [n_obj,6] result.
+#include "slhip_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_sobel_valid(const int16_t* __restrict__ inst, const float* __restrict__ depth,
+                                                     int dstride, int H, int W, uint8_t* __restrict__ valid)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int h = p / W, w = p % W;
+    uint8_t v = 1;
+    if (h >= 1 && h < H - 1 && w >= 1 && w < W - 1) {
+        const int16_t cur = inst[p];
+        if (cur != 0) {
+            const float cd = depth[(size_t)p * dstride];
+#pragma unroll
+            for (int x = -1; x <= 1; ++x)
+#pragma unroll
+                for (int y = -1; y <= 1; ++y) {
+                    const int q = (h + x) * W + (w + y);
+                    const int16_t o = inst[q];
+                    if (o != cur && o != 0 && depth[(size_t)q * dstride] < cd) v = 0;
+                }
+        }
+    }
+    valid[p] = v;
+}
+
+__global__ __launch_bounds__(256) void k_dilate(const uint8_t* __restrict__ mask, const uint8_t* __restrict__ valid,
+                                                const float* __restrict__ coords, int cstride, int H, int W,
+                                                uint8_t* __restrict__ out_mask, float* __restrict__ out_coords)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int h = p / W, w = p % W;
+    uint8_t om = 0;
+    float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+    if (h >= 1 && h < H - 1 && w >= 1 && w < W - 1) {
+        om = mask[p];
+        cx = coords[(size_t)p * cstride]; cy = coords[(size_t)p * cstride + 1]; cz = coords[(size_t)p * cstride + 2];
+        if (om == 0) {
+            bool all_valid = true, all_background = true;
+            float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+            // the reference's `break` only leaves the inner loop; it never changes the outcome
+            // because all_valid is already false then (bridge_diff.cpp:125-142)
+#pragma unroll
+            for (int x = -1; x <= 1; ++x)
+#pragma unroll
+                for (int y = -1; y <= 1; ++y) {
+                    const int q = (h + x) * W + (w + y);
+                    if (mask[q] != 0) {
+                        all_background = false;
+                        nx = coords[(size_t)q * cstride]; ny = coords[(size_t)q * cstride + 1]; nz = coords[(size_t)q * cstride + 2];
+                    }
+                    if (valid[q] == 0) all_valid = false;
+                }
+            if (!all_background && all_valid) { om = 1; cx = nx; cy = ny; cz = nz; }
+        }
+    }
+    out_mask[p] = om;
+    out_coords[3 * (size_t)p] = cx; out_coords[3 * (size_t)p + 1] = cy; out_coords[3 * (size_t)p + 2] = cz;
+}
+
+__device__ __forceinline__ void pixel_gradients(const uint8_t* __restrict__ rgb, int h, int w, int H, int W, float* gx, float* gy)
+{
+    const float sx = (float)W / 4.0f, sy = (float)H / 4.0f;
+    const size_t p = (size_t)h * W + w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float l = w > 0 ? (float)rgb[4 * (p - 1) + c] / 255.0f : 0.0f;
+        const float r = w < W - 1 ? (float)rgb[4 * (p + 1) + c] / 255.0f : 0.0f;
+        const float u = h > 0 ? (float)rgb[4 * (p - W) + c] / 255.0f : 0.0f;
+        const float d = h < H - 1 ? (float)rgb[4 * (p + W) + c] / 255.0f : 0.0f;
+        gx[c] = -((r - l) * sx);
+        gy[c] = -((d - u) * sy);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_image_gradients(const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ valid,
+                                                         int H, int W, float* __restrict__ grad_x, float* __restrict__ grad_y)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    float gx[3], gy[3];
+    pixel_gradients(rgb, p / W, p % W, H, W, gx, gy);
+    const bool v = valid[p] != 0;
+    const size_t N = (size_t)H * W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        grad_x[c * N + p] = v ? gx[c] : 0.0f;
+        grad_y[c * N + p] = v ? gy[c] : 0.0f;
+    }
+}
+
+struct Mat4 { float m[16]; };
+
+constexpr int kMaxDiffObjects = 256;
+
+__global__ __launch_bounds__(256) void k_pose_backward(const uint8_t* __restrict__ rgb, const float* __restrict__ coord,
+                                                       const int16_t* __restrict__ inst, const uint8_t* __restrict__ valid,
+                                                       const float* __restrict__ grad_img, Mat4 P,
+                                                       const float* __restrict__ poses, const int* __restrict__ obj_inst,
+                                                       int n_obj, int H, int W, double* __restrict__ acc)
+{
+    __shared__ double s_acc[kMaxDiffObjects * 6];
+    __shared__ int s_touched[kMaxDiffObjects];
+    for (int i = threadIdx.x; i < n_obj * 6; i += 256) s_acc[i] = 0.0;
+    for (int i = threadIdx.x; i < n_obj; i += 256) s_touched[i] = 0;
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int h = p / W, w = p % W;
+    if (p < H * W && h >= 1 && h < H - 1 && w >= 1 && w < W - 1) {
+        int16_t nid[9];
+        bool all_valid = true;
+#pragma unroll
+        for (int x = -1; x <= 1; ++x)
+#pragma unroll
+            for (int y = -1; y <= 1; ++y) {
+                const int q = (h + x) * W + (w + y);
+                nid[(x + 1) * 3 + (y + 1)] = inst[q];
+                if (valid[q] == 0) all_valid = false;
+            }
+        const int16_t own = nid[4];
+        bool any = own != 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) any = any || (nid[k] != 0 && all_valid);
+        if (any) {
+            const size_t N = (size_t)H * W;
+            float gx[3], gy[3];
+            pixel_gradients(rgb, h, w, H, W, gx, gy);
+            double s0 = 0.0, s1 = 0.0;
+            if (valid[p]) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double gi = (double)grad_img[c * N + p];
+                    s0 += gi * (double)gx[c];
+                    s1 += gi * (double)gy[c];
+                }
+            }
+            for (int o = 0; o < n_obj; ++o) {
+                const int16_t id = (int16_t)obj_inst[o];
+                int src = -1;
+                if (own == id) src = 4;
+                else if (all_valid) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) if (nid[k] == id) src = k;  // last neighbour in scan order
+                }
+                if (src < 0) continue;
+                const int q = (h + src / 3 - 1) * W + (w + src % 3 - 1);
+                const double X[4] = {(double)coord[4 * (size_t)q], (double)coord[4 * (size_t)q + 1], (double)coord[4 * (size_t)q + 2], 1.0};
+                const float* T = poses + 16 * o;
+                double y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    y[r] = (double)T[4 * r] * X[0] + (double)T[4 * r + 1] * X[1] + (double)T[4 * r + 2] * X[2] + (double)T[4 * r + 3] * X[3];
+                double Py[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    Py[r] = (double)P.m[4 * r] * y[0] + (double)P.m[4 * r + 1] * y[1] + (double)P.m[4 * r + 2] * y[2] + (double)P.m[4 * r + 3] * y[3];
+                double r3[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double g0 = (double)P.m[i] * (1.0 / Py[2]) + ((double)P.m[8 + i] * (-1.0 / (Py[2] * Py[2]))) * Py[0];
+                    const double g1 = (double)P.m[4 + i] * (1.0 / Py[2]) + ((double)P.m[8 + i] * (-1.0 / (Py[2] * Py[2]))) * Py[1];
+                    r3[i] = s0 * g0 + s1 * g1;
+                }
+                const double GX[6][4] = {{0, -X[2], X[1], 0}, {X[2], 0, -X[0], 0}, {-X[1], X[0], 0, 0},
+                                         {1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    double g = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const double wv = (double)T[4 * i] * GX[k][0] + (double)T[4 * i + 1] * GX[k][1] + (double)T[4 * i + 2] * GX[k][2] + (double)T[4 * i + 3] * GX[k][3];
+                        g += r3[i] * wv;
+                    }
+                    atomicAdd(&s_acc[o * 6 + k], g);
+                }
+                s_touched[o] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_obj * 6; i += 256)
+        if (s_touched[i / 6]) atomicAdd(&acc[i], s_acc[i]);
+}
+
+__global__ void k_acc_to_float(const double* __restrict__ acc, float* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)acc[i];
+}
+
+}  // namespace
+
+extern "C" int slhip_diff_sobel_valid(const int16_t* d_inst, const float* d_depth, int depth_stride, int H, int W,
+                                      uint8_t* d_valid, void* stream)
+{
+    if (!d_inst || !d_depth || !d_valid || H <= 0 || W <= 0) { slhip::set_error("slhip_diff_sobel_valid: bad argument"); return -1; }
+    k_sobel_valid<<<(H * W + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_inst, d_depth, depth_stride, H, W, d_valid);
+    SLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int slhip_diff_dilate(const uint8_t* d_mask, const uint8_t* d_valid, const float* d_coords, int coord_stride,
+                                 int H, int W, uint8_t* d_out_mask, float* d_out_coords, void* stream)
+{
+    if (!d_mask || !d_valid || !d_coords || !d_out_mask || !d_out_coords) { slhip::set_error("slhip_diff_dilate: null argument"); return -1; }
+    k_dilate<<<(H * W + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_mask, d_valid, d_coords, coord_stride, H, W, d_out_mask, d_out_coords);
+    SLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int slhip_diff_image_gradients(const uint8_t* d_rgb, const uint8_t* d_valid, int H, int W, float* d_grad_x,
+                                          float* d_grad_y, void* stream)
+{
+    if (!d_rgb || !d_valid || !d_grad_x || !d_grad_y) { slhip::set_error("slhip_diff_image_gradients: null argument"); return -1; }
+    k_image_gradients<<<(H * W + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_rgb, d_valid, H, W, d_grad_x, d_grad_y);
+    SLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int slhip_diff_pose_backward(const uint8_t* d_rgb, const float* d_coord, const int16_t* d_inst,
+                                        const float* d_grad_img, const float* h_proj, const float* d_poses,
+                                        const int32_t* d_obj_inst, int n_obj, int H, int W, uint8_t* d_valid,
+                                        double* d_acc, float* d_out, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_rgb || !d_coord || !d_inst || !d_grad_img || !h_proj || !d_poses || !d_obj_inst || !d_valid || !d_acc || !d_out) {
+        slhip::set_error("slhip_diff_pose_backward: null argument");
+        return -1;
+    }
+    if (n_obj <= 0) return 0;
+    if (n_obj > kMaxDiffObjects) { slhip::set_error("slhip_diff_pose_backward: at most %d objects", kMaxDiffObjects); return -1; }
+    Mat4 P;
+    for (int i = 0; i < 16; ++i) P.m[i] = h_proj[i];
+    const int blocks = (H * W + 255) / 256;
+    k_sobel_valid<<<blocks, 256, 0, stream>>>(d_inst, d_coord + 3, 4, H, W, d_valid);
+    SLHIP_CHECK(hipMemsetAsync(d_acc, 0, sizeof(double) * 6 * n_obj, stream));
+    k_pose_backward<<<blocks, 256, 0, stream>>>(d_rgb, d_coord, d_inst, d_valid, d_grad_img, P, d_poses, d_obj_inst, n_obj, H, W, d_acc);
+    k_acc_to_float<<<(6 * n_obj + 63) / 64, 64, 0, stream>>>(d_acc, d_out, 6 * n_obj);
+    SLHIP_LAUNCH_CHECK();
+    return 0;
+}

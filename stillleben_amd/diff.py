@@ -1,1 +1,152 @@
-"""placeholder -- filled in later this round"""
+"""stillleben.diff -- render-and-compare pose gradients (reference python/stillleben/diff.py,
+python/src/bridge_diff.cpp, python/src/diff.cu) on the HIP device.
+
+Same public surface as the reference: ``compute_image_space_gradients``,
+``backpropagate_gradient_to_poses``, ``apply_pose_delta`` plus the two native stencils
+``generate_sobel_valid_mask`` / ``dilate_object_mask``.  All pixel work runs in
+``lib/libslhip.so`` (no CPU implementation: CPU tensors are moved to the HIP device and the
+results moved back, so "the device follows the first argument" as in bridge_diff.cpp:27-28)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._context import engine
+from .profiling import Timer
+
+__all__ = [
+    'compute_image_space_gradients', 'backpropagate_gradient_to_poses', 'apply_pose_delta',
+    'generate_sobel_valid_mask', 'dilate_object_mask',
+]
+
+DIFF_AVAILABLE = True
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(eng):
+    return C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+
+
+def generate_sobel_valid_mask(instance_indices, depth_image):
+    """bridge_diff.cpp:13-69: int16[H,W], float[H,W] -> bool[H,W]."""
+    if instance_indices.dim() != 2 or depth_image.dim() != 2:
+        raise ValueError("input tensors should be two-dimensional")
+    if instance_indices.shape != depth_image.shape:
+        raise ValueError("instance_indices and depth_image should be of same height and width")
+    eng = engine()
+    out_dev = instance_indices.device
+    H, W = instance_indices.shape
+    inst = instance_indices.to(eng.device, torch.int16).contiguous()
+    depth = depth_image.to(eng.device, torch.float32).contiguous()
+    valid = torch.empty((H, W), dtype=torch.uint8, device=eng.device)
+    with torch.cuda.device(eng.device):
+        _abi.check(eng.L.slhip_diff_sobel_valid(_p(inst), _p(depth), 1, H, W, _p(valid), _stream(eng)), "slhip_diff_sobel_valid")
+    return valid.bool().to(out_dev)
+
+
+def dilate_object_mask(object_mask, sobel_valid_mask, coordinates):
+    """bridge_diff.cpp:71-157: bool[H,W], bool[H,W], float[H,W,3] -> (bool[H,W], float[H,W,3])."""
+    if object_mask.dim() != 2 or sobel_valid_mask.dim() != 2:
+        raise ValueError("object_mask &  sobel_valid_mask should be two-dimensional")
+    if coordinates.dim() != 3:
+        raise ValueError("coordinates should be three-dimensional")
+    if object_mask.shape != sobel_valid_mask.shape or object_mask.shape != coordinates.shape[:2]:
+        raise ValueError("object_mask, sobel_valid_mask, and coordinates should be of same height and width")
+    eng = engine()
+    out_dev = object_mask.device
+    H, W = object_mask.shape
+    m = object_mask.to(eng.device, torch.uint8).contiguous()
+    v = sobel_valid_mask.to(eng.device, torch.uint8).contiguous()
+    c = coordinates.to(eng.device, torch.float32).contiguous()
+    om = torch.empty((H, W), dtype=torch.uint8, device=eng.device)
+    oc = torch.empty((H, W, 3), dtype=torch.float32, device=eng.device)
+    with torch.cuda.device(eng.device):
+        _abi.check(eng.L.slhip_diff_dilate(_p(m), _p(v), _p(c), int(c.shape[2]), H, W, _p(om), _p(oc), _stream(eng)),
+                   "slhip_diff_dilate")
+    return om.bool().to(out_dev), oc.to(out_dev)
+
+
+def compute_image_space_gradients(scene, render_result):
+    """diff.py:73-127 -> (grad_x [3,H,W], grad_y [3,H,W], sobel_valid_mask bool[H,W])."""
+    eng = engine()
+    rgb = render_result.rgb()
+    out_dev = rgb.device
+    H, W = rgb.shape[:2]
+    with Timer('sobel_valid_mask'):
+        inst = render_result.instance_index().squeeze(-1).to(eng.device).contiguous()
+        depth = render_result.depth().to(eng.device).contiguous()
+        valid = torch.empty((H, W), dtype=torch.uint8, device=eng.device)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.L.slhip_diff_sobel_valid(_p(inst), _p(depth), 1, H, W, _p(valid), _stream(eng)),
+                       "slhip_diff_sobel_valid")
+    with Timer('sobel'):
+        rgb_d = rgb.to(eng.device).contiguous()
+        gx = torch.empty((3, H, W), dtype=torch.float32, device=eng.device)
+        gy = torch.empty((3, H, W), dtype=torch.float32, device=eng.device)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.L.slhip_diff_image_gradients(_p(rgb_d), _p(valid), H, W, _p(gx), _p(gy), _stream(eng)),
+                       "slhip_diff_image_gradients")
+    return gx.to(out_dev), gy.to(out_dev), valid.bool().to(out_dev)
+
+
+def backpropagate_gradient_to_poses(scene, render_result, grad_objective_wrt_rnd_img, visualize_grad=False):
+    r"""diff.py:355-523: gradient of the objective w.r.t. the locally linearised pose parameters
+    (alpha, beta, gamma, a, b, c) of every object -> float[N, 6] (CPU tensor, as the reference)."""
+    eng = engine()
+    objs = scene.objects
+    n = len(objs)
+    out = torch.zeros(n, 6)
+    if n == 0:
+        return out
+    rgb = render_result.rgb().to(eng.device).contiguous()
+    H, W = rgb.shape[:2]
+    coord = render_result.coordDepth().to(eng.device).contiguous()
+    inst = render_result.instance_index().squeeze(-1).to(eng.device).contiguous()
+    g = grad_objective_wrt_rnd_img.to(eng.device, torch.float32).contiguous()
+    if tuple(g.shape) != (3, H, W):
+        raise ValueError("grad_objective_wrt_rnd_img must be 3xHxW")
+    poses = torch.stack([o.pose() for o in objs]).to(eng.device, torch.float32).contiguous()
+    ids = torch.tensor([o.instance_index for o in objs], dtype=torch.int32, device=eng.device)
+    P = np.ascontiguousarray(scene.projection_matrix().numpy(), dtype=np.float32)
+    valid = torch.empty((H, W), dtype=torch.uint8, device=eng.device)
+    acc = torch.empty(6 * n, dtype=torch.float64, device=eng.device)
+    res = torch.empty((n, 6), dtype=torch.float32, device=eng.device)
+    with torch.cuda.device(eng.device):
+        st = eng.L.slhip_diff_pose_backward(_p(rgb), _p(coord), _p(inst), _p(g), C.c_void_p(P.ctypes.data), _p(poses),
+                                            _p(ids), n, H, W, _p(valid), _p(acc), _p(res), _stream(eng))
+    _abi.check(st, "slhip_diff_pose_backward")
+    return res.cpu()
+
+
+def apply_pose_delta(pose, delta, orthonormalize=True):
+    r"""diff.py:525-590 (host-side in the reference too): pose . [I + skew(alpha,beta,gamma) | abc]."""
+    if pose.dim() == 3:
+        assert delta.dim() == 2
+        batched = True
+    else:
+        assert delta.dim() == 1
+        batched = False
+        pose = pose.unsqueeze(0)
+        delta = delta.unsqueeze(0)
+    device = pose.device
+    pose = pose.cpu().float()
+    delta = delta.cpu().float()
+    B = pose.size(0)
+    dm = torch.zeros(B, 4, 4)
+    dm[:, 0, 0] = 1.0; dm[:, 0, 1] = -delta[:, 2]; dm[:, 0, 2] = delta[:, 1]
+    dm[:, 1, 0] = delta[:, 2]; dm[:, 1, 1] = 1.0; dm[:, 1, 2] = -delta[:, 0]
+    dm[:, 2, 0] = -delta[:, 1]; dm[:, 2, 1] = delta[:, 0]; dm[:, 2, 2] = 1.0
+    dm[:, :3, 3] = delta[:, 3:]
+    dm[:, 3, 3] = 1.0
+    new_poses = torch.matmul(pose, dm)
+    if orthonormalize:
+        for b in range(B):
+            U, S, Vh = torch.linalg.svd(new_poses[b, :3, :3])
+            new_poses[b, :3, :3] = U @ Vh
+    if not batched:
+        new_poses = new_poses[0]
+    return new_poses.to(device)
