@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Generates `<mesh>.hulls.npz` fixtures with the REFERENCE's vendored V-HACD (compiled where it
+lies into oracle/_ref/vhacd_driver) and the reference's parameters/selection rule
+(src/mesh.cpp:351-355, :394-396, :426-429).  stillleben_amd.hulls picks these files up, so the
+GPU box settles the test meshes on exactly the hulls the reference would cook."""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from stillleben_amd import _loaders  # noqa: E402
+
+DRIVER = os.path.join(HERE, "..", "_ref", "vhacd_driver")
+
+
+def run(mesh_path):
+    cm = _loaders.load_any(mesh_path)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<II", len(cm.positions), len(cm.indices) // 3))
+            f.write(cm.positions.astype(np.float32).tobytes())
+            f.write(cm.indices.astype(np.uint32).tobytes())
+        subprocess.run([DRIVER, fin, fout], check=True)
+        raw = open(fout, "rb").read()
+    off = 0
+    (n,) = struct.unpack_from("<I", raw, off); off += 4
+    out = {"n_hulls": np.int32(n)}
+    for i in range(n):
+        nv, nt = struct.unpack_from("<II", raw, off); off += 8
+        (vol,) = struct.unpack_from("<d", raw, off); off += 8
+        v = np.frombuffer(raw, np.float32, 3 * nv, off).reshape(nv, 3); off += 12 * nv
+        t = np.frombuffer(raw, np.uint32, 3 * nt, off).reshape(nt, 3); off += 12 * nt
+        out["v%d" % i], out["t%d" % i] = v.copy(), t.astype(np.int32)
+    dst = mesh_path + ".hulls.npz"
+    np.savez_compressed(dst, **out)
+    print(mesh_path, "->", n, "hulls,", sum(len(out["v%d" % i]) for i in range(n)), "vertices,", os.path.getsize(dst) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    fx = os.path.join(ROOT, "tests", "fixtures")
+    for p in sys.argv[1:] or [os.path.join(fx, "cube.glb"), os.path.join(fx, "stanford_bunny", "scene.gltf")]:
+        run(p)
