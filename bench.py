@@ -219,18 +219,15 @@ def main():
         items.append(pipe.prepare([make_scene(sl, meshes, base + i) for i in range(args.batch)], seed=base))
     torch.cuda.synchronize()
 
-    gather_bufs = None
+    from stillleben_amd.parallel import BatchGatherer
+
+    gatherer = BatchGatherer(dist, world)
 
     def gather(outs):
         # RCCL all-gather of the rendered batches, one collective per dtype buffer and chunk
-        nonlocal gather_bufs
         if dist is None:
             return
-        tensors = [t for b in outs for t in (b.rgb, b.coord, b.cls, b.instance, b.normals) if t is not None]
-        if gather_bufs is None:
-            gather_bufs = [torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in tensors]
-        for t, g in zip(tensors, gather_bufs):
-            dist.all_gather_into_tensor(g, t)
+        gatherer([t for b in outs for t in (b.rgb, b.coord, b.cls, b.instance, b.normals) if t is not None])
 
     for k in range(args.warmup):
         gather(pipe.step(items[k], timed=False))
