@@ -208,8 +208,12 @@ typedef struct {
     uint32_t flags;
     uint32_t hull_begin, hull_end;
     int32_t stuck_counter;
-    uint32_t _pad;
-} slhip_body;                /* 240 bytes */
+    uint32_t drive_flags;    /* bit 0: linear spring drive enabled; bits 1..3: rotation about the
+                                joint x/y/z axis locked (ManipulationSim, manipulation_sim.cpp:28-93) */
+    float drive_target[4];   /* world position the object origin is driven to                 */
+    float drive_frame[4];    /* joint frame orientation (quaternion x y z w) = initial pose   */
+    float drive_params[4];   /* stiffness, damping, force limit (manipulation_sim.cpp:52-55), unused */
+} slhip_body;                /* 288 bytes */
 
 /* One scene of the settle batch: bodies [body_begin, body_end).                              */
 typedef struct {

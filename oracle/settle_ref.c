@@ -121,6 +121,7 @@ typedef struct {
     m3 Iinv_w;     /* world inverse inertia */
     float inv_mass;
     int dynamic;   /* moves this step (not static, not asleep) */
+    float dl[3], da[3]; /* accumulated drive impulses (linear along the joint axes, angular) */
 } wbody;
 
 typedef struct {
@@ -683,6 +684,57 @@ static void solve_contact(contact* c, wbody* wbs, const slhip_settle_params* prm
     apply_impulse(a, b, c, madd(scale(c->t1, d1), c->t2, d2));
 }
 
+/* D6 joint of ManipulationSim (manipulation_sim.cpp:46-93): world-anchored, linear X/Y/Z driven by
+   an implicit spring (soft constraint: gamma = 1/(dt (d + dt k)), beta = dt k / (d + dt k), impulse
+   per axis limited to forceLimit * dt), locked rotation axes as hard rows with the same 0.8/dt
+   positional bias as contacts (position iterations only). */
+static void solve_drive(const slhip_body* b, wbody* w, const slhip_settle_params* prm, int biased)
+{
+    if (!(b->drive_flags & 1u) || !w->dynamic) return;
+    const float dt = prm->dt;
+    const float k = b->drive_params[0], d = b->drive_params[1], flim = b->drive_params[2] * dt;
+    quat qj = {b->drive_frame[0], b->drive_frame[1], b->drive_frame[2], b->drive_frame[3]};
+    m3 J;
+    quat_to_m3(qj, &J);
+    v3 r = sub(w->t, w->x); /* object origin relative to the COM */
+    v3 err = sub(w->t, V(b->drive_target[0], b->drive_target[1], b->drive_target[2]));
+    const float den = d + dt * k;
+    const float gamma = 1.0f / (dt * den);
+    const float beta = dt * k / den;
+    for (int a = 0; a < 3; ++a) {
+        v3 ax = V(J.m[a], J.m[3 + a], J.m[6 + a]); /* column a of the joint rotation */
+        v3 rn = cross(r, ax);
+        float K = w->inv_mass + dot(cross(m3_mul(&w->Iinv_w, rn), r), ax);
+        float meff = 1.0f / (K + gamma);
+        float u = dot(vel_at(w, r), ax);
+        float C = dot(err, ax);
+        float dlam = -meff * (u + (beta / dt) * C + gamma * w->dl[a]);
+        float lam = w->dl[a] + dlam;
+        if (lam > flim) lam = flim;
+        if (lam < -flim) lam = -flim;
+        dlam = lam - w->dl[a];
+        w->dl[a] = lam;
+        v3 Jimp = scale(ax, dlam);
+        w->v = madd(w->v, Jimp, w->inv_mass);
+        w->w = add(w->w, m3_mul(&w->Iinv_w, cross(r, Jimp)));
+    }
+    /* rotation error of the body w.r.t. the joint frame: q_err = q * conj(qj), theta ~ 2 q_err.xyz */
+    quat qc = {-qj.x, -qj.y, -qj.z, qj.w};
+    quat qe = quat_mul(w->q, qc);
+    float sgn = qe.w < 0.0f ? -2.0f : 2.0f;
+    v3 theta = V(qe.x * sgn, qe.y * sgn, qe.z * sgn);
+    for (int a = 0; a < 3; ++a) {
+        if (!(b->drive_flags & (2u << a))) continue;
+        v3 ax = V(J.m[a], J.m[3 + a], J.m[6 + a]);
+        float K = dot(m3_mul(&w->Iinv_w, ax), ax);
+        if (!(K > 0.0f)) continue;
+        float bias = biased ? 0.8f * dot(theta, ax) / dt : 0.0f;
+        float dlam = -(dot(w->w, ax) + bias) / K;
+        w->da[a] += dlam;
+        w->w = add(w->w, m3_mul(&w->Iinv_w, scale(ax, dlam)));
+    }
+}
+
 /* greedy colouring in group order: a group gets the smallest colour unused by its bodies */
 static void color_groups(scene_ws* ws, int n_bodies)
 {
@@ -702,13 +754,14 @@ static void color_groups(scene_ws* ws, int n_bodies)
     ws->n_colors = nc;
 }
 
-static void solve_iteration(scene_ws* ws, const slhip_settle_params* prm, int biased)
+static void solve_iteration(scene_ws* ws, const slhip_body* bodies, int nb, const slhip_settle_params* prm, int biased)
 {
     for (int col = 0; col < ws->n_colors; ++col)
         for (int g = 0; g < ws->n_groups; ++g) {
             if (ws->g_color[g] != col) continue;
             for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) solve_contact(&ws->c[i], ws->wb, prm, biased);
         }
+    for (int i = 0; i < nb; ++i) solve_drive(&bodies[i], &ws->wb[i], prm, biased);
 }
 
 /* world AABB of a hull = |R| * local half extents around R c + t; boxes must overlap within margin */
@@ -742,6 +795,7 @@ static void load_body(const slhip_body* b, wbody* w)
     w->w = V(b->ang_vel[0], b->ang_vel[1], b->ang_vel[2]);
     w->inv_mass = b->inv_mass;
     w->dynamic = !(b->flags & (SLHIP_BODY_STATIC | SLHIP_BODY_ASLEEP)) && b->inv_mass > 0.0f;
+    for (int k = 0; k < 3; ++k) { w->dl[k] = 0.0f; w->da[k] = 0.0f; }
 }
 
 static void update_world_inertia(const slhip_body* b, wbody* w)
@@ -894,7 +948,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
 
     /* (g) colouring, (h) position iterations (biased) */
     color_groups(ws, nb);
-    for (uint32_t it = 0; it < prm->pos_iters; ++it) solve_iteration(ws, prm, 1);
+    for (uint32_t it = 0; it < prm->pos_iters; ++it) solve_iteration(ws, bodies, nb, prm, 1);
 
     /* (i) integrate poses with the biased velocities */
     for (int i = 0; i < nb; ++i) {
@@ -914,7 +968,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
     }
 
     /* (j) velocity iterations (unbiased): what is left in v,w is carried to the next step */
-    for (uint32_t it = 0; it < prm->vel_iters; ++it) solve_iteration(ws, prm, 0);
+    for (uint32_t it = 0; it < prm->vel_iters; ++it) solve_iteration(ws, bodies, nb, prm, 0);
 
     /* (k) store, sleep bookkeeping */
     for (int i = 0; i < nb; ++i) {
@@ -924,7 +978,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         /* mass-normalised kinetic energy; the angular part uses the bounding radius as lever */
         float r = bodies[i].bsphere[3];
         float en = 0.5f * (dot(wb[i].v, wb[i].v) + r * r * dot(wb[i].w, wb[i].w));
-        if (en >= prm->sleep_threshold) bodies[i].wake_counter = prm->wake_time;
+        if (en >= prm->sleep_threshold || (bodies[i].drive_flags & 1u)) bodies[i].wake_counter = prm->wake_time;
         else {
             bodies[i].wake_counter -= dt;
             if (bodies[i].wake_counter <= 0.0f) {

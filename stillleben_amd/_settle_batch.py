@@ -15,9 +15,10 @@ BODY_DTYPE = np.dtype([
     ("bsphere", np.float32, (4,)),
     ("bbox_center", np.float32, (4,)),
     ("max_lin_vel", np.float32), ("separation", np.float32), ("wake_counter", np.float32), ("flags", np.uint32),
-    ("hull_begin", np.uint32), ("hull_end", np.uint32), ("stuck_counter", np.int32), ("_pad", np.uint32),
+    ("hull_begin", np.uint32), ("hull_end", np.uint32), ("stuck_counter", np.int32), ("drive_flags", np.uint32),
+    ("drive_target", np.float32, (4,)), ("drive_frame", np.float32, (4,)), ("drive_params", np.float32, (4,)),
 ])
-assert BODY_DTYPE.itemsize == 240
+assert BODY_DTYPE.itemsize == 288
 
 HULL_DTYPE = np.dtype([("vtx_begin", np.uint32), ("vtx_count", np.uint32), ("_pad", np.uint32, (2,)),
                        ("sphere", np.float32, (4,)), ("aabb_center", np.float32, (4,)), ("aabb_half", np.float32, (4,))])
@@ -137,6 +138,12 @@ def body_record(obj, pool, rec):
     rec["flags"] = BODY_STATIC if obj._static else 0
     rec["hull_begin"], rec["hull_end"] = hb, he
     rec["stuck_counter"] = obj._stuck_counter
+    drv = getattr(obj, "_drive", None)
+    if drv is not None:
+        rec["drive_flags"] = drv["flags"]
+        rec["drive_target"][:3] = drv["target"]
+        rec["drive_frame"] = drv["frame"]
+        rec["drive_params"][:3] = (drv["stiffness"], drv["damping"], drv["force_limit"])
 
 
 def build_settle_batch(scenes, pool, with_plane):

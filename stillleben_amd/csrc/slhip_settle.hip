@@ -19,7 +19,7 @@
 
 namespace {
 
-static_assert(sizeof(slhip_body) == 240, "slhip_body layout");
+static_assert(sizeof(slhip_body) == 288, "slhip_body layout");
 static_assert(sizeof(slhip_hull) == 64, "slhip_hull layout");
 static_assert(sizeof(slhip_settle_params) == 100, "slhip_settle_params layout");
 
@@ -106,6 +106,7 @@ __device__ __forceinline__ quat quat_mul(quat a, quat b)
 struct WBody {
     v3 x; quat q; m3 R; v3 t; v3 v, w; m3 Iinv_w;
     float inv_mass; int dynamic;
+    float dl[3], da[3];   // accumulated drive impulses
 };
 
 // solver contact, compacted in LDS (plane contacts first, then hull-pair contacts in pair order)
@@ -771,6 +772,55 @@ __device__ void solve_contact(Contact* cp, WBody* wbs, const slhip_settle_params
     cp->ln = c.ln; cp->lt1 = c.lt1; cp->lt2 = c.lt2;
 }
 
+// D6 joint drive of ManipulationSim (same arithmetic as the oracle's solve_drive)
+__device__ void solve_drive(const slhip_body& b, WBody& w, const slhip_settle_params& prm, bool biased)
+{
+    if (!(b.drive_flags & 1u) || !w.dynamic) return;
+    const float dt = prm.dt;
+    const float k = b.drive_params[0], d = b.drive_params[1], flim = b.drive_params[2] * dt;
+    quat qj; qj.x = b.drive_frame[0]; qj.y = b.drive_frame[1]; qj.z = b.drive_frame[2]; qj.w = b.drive_frame[3];
+    m3 J;
+    quat_to_m3(qj, J);
+    const v3 r = sub(w.t, w.x);
+    const v3 err = sub(w.t, V(b.drive_target[0], b.drive_target[1], b.drive_target[2]));
+    const float den = d + dt * k;
+    const float gamma = 1.0f / (dt * den);
+    const float beta = dt * k / den;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const v3 ax = V(J.m[a], J.m[3 + a], J.m[6 + a]);
+        const v3 rn = cross(r, ax);
+        const float K = w.inv_mass + dot(cross(m3_mul(w.Iinv_w, rn), r), ax);
+        const float meff = 1.0f / (K + gamma);
+        const float u = dot(vel_at(w, r), ax);
+        const float C = dot(err, ax);
+        float dlam = -meff * (u + (beta / dt) * C + gamma * w.dl[a]);
+        float lam = w.dl[a] + dlam;
+        if (lam > flim) lam = flim;
+        if (lam < -flim) lam = -flim;
+        dlam = lam - w.dl[a];
+        w.dl[a] = lam;
+        const v3 Jimp = scale(ax, dlam);
+        w.v = madd(w.v, Jimp, w.inv_mass);
+        w.w = add(w.w, m3_mul(w.Iinv_w, cross(r, Jimp)));
+    }
+    quat qc; qc.x = -qj.x; qc.y = -qj.y; qc.z = -qj.z; qc.w = qj.w;
+    const quat qe = quat_mul(w.q, qc);
+    const float sgn = qe.w < 0.0f ? -2.0f : 2.0f;
+    const v3 theta = V(qe.x * sgn, qe.y * sgn, qe.z * sgn);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (!(b.drive_flags & (2u << a))) continue;
+        const v3 ax = V(J.m[a], J.m[3 + a], J.m[6 + a]);
+        const float K = dot(m3_mul(w.Iinv_w, ax), ax);
+        if (!(K > 0.0f)) continue;
+        const float bias = biased ? 0.8f * dot(theta, ax) / dt : 0.0f;
+        const float dlam = -(dot(w.w, ax) + bias) / K;
+        w.da[a] += dlam;
+        w.w = add(w.w, m3_mul(w.Iinv_w, scale(ax, dlam)));
+    }
+}
+
 __device__ void load_body(const slhip_body& b, WBody& w)
 {
     for (int r = 0; r < 3; ++r)
@@ -783,6 +833,8 @@ __device__ void load_body(const slhip_body& b, WBody& w)
     w.w = V(b.ang_vel[0], b.ang_vel[1], b.ang_vel[2]);
     w.inv_mass = b.inv_mass;
     w.dynamic = (!(b.flags & (SLHIP_BODY_STATIC | SLHIP_BODY_ASLEEP)) && b.inv_mass > 0.0f) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w.dl[k] = 0.0f; w.da[k] = 0.0f; }
 }
 
 __device__ void update_world_inertia(const slhip_body& b, WBody& w)
@@ -1196,7 +1248,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             PROF_COUNT(2, n_groups); PROF_COUNT(3, ncol); PROF_COUNT(1, n_active);
 
             // (h) position iterations
-            for (unsigned it = 0; it < prm.pos_iters; ++it)
+            for (unsigned it = 0; it < prm.pos_iters; ++it) {
                 for (int col = 0; col < ncol; ++col) {
                     for (int g = lane; g < n_groups; g += 64) {
                         const Group G = groups[g];
@@ -1205,6 +1257,9 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     }
                     __syncthreads();
                 }
+                for (int i = lane; i < nb; i += 64) solve_drive(bodies[i], wb[i], prm, true);
+                __syncthreads();
+            }
             PROF(8);
 
             // (i) integrate poses
@@ -1228,7 +1283,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             PROF(9);
 
             // (j) velocity iterations
-            for (unsigned it = 0; it < prm.vel_iters; ++it)
+            for (unsigned it = 0; it < prm.vel_iters; ++it) {
                 for (int col = 0; col < ncol; ++col) {
                     for (int g = lane; g < n_groups; g += 64) {
                         const Group G = groups[g];
@@ -1237,6 +1292,9 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     }
                     __syncthreads();
                 }
+                for (int i = lane; i < nb; i += 64) solve_drive(bodies[i], wb[i], prm, false);
+                __syncthreads();
+            }
             PROF(10);
 
             // (k) store + sleep bookkeeping
@@ -1246,7 +1304,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                 wb[i].t = sub(wb[i].x, m3_mul(wb[i].R, V(bodies[i].com[0], bodies[i].com[1], bodies[i].com[2])));
                 const float r = bodies[i].bsphere[3];
                 const float en = 0.5f * (dot(wb[i].v, wb[i].v) + r * r * dot(wb[i].w, wb[i].w));
-                if (en >= prm.sleep_threshold) bodies[i].wake_counter = prm.wake_time;
+                if (en >= prm.sleep_threshold || (bodies[i].drive_flags & 1u)) bodies[i].wake_counter = prm.wake_time;
                 else {
                     bodies[i].wake_counter -= dt;
                     if (bodies[i].wake_counter <= 0.0f) {

@@ -141,3 +141,34 @@ def test_public_api(sl):
         assert float(o.linear_velocity.abs().max()) < 0.05
     scene.check_collisions()
     assert all(o.separation == 0.0 for o in scene.objects)
+
+
+def test_manipulation_sim_parity_and_api(sl, oracle):
+    from stillleben_amd import physics
+
+    cube = scaled(sl, S.CUBE, 0.1)
+    scene = sl.Scene((320, 240))
+    target = sl.Object(cube)
+    scene.add_object(target)
+    p = torch.eye(4)
+    p[0, 3] = 0.15
+    target.set_pose(p)
+    tool = sl.Object(cube)
+    sim = sl.ManipulationSim(scene, tool, torch.eye(4))
+    assert tool in scene.objects
+    tool._drive["target"] = np.array([0.3, 0.0, 0.0], np.float32)
+    se = physics.settle_engine()
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(False, 0.0)])
+    prm = SB.default_params(tabletop=False, dt=0.005, frames=50, substeps=1)
+    gpu = se.run(srec, bodies.copy(), prm)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    oracle.settle(srec, ref, hulls, verts, prm)
+    assert_bodies_equal(gpu, ref)
+    # public API: step towards a goal
+    goal = torch.eye(4)
+    goal[0, 3] = 0.05
+    x0 = float(tool.pose()[0, 3])
+    for _ in range(20):
+        sim.step(goal, 0.005)
+    assert float(tool.pose()[0, 3]) > x0

@@ -201,3 +201,43 @@ def test_overlap_query(sl, oracle):
     b_.set_pose(p)
     srec, bodies = SB.build_settle_batch([scene], pool, [(False, 0.0)])
     assert oracle.overlap_any(srec, bodies, hulls, verts).tolist() == [0, 0]
+
+
+def _drive_scene(sl):
+    cube = scaled_cube(sl, 0.1)
+    scene = sl.Scene((320, 240))
+    tool, target = sl.Object(cube), sl.Object(cube)
+    scene.add_object(target)
+    p = torch.eye(4)
+    p[0, 3] = 0.15
+    target.set_pose(p)
+    init = torch.eye(4)
+    sim = sl.ManipulationSim(scene, tool, init)
+    return scene, sim, tool, target
+
+
+def test_manipulation_drive_spring(sl, oracle):
+    # S10: the manipulator is pulled to the goal by the spring drive, keeps its orientation
+    # (locked axes) and pushes a free object out of the way; the force limit caps its acceleration.
+    scene, sim, tool, target = _drive_scene(sl)
+    pool = SB.HullPool()
+    tool._drive["target"] = np.array([0.3, 0.0, 0.0], np.float32)
+    srec, bodies = SB.build_settle_batch([scene], pool, [(False, 0.0)])
+    hulls, verts = pool.arrays()
+    prm = SB.default_params(tabletop=False, dt=0.005, frames=1, substeps=1)
+    prm["gravity"] = (0.0, 0.0, 0.0)
+    mass = tool.mass
+    vmax = 0.0
+    for i in range(400):
+        oracle.settle(srec, bodies, hulls, verts, prm)
+        v = float(bodies[1]["lin_vel"][0])
+        if i == 0:
+            # force limit 60 N: dv <= F dt / m (manipulation_sim.cpp:55)
+            assert 0 < v <= 60.0 * 0.005 / mass * 1.0001
+        vmax = max(vmax, v)
+    tool_x, target_x = bodies[1]["pose"][3], bodies[0]["pose"][3]
+    assert abs(tool_x - 0.3) < 0.05                      # reached the goal neighbourhood
+    assert target_x > 0.3                                # the free cube was pushed ahead
+    R = bodies[1]["pose"].reshape(4, 4)[:3, :3]
+    assert np.allclose(R, np.eye(3), atol=2e-2)          # rotation stayed locked
+    assert np.all(np.isfinite(bodies["pose"]))
