@@ -274,6 +274,15 @@ def main():
         }
         if roof_render["achieved"]:
             roof_render["frac"] = roof_render["achieved"] / roof_render["peak"]
+        # HBM traffic from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes on
+        # the same workload, committed under profiles/): bytes per scene x scenes per launch
+        pmc = os.path.join(ROOT, "profiles", "r01", "render_pmc_b64.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                per_scene = json.load(f)["kernels"]["k_shade"]["hbm_bytes_per_scene"]
+            roof_render["traffic"] = per_scene * args.render_chunk
+            roof_render["traffic_source"] = "profiles/r01/render_pmc_b64.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            roof_render["algorithmic_bytes_per_launch"] = shade_bytes / n_chunks
         # settle: hull vertices + body state are read once and written once per scene (HBM),
         # everything else lives in LDS/L2: an HBM fraction is reported for completeness only
         settle_bytes = args.batch * (N_OBJECTS * 240 * 2 + 20 * 64 * 16)
