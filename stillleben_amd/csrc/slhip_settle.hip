@@ -109,12 +109,17 @@ struct WBody {
     float dl[3], da[3];   // accumulated drive impulses
 };
 
-// solver contact, compacted in LDS (plane contacts first, then hull-pair contacts in pair order)
+// solver contact, compacted in LDS (plane contacts first, then hull-pair contacts in pair order).
+// 80 bytes: the tangent basis is a pure function of n and is recomputed in the solver, the
+// restitution target is folded into `bounce` (-inf = none).
 struct Contact {
     short a, b;
-    v3 ra, rb, n, t1, t2;
+    v3 ra, rb, n;
     float err;            // sep - rest
-    float kn, kt1, kt2, ln, lt1, lt2, vn0, mu_s, mu_d, e;
+    float kn, kt1, kt2, ln, lt1, lt2;
+    float bounce;         // required rebound velocity (-e * vn0) or a large negative number
+    float mu_s, mu_d;
+    float e;              // restitution (consumed by prep)
 };
 
 // raw narrowphase result of one hull pair / one body-vs-plane test (registers)
@@ -148,7 +153,9 @@ struct Shape {
 
 // argmax_i dot(v_i, d) with first-maximum tie break.  Vertices are fetched eight at a time so
 // that the (LDS or L1) latency of the batch overlaps; the compare chain stays in index order.
-__device__ __forceinline__ v3 support(const Shape& s, const float4* __restrict__ hv, v3 d)
+struct f3 { float x, y, z; };   // 12-byte LDS vertex
+
+__device__ __forceinline__ v3 support(const Shape& s, const f3* __restrict__ hv, v3 d)
 {
     const v3 dl = m3_tmul(s.R, d);
     int best = 0;
@@ -159,7 +166,10 @@ __device__ __forceinline__ v3 support(const Shape& s, const float4* __restrict__
         float4 p[8];
         if (s.lds >= 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) p[j] = hv[s.lds + min(base + j, n - 1)];
+            for (int j = 0; j < 8; ++j) {
+                const f3 q = hv[s.lds + min(base + j, n - 1)];
+                p[j] = make_float4(q.x, q.y, q.z, 1.0f);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) p[j] = s.g[min(base + j, n - 1)];
@@ -319,7 +329,7 @@ __device__ __forceinline__ bool same_w(const SV& a, const SV& b)
 }
 
 // returns 1 (separated, witnesses valid), 0 (touching / overlapping), 2 (farther than margin)
-__device__ int gjk_distance(const Shape& A, const Shape& B, const float4* __restrict__ hv, v3 init_dir, float margin,
+__device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict__ hv, v3 init_dir, float margin,
                             v3* pa, v3* pb, float* dist)
 {
     Simplex S;
@@ -375,7 +385,7 @@ __device__ __forceinline__ void tangents(v3 n, v3* t1, v3* t2)
     *t2 = cross(n, *t1);
 }
 
-__device__ void overlap_fallback(const Shape& A, const Shape& B, const float4* __restrict__ hv, v3 ca, v3 cb, v3* n,
+__device__ void overlap_fallback(const Shape& A, const Shape& B, const f3* __restrict__ hv, v3 ca, v3 cb, v3* n,
                                  float* sep, v3* pa, v3* pb)
 {
     v3 axes[7];
@@ -500,7 +510,7 @@ __device__ float reduce_candidates(const Cand5& c, v3 nrm, RawContacts& out)
 
 // hull pair -> up to 4 raw contacts; returns min separation (or +inf)
 __device__ float hull_pair_contacts(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
-                                    const float4* __restrict__ hv, const slhip_settle_params& prm, float margin,
+                                    const f3* __restrict__ hv, const slhip_settle_params& prm, float margin,
                                     RawContacts& out)
 {
     out.count = 0;
@@ -582,12 +592,16 @@ __device__ float hull_pair_contacts(const WBody& wa, const WBody& wb, const Hull
 
 // body vs table plane: four order-independent selections over all hull vertices in the band
 // (same rule as the oracle's plane_contacts)
-__device__ __forceinline__ float4 hull_vertex(const HullRef& h, const float4* __restrict__ hv, int i)
+__device__ __forceinline__ float4 hull_vertex(const HullRef& h, const f3* __restrict__ hv, int i)
 {
-    return h.lds >= 0 ? hv[h.lds + i] : h.g[i];
+    if (h.lds >= 0) {
+        const f3 q = hv[h.lds + i];
+        return make_float4(q.x, q.y, q.z, 1.0f);
+    }
+    return h.g[i];
 }
 
-__device__ void plane_contacts(const WBody& w, const HullRef* lh, const float4* __restrict__ hv, int lh_begin, int lh_end,
+__device__ void plane_contacts(const WBody& w, const HullRef* lh, const f3* __restrict__ hv, int lh_begin, int lh_end,
                                float plane_z, float margin, RawContacts& out)
 {
     out.count = 0;
@@ -659,11 +673,10 @@ __device__ __forceinline__ void fill_contact(Contact* c, int a, int b, const WBo
     k.ra = sub(pa, wa.x);
     k.rb = wbb ? sub(pb, wbb->x) : V(0, 0, 0);
     k.n = n;
-    tangents(n, &k.t1, &k.t2);
     k.err = sep - rest;
     k.kn = k.kt1 = k.kt2 = 0.0f;
     k.ln = k.lt1 = k.lt2 = 0.0f;
-    k.vn0 = 0.0f;
+    k.bounce = -3.0e38f;
     k.mu_s = mu_s; k.mu_d = mu_d; k.e = e;
     *c = k;
 }
@@ -705,18 +718,23 @@ __device__ __forceinline__ float eff_mass(const WBody& a, const WBody* b, v3 ra,
     return k > 0.0f ? 1.0f / k : 0.0f;
 }
 
-__device__ void prep_contact(Contact* cp, const WBody* wbs)
+__device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_threshold)
 {
     Contact c = *cp;
     const WBody& a = wbs[c.a];
     const WBody* b = c.b >= 0 ? &wbs[c.b] : nullptr;
+    v3 t1, t2;
+    tangents(c.n, &t1, &t2);
     c.kn = eff_mass(a, b, c.ra, c.rb, c.n);
-    c.kt1 = eff_mass(a, b, c.ra, c.rb, c.t1);
-    c.kt2 = eff_mass(a, b, c.ra, c.rb, c.t2);
+    c.kt1 = eff_mass(a, b, c.ra, c.rb, t1);
+    c.kt2 = eff_mass(a, b, c.ra, c.rb, t2);
     v3 rel = vel_at(a, c.ra);
     if (b) rel = sub(rel, vel_at(*b, c.rb));
-    c.vn0 = dot(rel, c.n);
-    cp->kn = c.kn; cp->kt1 = c.kt1; cp->kt2 = c.kt2; cp->vn0 = c.vn0;
+    const float vn0 = dot(rel, c.n);
+    // the oracle tests (vn0 < -threshold && e > 0) in every solve; fold it once
+    float bounce = -3.0e38f;
+    if (vn0 < -bounce_threshold && c.e > 0.0f) bounce = -c.e * vn0;
+    cp->kn = c.kn; cp->kt1 = c.kt1; cp->kt2 = c.kt2; cp->bounce = bounce;
 }
 
 __device__ __forceinline__ void apply_impulse(WBody& a, WBody* b, const Contact& c, v3 J)
@@ -745,10 +763,7 @@ __device__ void solve_contact(Contact* cp, WBody* wbs, const slhip_settle_params
     float target;
     if (err > 0.0f) target = -err * inv_dt;
     else target = biased ? -0.8f * err * inv_dt : 0.0f;
-    if (c.vn0 < -prm.bounce_threshold && c.e > 0.0f) {
-        const float bounce = -c.e * c.vn0;
-        if (bounce > target) target = bounce;
-    }
+    if (c.bounce > target) target = c.bounce;
     float dl = (target - vn) * c.kn;
     float ln = c.ln + dl;
     if (ln < 0.0f) ln = 0.0f;
@@ -757,8 +772,10 @@ __device__ void solve_contact(Contact* cp, WBody* wbs, const slhip_settle_params
     apply_impulse(a, b, c, scale(c.n, dl));
     rel = vel_at(a, c.ra);
     if (b) rel = sub(rel, vel_at(*b, c.rb));
-    float l1 = c.lt1 - dot(rel, c.t1) * c.kt1;
-    float l2 = c.lt2 - dot(rel, c.t2) * c.kt2;
+    v3 t1, t2;
+    tangents(c.n, &t1, &t2);
+    float l1 = c.lt1 - dot(rel, t1) * c.kt1;
+    float l2 = c.lt2 - dot(rel, t2) * c.kt2;
     const float mag2 = fmaf(l2, l2, l1 * l1);
     const float lim_s = c.mu_s * c.ln;
     if (mag2 > lim_s * lim_s) {
@@ -768,7 +785,7 @@ __device__ void solve_contact(Contact* cp, WBody* wbs, const slhip_settle_params
     }
     const float d1 = l1 - c.lt1, d2 = l2 - c.lt2;
     c.lt1 = l1; c.lt2 = l2;
-    apply_impulse(a, b, c, madd(scale(c.t1, d1), c.t2, d2));
+    apply_impulse(a, b, c, madd(scale(t1, d1), t2, d2));
     cp->ln = c.ln; cp->lt1 = c.lt1; cp->lt2 = c.lt2;
 }
 
@@ -916,7 +933,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int& total)
 // ---------------------------------------------------------------------------------------------
 struct LdsLayout {
     int nb_cap, lh_cap, hv_cap;   // bodies, local hulls, hull vertices (0 = vertices stay global)
-    int off_wb, off_lh, off_body_lh, off_hv, off_contacts, off_hp, off_hp_off, off_hp_sep, off_groups, off_misc;
+    int off_wb, off_lh, off_body_lh, off_hv, off_contacts, off_hp, off_hp_off, off_groups, off_misc;
     int total;
 };
 
@@ -932,15 +949,14 @@ __host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_
     L.off_wb = take(nb_cap * (int)sizeof(WBody));
     L.off_lh = take(lh_cap * (int)sizeof(HullRef));
     L.off_body_lh = take((nb_cap + 1) * 4);
-    L.off_hv = take(hv_cap * 16);
+    L.off_hv = take(hv_cap * 12);
     L.off_contacts = take(kMaxActive * (int)sizeof(Contact));
     L.off_hp = take(SLHIP_MAX_HULL_PAIRS * (int)sizeof(HpEntry));
     L.off_hp_off = take((SLHIP_MAX_HULL_PAIRS + 1) * 2);
-    L.off_hp_sep = take(SLHIP_MAX_HULL_PAIRS * 4);
     int g_cap = nb_cap + nb_cap * (nb_cap - 1) / 2;   // plane groups + body pairs
     if (g_cap > kMaxGroups) g_cap = kMaxGroups;
     L.off_groups = take(g_cap * (int)sizeof(Group));
-    L.off_misc = take(nb_cap * 8 + nb_cap * 4 + 64);
+    L.off_misc = take(nb_cap * 8 + nb_cap * 4 + nb_cap * 4 + 64);
     L.total = o;
     return L;
 }
@@ -954,15 +970,15 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
     WBody* wb = reinterpret_cast<WBody*>(smem + L.off_wb);
     HullRef* lh = reinterpret_cast<HullRef*>(smem + L.off_lh);
     int* body_lh = reinterpret_cast<int*>(smem + L.off_body_lh);
-    float4* hv = reinterpret_cast<float4*>(smem + L.off_hv);
+    f3* hv = reinterpret_cast<f3*>(smem + L.off_hv);
     Contact* ac = reinterpret_cast<Contact*>(smem + L.off_contacts);
     HpEntry* hp = reinterpret_cast<HpEntry*>(smem + L.off_hp);
     unsigned short* hp_off = reinterpret_cast<unsigned short*>(smem + L.off_hp_off);
-    float* hp_sep = reinterpret_cast<float*>(smem + L.off_hp_sep);
     Group* groups = reinterpret_cast<Group*>(smem + L.off_groups);
     unsigned long long* used = reinterpret_cast<unsigned long long*>(smem + L.off_misc);
     int* wake = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 8);
-    int* counters = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 12);  // [0]=n_groups [1]=n_colors
+    int* sep_key = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 12);   // min separation, ordered-int
+    int* counters = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 16);  // [0]=n_groups [1]=n_colors
 
     const slhip_settle_scene sc = scenes[blockIdx.x];
     slhip_body* bodies = bodies_all + sc.body_begin;
@@ -997,7 +1013,11 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                 }
                 if (in_lds) {
                     const float4* src = reinterpret_cast<const float4*>(hull_verts) + hulls[h].vtx_begin;
-                    for (int k = lane; k < cnt; k += 64) hv[n_hv + k] = src[k];
+                    for (int k = lane; k < cnt; k += 64) {
+                        const float4 q = src[k];
+                        f3 t; t.x = q.x; t.y = q.y; t.z = q.z;
+                        hv[n_hv + k] = t;
+                    }
                     n_hv += cnt;
                 }
                 ++n_lh;
@@ -1023,6 +1043,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     wb[i].w = scale(wb[i].w, damp);
                 }
                 wake[i] = 0;
+                sep_key[i] = 0x7f7fffff;  // ordered key of the largest finite float (>= kInf)
             }
             __syncthreads();
             PROF(0);
@@ -1158,7 +1179,11 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     const v3 dv = sub(wb[i].v, wb[j].v);
                     const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
                     smin = hull_pair_contacts(wb[i], wb[j], lh[e.la], lh[e.lb], hv, prm, margin, rc);
-                    hp_sep[k] = smin;
+                    // min over hull pairs is order independent: float -> monotone int key
+                    int key = __float_as_int(smin);
+                    key = key >= 0 ? key : key ^ 0x7fffffff;
+                    atomicMin(&sep_key[i], key);
+                    atomicMin(&sep_key[j], key);
                 }
                 int total;
                 const int off = n_active + wave_excl_scan(rc.count, total);
@@ -1187,10 +1212,10 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                 groups[g] = G;
             }
             for (int i = lane; i < nb; i += 64) {
-                float s = kInf;
-                for (int k = 0; k < n_hp; ++k)
-                    if (hp[k].ba == i || hp[k].bb == i) s = fminf(s, hp_sep[k]);
-                bodies[i].separation = s;
+                int key = sep_key[i];
+                key = key >= 0 ? key : key ^ 0x7fffffff;
+                const float sv = __int_as_float(key);
+                bodies[i].separation = sv > kInf ? kInf : sv;
             }
             __syncthreads();
             PROF(4);
@@ -1223,7 +1248,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             PROF(5);
 
             // (f) prep
-            for (int c = lane; c < n_active; c += 64) prep_contact(&ac[c], wb);
+            for (int c = lane; c < n_active; c += 64) prep_contact(&ac[c], wb, prm.bounce_threshold);
             PROF(6);
             // (g) greedy colouring in group order (serial by definition)
             if (lane == 0) {
@@ -1375,7 +1400,7 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
                     if (dot(dd, dd) > r2 * r2) continue;
                     v3 pa, pb;
                     float dist;
-                    if (gjk_distance(A, B, nullptr, dd, 0.0f, &pa, &pb, &dist) == 0) hit = true;
+                    if (gjk_distance(A, B, (const f3*)nullptr, dd, 0.0f, &pa, &pb, &dist) == 0) hit = true;
                 }
         }
         if (!hit && sc.has_plane) {
@@ -1424,10 +1449,10 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
     int lh_cap = params->max_hulls_per_scene ? (int)params->max_hulls_per_scene : 1024;
     int hv_cap = (int)params->max_hull_verts_per_scene;
     LdsLayout L = make_layout(nb_cap, lh_cap, hv_cap);
-    const int kLdsBudget = 53 * 1024;  // 3 scenes per CU (160 KiB LDS)
+    const int kLdsBudget = 40 * 1024;  // 4 scenes per CU (160 KiB LDS)
     if (L.total > kLdsBudget) {
         const int over = L.total - kLdsBudget;
-        hv_cap = hv_cap - (over + 15) / 16;
+        hv_cap = hv_cap - (over + 11) / 12;
         if (hv_cap < 0) hv_cap = 0;
         L = make_layout(nb_cap, lh_cap, hv_cap);
     }
