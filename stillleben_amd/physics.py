@@ -177,21 +177,30 @@ def is_object_colliding(scene, obj):
 
 
 def find_noncolliding_pose(scene, obj, sampler="random", max_iterations=10, **kwargs):
-    """scene.h:245-261: rejection-sample poses until the object does not collide."""
+    """scene.h:245-261 + python/src/py_scene.cpp:196-245: rejection-sample poses (set directly as
+    the object pose, like the reference) until the object does not collide."""
     if obj not in scene._objects:
         raise ValueError("object is not part of the scene")
     diameter = obj._mesh.bbox.np_diagonal()
+    pos = pose_sampling.RandomPositionSampler(scene._projection, diameter, kwargs.get("min_size_factor", 0.4))
     if sampler == "random":
-        pos = pose_sampling.RandomPositionSampler(scene._projection, diameter, kwargs.get("min_size_factor", 0.4))
-    elif sampler in ("viewpoint", "view_corrected"):
-        pos = pose_sampling.RandomPositionSampler(scene._projection, diameter, kwargs.get("min_size_factor", 0.4))
+        smp = pose_sampling.RandomPoseSampler(pos)
+    elif sampler == "viewpoint":
+        if "viewpoint" not in kwargs:
+            raise ValueError("sampler='viewpoint' needs viewpoint argument")
+        vp = kwargs["viewpoint"]
+        vp = vp.detach().cpu().numpy() if hasattr(vp, "detach") else np.asarray(vp)
+        smp = pose_sampling.ViewPointPoseSampler(pos, vp.astype(np.float32).reshape(3))
+    elif sampler == "view_corrected":
+        if "orientation" not in kwargs:
+            raise ValueError("sampler='view_corrected' needs orientation argument")
+        o = kwargs["orientation"]
+        o = o.detach().cpu().numpy() if hasattr(o, "detach") else np.asarray(o)
+        smp = pose_sampling.ViewCorrectedPoseSampler(pos, o.astype(np.float32))
     else:
         raise ValueError("unknown sampler '%s'" % sampler)
     for _ in range(int(max_iterations)):
-        q = pose_sampling.random_quaternion(scene._rng)
-        p = pos(scene._rng)
-        pose_in_cam = M.from_rt(M.quat_to_matrix(q), p)
-        obj._pose = (scene._camera_pose @ pose_in_cam).astype(np.float32)
+        obj._pose = smp(scene._rng)
         if not is_object_colliding(scene, obj):
             return True
     return False

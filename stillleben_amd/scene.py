@@ -101,9 +101,8 @@ class Scene:
     def place_object_randomly(self, diameter, min_size_factor=0.4):
         from . import pose_sampling
 
-        s = pose_sampling.RandomPositionSampler(self._projection, diameter, min_size_factor)
-        q = pose_sampling.random_quaternion(self._rng)
-        return torch.from_numpy(M.from_rt(M.quat_to_matrix(q), s(self._rng)))
+        s = pose_sampling.RandomPoseSampler(pose_sampling.RandomPositionSampler(self._projection, diameter, min_size_factor))
+        return torch.from_numpy(s(self._rng))
 
     # ---- objects ---------------------------------------------------------------------------
     @property

@@ -133,3 +133,40 @@ def test_gradient_sign_property(sl):
         positive += int(d[0][param] > 0)
         obj.set_pose(pose)
     assert positive >= 5   # the reference asserts > 0 for every parameter with its pyramid loss
+
+
+def test_c5_many_objects_linearity(sl):
+    # BASELINE config 5 scale (64 objects in one 640x480 view): the pose backward is linear in the
+    # image gradient and additive over hypotheses -- size-independent properties
+    cube = sl.Mesh(S.CUBE, physics=False)
+    cube.center_bbox()
+    cube.scale_to_bbox_diagonal(0.12)
+    scene = sl.Scene((640, 480))
+    scene.set_camera_intrinsics(1066.778, 1067.487, 312.9869, 241.3109)
+    rng = np.random.default_rng(5)
+    for i in range(64):
+        o = sl.Object(cube)
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, :3] = S.random_rotation(rng)
+        pose[:3, 3] = [((i % 8) - 3.5) * 0.11, ((i // 8) - 3.5) * 0.085, 1.6 + 0.3 * rng.uniform()]
+        o.set_pose(torch.from_numpy(pose))
+        scene.add_object(o)
+    scene.light_directions = torch.tensor([[0.1, 0.2, 0.9]])
+    scene.manual_exposure = 1.0
+    res = sl.RenderPass().render(scene)
+    assert len(torch.unique(res.instance_index())) >= 60
+    g1 = torch.from_numpy(pattern_grad(480, 640))
+    g2 = torch.from_numpy(np.random.default_rng(1).standard_normal((3, 480, 640)).astype(np.float32))
+    d1 = sl.diff.backpropagate_gradient_to_poses(scene, res, g1)
+    d2 = sl.diff.backpropagate_gradient_to_poses(scene, res, g2)
+    d12 = sl.diff.backpropagate_gradient_to_poses(scene, res, 2.0 * g1 - 0.5 * g2)
+    assert d1.shape == (64, 6)
+    scale = max(float(d1.abs().max()), float(d2.abs().max()))
+    assert float((d12 - (2.0 * d1 - 0.5 * d2)).abs().max()) <= 2e-5 * scale
+    # an object whose pixels receive zero gradient gets a zero pose gradient
+    inst = res.instance_index().squeeze(-1)
+    g0 = g2.clone()
+    near = torch.nn.functional.max_pool2d((inst == 1).float()[None, None], 5, 1, 2)[0, 0] > 0
+    g0[:, near] = 0.0
+    d0 = sl.diff.backpropagate_gradient_to_poses(scene, res, g0)
+    assert float(d0[0].abs().max()) == 0.0 and float(d0[1:].abs().max()) > 0.0

@@ -159,3 +159,41 @@ def test_public_api_roundtrip(sl, eng):
     assert res.barycentric_coeffs().shape == (480, 640, 3)
     assert res.cam_coordinates().shape == (480, 640, 4)
     assert res.normals().shape == (480, 640, 4)
+
+
+def test_c4_bunny_x50_raster_stress(sl, oracle, eng):
+    # BASELINE config 4: stanford bunny x50 (3.47 M triangles) on a seeded 5x10 grid at z in [1,3] m,
+    # 640x480, all 8 outputs, render only -- bit-exact against the oracle
+    m = sl.Mesh(S.BUNNY, physics=False)
+    m.center_bbox()
+    m.scale_to_bbox_diagonal(0.5)
+    scene = sl.Scene((640, 480))
+    rng = np.random.default_rng(4)
+    for i in range(50):
+        o = sl.Object(m)
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, :3] = S.random_rotation(rng)
+        gx, gy = i % 10, i // 10
+        z = 1.0 + 2.0 * (i / 49.0)
+        pose[:3, 3] = [(gx - 4.5) * 0.11 * z, (gy - 2.0) * 0.16 * z, z]
+        o.set_pose(torch.from_numpy(pose))
+        scene.add_object(o)
+    scene.light_directions = torch.tensor([[0.2, 0.5, 0.8]])
+    bufs, ref = both(eng, oracle, [scene], ssao=False, shadows=False)
+    assert len(np.unique(ref.instance)) == 51
+    assert_geometry_equal(bufs, ref)
+    assert_rgb_close(bufs, ref)
+
+
+def test_batch_equals_single_scene_renders(sl, eng):
+    # size-independent property for the batched path (BASELINE config 3): rendering B scenes in one
+    # launch sequence is identical to rendering each scene alone
+    scs = [S.clutter_scene(sl, 300 + i, n_objects=6, size=(320, 240), with_bunny=(i % 3 == 0)) for i in range(12)]
+    for s in scs:
+        s.manual_exposure = 1.0
+    batch = eng.render(scs, _abi.OUT_ALL, ssao=True, shadows=True)
+    torch.cuda.synchronize()
+    for i, s in enumerate(scs):
+        one = eng.render([s], _abi.OUT_ALL, ssao=True, shadows=True)
+        for name in ("rgb", "coord", "cls", "instance", "normals", "vertex_idx", "bary", "cam_coord"):
+            assert torch.equal(getattr(batch, name)[i], getattr(one, name)[0]), (name, i)

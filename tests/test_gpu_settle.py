@@ -172,3 +172,21 @@ def test_manipulation_sim_parity_and_api(sl, oracle):
     for _ in range(20):
         sim.step(goal, 0.005)
     assert float(tool.pose()[0, 3]) > x0
+
+
+def test_batch_settle_equals_single(sl, oracle):
+    # BASELINE config 3 property: a scene's result does not depend on what else is in the launch
+    from stillleben_amd import physics
+
+    cube = scaled(sl, S.CUBE, 0.15)
+    scs = [heap(sl, 500 + i, 6, cube) for i in range(32)]
+    se = physics.settle_engine()
+    planes = [(True, TABLE)] * len(scs)
+    srec, bodies = SB.build_settle_batch(scs, se.pool, planes)
+    prm = SB.default_params(frames=30)
+    all_ = se.run(srec, bodies.copy(), prm)
+    for i in (0, 13, 31):
+        s1, b1 = SB.build_settle_batch([scs[i]], se.pool, [planes[i]])
+        one = se.run(s1, b1.copy(), prm)
+        lo, hi = int(srec[i]["body_begin"]), int(srec[i]["body_end"])
+        assert_bodies_equal(all_[lo:hi], one)

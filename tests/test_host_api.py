@@ -135,3 +135,31 @@ def test_out_of_scope_shims_fail_loudly(sl):
     scene = sl.Scene((64, 48))
     with pytest.warns(UserWarning):
         sl.view(scene)
+
+
+def test_pose_samplers(sl):
+    # pose.h:56-218: sampled positions project inside 80 % of the frustum at a distance in
+    # [1.2 d, d / 0.4]; the viewpoint sampler turns the chosen object axis towards the camera
+    from stillleben_amd import pose_sampling as ps
+
+    scene = sl.Scene((640, 480))
+    P = scene.projection_matrix().numpy()
+    rng = np.random.default_rng(0)
+    d = ps.minimum_distance_for_object_diameter(0.3, P)
+    assert d == pytest.approx(max(P[0, 0], P[1, 1]) * 0.15)
+    pos = ps.RandomPositionSampler(P, 0.3)
+    for _ in range(50):
+        p = pos(rng)
+        assert 1.2 * d - 1e-5 <= p[2] <= d / 0.4 + 1e-5
+        assert abs(P[0, 0] * p[0] / p[2]) <= 0.8 + 1e-5 and abs(P[1, 1] * p[1] / p[2]) <= 0.8 + 1e-5
+    vp = ps.ViewPointPoseSampler(pos, (0.0, 0.0, 1.0))
+    for _ in range(10):
+        T = vp(rng)
+        R, t = T[:3, :3], T[:3, 3]
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-5)
+        assert np.allclose(R @ np.array([0, 0, 1.0]), -t / np.linalg.norm(t), atol=1e-5)
+    vc = ps.ViewCorrectedPoseSampler(pos, np.eye(3))
+    T = vc(rng)
+    # the corrected orientation maps the viewing ray back onto +z
+    assert np.allclose(T[:3, :3].T @ (T[:3, 3] / np.linalg.norm(T[:3, 3])), [0, 0, 1], atol=1e-5)
+    assert np.allclose(ps.rotation_correction_for_translation(np.array([0, 0, 2.0])), np.eye(3))
