@@ -74,14 +74,17 @@ typedef struct {
     float normal_to_world[12];   /* 3x3 row-major, rows padded to 4 floats */
     float base_color[4];
     float emissive[4];
-    float alpha_cutoff, metallic, roughness, _pad0;
-    uint32_t class_index, instance_index, flags, _pad1;
+    float alpha_cutoff, metallic, roughness;
+    uint32_t scene;              /* index of the owning scene in the batch            */
+    uint32_t class_index, instance_index, flags;
+    uint32_t n_verts;            /* vertices of the mesh this draw indexes into       */
     uint32_t vtx_base;           /* first vertex in the pool                          */
     uint32_t idx_base;           /* first index in the pool                           */
     uint32_t n_tris;
     uint32_t prim_base;          /* id of triangle 0 in the scene's draw order        */
     uint32_t tex_offset;         /* byte offset of the RGBA8 base-colour texture      */
-    uint32_t tex_w, tex_h, _pad2;
+    uint32_t tex_w, tex_h;
+    uint32_t clip_base;          /* first entry of this draw in the clip-position scratch */
 } slhip_draw;                    /* 272 bytes */
 
 /* Per-scene camera + lights (reference Scene::setCameraIntrinsics src/scene.cpp:222-253,
@@ -144,8 +147,12 @@ typedef struct {
     float*    d_shadow;       /* f32 [B,NUM_LIGHTS,S,S] shadow depth (only active lights)    */
     uint32_t* d_queue;        /* large-triangle work queue: [0]=count, then (prim,tile) pairs */
     float*    d_lum;          /* f32 [B,4] HDR sums for auto exposure                        */
+    float*    d_clip;         /* f32 [1 + NUM_LIGHTS][n_clip_verts][4]: clip positions written by the
+                                 MFMA vertex-transform kernel (plane 0: camera, 1..3: lights)  */
     uint32_t  queue_capacity; /* number of (prim,tile) pairs that fit                        */
     uint32_t  shadow_res;     /* S (reference: 2048, render_pass.cpp:271)                    */
+    uint32_t  n_clip_verts;   /* sum of n_verts over the draws of the batch                  */
+    uint32_t  _pad;
 } slhip_render_scratch;
 
 /* Renders a batch of scenes.  Replaces RenderPass::render (src/render_pass.cpp:303-796):
@@ -153,7 +160,7 @@ typedef struct {
  * previous result's objectCoordinates; NULL = none) implements `depthBufferResult`.         */
 int slhip_render(const slhip_mesh_pool* pool,
                  const slhip_scene* d_scenes, const slhip_draw* d_draws,
-                 const slhip_chunk* d_chunks, uint32_t n_scenes, uint32_t n_chunks,
+                 const slhip_chunk* d_chunks, uint32_t n_scenes, uint32_t n_draws, uint32_t n_chunks,
                  uint32_t width, uint32_t height, uint32_t flags,
                  const float* d_depth_peel,
                  const slhip_render_out* out, const slhip_render_scratch* scratch,

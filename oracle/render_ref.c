@@ -22,9 +22,11 @@
  * leaves implementation-defined (sub-pixel snapping, interpolation order, tie-breaks) are
  * FIXED here and are the contract the HIP path must reproduce bit-for-bit:
  *
- *   R1  every 4x4 * vec4 product is the k-ordered chain
+ *   R1  every 4x4 * vec4 (and 4x4 * 4x4) product is the k-ordered chain
  *          fma(m3,v3, fma(m2,v2, fma(m1,v1, fma(m0,v0, 0))))
  *       (bitwise what v_mfma_f32_16x16x4_f32 computes), compiled with -ffp-contract=off.
+ *       Clip positions use the composite matrix P (W2C (O2W M2O)) (one product per vertex);
+ *       the varyings object/world/camera coordinates follow the shader's sequential chain.
  *   R2  x_win = fma(x_ndc, W/2, W/2), y likewise, z_win = fma(z_ndc, .5, .5); ndc = clip/w
  *       with a correctly rounded division.
  *   R3  window x,y snapped to 1/256 px:  X = (int)floorf(fmaf(x_win, 256, 0.5)).
@@ -139,7 +141,16 @@ static void vertex_stage(const slhip_mesh_pool* pool, const slhip_scene* sc, con
     const float* n = pool->d_nrm + 4 * (size_t)v;
     mv3p(dr->normal_to_world, n, o->nrm);
     normalize3(o->nrm);
-    mv4(sc->proj, cam4, o->clip);
+    /* clip position: ONE product with the composite matrix MVP = P (W2C (O2W M2O)), each
+       matrix product being the same k-ordered chain -- the form the MFMA vertex kernel of the
+       product evaluates (v_mfma_f32_16x16x4_f32: 16 vertices x {camera, 3 light} clip rows) */
+    {
+        float T1[16], T2[16], MVP[16];
+        mm4(dr->object_to_world, dr->mesh_to_object, T1);
+        mm4(sc->world_to_cam, T1, T2);
+        mm4(sc->proj, T2, MVP);
+        mv4(MVP, pos, o->clip);
+    }
     o->uv[0] = pool->d_uv[2 * (size_t)v + 0];
     o->uv[1] = pool->d_uv[2 * (size_t)v + 1];
 }

@@ -57,11 +57,11 @@ DRAW_DTYPE = np.dtype(
         ("alpha_cutoff", np.float32),
         ("metallic", np.float32),
         ("roughness", np.float32),
-        ("_pad0", np.float32),
+        ("scene", np.uint32),
         ("class_index", np.uint32),
         ("instance_index", np.uint32),
         ("flags", np.uint32),
-        ("_pad1", np.uint32),
+        ("n_verts", np.uint32),
         ("vtx_base", np.uint32),
         ("idx_base", np.uint32),
         ("n_tris", np.uint32),
@@ -69,7 +69,7 @@ DRAW_DTYPE = np.dtype(
         ("tex_offset", np.uint32),
         ("tex_w", np.uint32),
         ("tex_h", np.uint32),
-        ("_pad2", np.uint32),
+        ("clip_base", np.uint32),
     ],
     align=False,
 )
@@ -119,8 +119,11 @@ class RenderScratch(C.Structure):
         ("d_shadow", C.c_void_p),
         ("d_queue", C.c_void_p),
         ("d_lum", C.c_void_p),
+        ("d_clip", C.c_void_p),
         ("queue_capacity", C.c_uint32),
         ("shadow_res", C.c_uint32),
+        ("n_clip_verts", C.c_uint32),
+        ("_pad", C.c_uint32),
     ]
 
 
@@ -152,7 +155,7 @@ def lib():
     L.slhip_device_init.argtypes = [C.c_int]
     L.slhip_render.argtypes = [
         C.POINTER(MeshPool), C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
         C.c_void_p, C.POINTER(RenderOut), C.POINTER(RenderScratch), C.c_void_p,
     ]
     L.slhip_render_scratch_bytes.argtypes = [

@@ -164,6 +164,7 @@ def build_batch(scenes, pool, predicate=None, with_shadows=True):
             d["metallic"], d["roughness"] = 0.04, 0.5
             d["flags"] = flags
             d["vtx_base"], d["idx_base"], d["n_tris"], d["prim_base"] = 0, 0, 2, prim
+            d["scene"], d["n_verts"] = si, 4
             prim += 2
             draws.append(d)
         for obj in objs:
@@ -197,6 +198,7 @@ def build_batch(scenes, pool, predicate=None, with_shadows=True):
                 d["idx_base"] = slot.idx_base + sm.first_index
                 d["n_tris"] = sm.n_indices // 3
                 d["prim_base"] = prim
+                d["scene"], d["n_verts"] = si, slot.n_vertices
                 prim += sm.n_indices // 3
                 draws.append(d)
         srec[si]["draw_end"] = len(draws)
@@ -206,5 +208,7 @@ def build_batch(scenes, pool, predicate=None, with_shadows=True):
             for first in range(0, nt, _abi.CHUNK_TRIS):
                 chunks.append((si, di, first, min(_abi.CHUNK_TRIS, nt - first)))
     drec = np.array(draws, dtype=_abi.DRAW_DTYPE) if draws else np.zeros(0, dtype=_abi.DRAW_DTYPE)
+    if len(drec):
+        drec["clip_base"] = np.concatenate([[0], np.cumsum(drec["n_verts"][:-1], dtype=np.uint64)]).astype(np.uint32)
     crec = np.array(chunks, dtype=_abi.CHUNK_DTYPE) if chunks else np.zeros(0, dtype=_abi.CHUNK_DTYPE)
     return srec, drec, crec

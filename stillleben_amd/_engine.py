@@ -128,10 +128,17 @@ class Engine:
             buffers = RenderBuffers(self.device, B, H, W, mask)
         out = buffers.abi()
         scratch, keep = self.scratch(B, H, W, want_rgb, ssao, shadows)
+        n_clip = int(drec["n_verts"].sum()) if len(drec) else 0
+        planes = 1 + (_abi.NUM_LIGHTS if shadows else 0)
+        need = max(16, n_clip * planes * 16)
+        if getattr(self, "_clip", None) is None or self._clip.numel() < need:
+            self._clip = torch.empty(need, dtype=torch.uint8, device=self.device)
+        scratch.d_clip = _ptr(self._clip)
+        scratch.n_clip_verts = n_clip
         flags = mask | (_abi.RENDER_SSAO if ssao else 0) | (_abi.RENDER_SHADOWS if shadows else 0)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
-            st = self.L.slhip_render(C.byref(pool), _ptr(d_s), _ptr(d_d), _ptr(d_c), B, len(crec), W, H, flags,
+            st = self.L.slhip_render(C.byref(pool), _ptr(d_s), _ptr(d_d), _ptr(d_c), B, len(drec), len(crec), W, H, flags,
                                      _ptr(depth_peel), C.byref(out), C.byref(scratch), C.c_void_p(stream))
         _abi.check(st, "slhip_render")
         # keep the record tensors alive until the stream has consumed them

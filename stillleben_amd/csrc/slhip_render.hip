@@ -278,10 +278,63 @@ __device__ __forceinline__ void vertex_full(const slhip_mesh_pool& pool, const s
     const float n[3] = {n4.x, n4.y, n4.z};
     mv3p(dr->normal_to_world, n, o.nrm);
     normalize3(o.nrm);
-    mv4(sc->proj, cam4, o.clip);
     const float2 uv = reinterpret_cast<const float2*>(pool.d_uv)[v];
     o.uv[0] = uv.x;
     o.uv[1] = uv.y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_vertex_xform: batched 4x4 vertex transforms on the matrix cores.
+//   D[16x16] = A[16x4] * B[4x16] with v_mfma_f32_16x16x4_f32 (exact fp32, bitwise a k-ordered
+//   fmaf chain):  A rows 0-3 = MVP = P (W2C (O2W M2O)), rows 4-7 / 8-11 / 12-15 = the light
+//   clip matrices S_l (O2W M2O) of the three lights; B column j = (x,y,z,1) of vertex j.
+//   One instruction transforms 16 vertices into camera clip space AND the three shadow clip
+//   spaces.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; it receives D[(l>>4)*4+r][l&15],
+//   i.e. lanes 0-15 hold the camera clip position of their vertex, lanes 16-31 light 0, ...
+//   and every lane stores one float4 (fully coalesced 256 B per plane).
+// ---------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_vertex_xform(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+                                                      const slhip_draw* __restrict__ draws, float4* __restrict__ clip,
+                                                      unsigned n_clip_verts, int with_lights)
+{
+    const slhip_draw* dr = draws + blockIdx.y;
+    const unsigned nv = dr->n_verts;
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((blockIdx.x * 4 + wave) * 64 >= nv) return;
+    const slhip_scene* sc = scenes + dr->scene;
+    // composite matrices (wave-uniform inputs; every lane evaluates the same chains)
+    float T1[16], T2[16], M[16];
+    mm4(dr->object_to_world, dr->mesh_to_object, T1);
+    const unsigned row = lane & 15, k = lane >> 4;
+    const unsigned grp = row >> 2;        // 0: camera, 1..3: light grp-1
+    float a = 0.0f;
+    if (grp == 0) {
+        mm4(sc->world_to_cam, T1, T2);
+        mm4(sc->proj, T2, M);
+        a = M[4 * (row & 3) + k];
+    } else if (with_lights) {
+        mm4(sc->shadow_mat[grp - 1], T1, M);
+        a = M[4 * (row & 3) + k];
+    }
+    const float* pos = pool.d_pos + 4 * (size_t)dr->vtx_base;
+    // 64 vertices per wave and pass = 4 MFMA batches; grid-stride over the draw's vertices
+    for (unsigned first = (blockIdx.x * 4 + wave) * 64; first < nv; first += gridDim.x * 256)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const unsigned v0 = first + 16 * b;
+        if (v0 >= nv) break;
+        const unsigned vj = min(v0 + (lane & 15), nv - 1);
+        // B[k][j]: component k of vertex j (w = 1): the wave reads 16 x 16 contiguous bytes
+        const float bval = k < 3 ? pos[4 * (size_t)vj + k] : 1.0f;
+        floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc, 0, 0, 0);
+        // lane holds rows (lane>>4)*4 + 0..3 of column lane&15 = the float4 of plane (lane>>4)
+        const unsigned plane = lane >> 4;
+        if (v0 + (lane & 15) < nv && (plane == 0 || with_lights))
+            clip[(size_t)plane * n_clip_verts + dr->clip_base + v0 + (lane & 15)] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -439,7 +492,7 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
                                                 const slhip_chunk* __restrict__ chunks, int W, int H,
                                                 const float* __restrict__ depth_peel,
                                                 unsigned long long* __restrict__ vis, unsigned* queue,
-                                                unsigned capacity)
+                                                unsigned capacity, const float4* __restrict__ clipbuf)
 {
     const slhip_chunk ch = chunks[blockIdx.x];
     if (threadIdx.x >= ch.count) return;
@@ -450,10 +503,15 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
     const unsigned vi[3] = {ip[0], ip[1], ip[2]};
 
     ClipVert cv[3];
-    float camz[3];
+    float camz[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        vertex_clip(pool, sc, dr, dr->vtx_base + vi[k], cv[k].clip, camz[k]);
+        const float4 c4 = clipbuf[dr->clip_base + vi[k]];   // written by k_vertex_xform (MFMA)
+        cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
+        if (depth_peel) {  // camera z of the vertex (shader chain) for the depth-peel test
+            float unused[4];
+            vertex_clip(pool, sc, dr, dr->vtx_base + vi[k], unused, camz[k]);
+        }
         cv[k].bary[0] = k == 0 ? 1.0f : 0.0f;
         cv[k].bary[1] = k == 1 ? 1.0f : 0.0f;
         cv[k].bary[2] = k == 2 ? 1.0f : 0.0f;
@@ -515,7 +573,8 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
 __global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                const slhip_draw* __restrict__ draws, int W, int H,
                                                unsigned long long* __restrict__ vis,
-                                               const unsigned* __restrict__ queue, unsigned capacity)
+                                               const unsigned* __restrict__ queue, unsigned capacity,
+                                               const float4* __restrict__ clipbuf)
 {
     const unsigned count = min(queue[0], capacity);
     const QItem* items = reinterpret_cast<const QItem*>(queue + 4);
@@ -531,12 +590,13 @@ __global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip
         const int sub = (int)(it.tri_sub >> 31);
         const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
         ClipVert cv[3];
-        float camz;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            vertex_clip(pool, sc, dr, dr->vtx_base + ip[k], cv[k].clip, camz);
+            const float4 c4 = clipbuf[dr->clip_base + ip[k]];
+            cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
             cv[k].bary[0] = cv[k].bary[1] = cv[k].bary[2] = 0.0f;
         }
+        (void)sc;
         ClipVert poly[4];
         const int n = clip_near(cv, poly);
         if (sub > n - 3) continue;
@@ -587,7 +647,8 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
                                                        const slhip_draw* __restrict__ draws,
                                                        const slhip_chunk* __restrict__ chunks, int S,
                                                        unsigned* __restrict__ shadow, unsigned* queue,
-                                                       unsigned capacity)
+                                                       unsigned capacity, const float4* __restrict__ clipbuf,
+                                                       unsigned n_clip_verts)
 {
     const slhip_chunk ch = chunks[blockIdx.x];
     const int light = blockIdx.y;
@@ -596,14 +657,15 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
     const slhip_draw* dr = draws + ch.draw;
     if (!(dr->flags & SLHIP_DRAW_CASTS_SHADOW)) return;
     if (!light_active(sc, light)) return;
-    float OM[16], T[16];
-    mm4(dr->object_to_world, dr->mesh_to_object, OM);
-    mm4(sc->shadow_mat[light], OM, T);
     const unsigned tri = ch.first_tri + threadIdx.x;
     const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
     float c[3][4];
+    const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) shadow_clip(pool, T, dr->vtx_base + ip[k], c[k]);
+    for (int k = 0; k < 3; ++k) {
+        const float4 c4 = plane[ip[k]];
+        c[k][0] = c4.x; c[k][1] = c4.y; c[k][2] = c4.z; c[k][3] = c4.w;
+    }
     Setup t;
     if (!setup_tri(c[0], c[1], c[2], S, S, t)) return;
     if (t.flipped) return;  // front face culled
@@ -616,7 +678,8 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
 __global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                       const slhip_draw* __restrict__ draws, int S,
                                                       unsigned* __restrict__ shadow,
-                                                      const unsigned* __restrict__ queue, unsigned capacity)
+                                                      const unsigned* __restrict__ queue, unsigned capacity,
+                                                      const float4* __restrict__ clipbuf, unsigned n_clip_verts)
 {
     const unsigned count = min(queue[0], capacity);
     const QItem* items = reinterpret_cast<const QItem*>(queue + 4);
@@ -628,16 +691,16 @@ __global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, cons
         if (it.draw == 0xFFFFFFFFu) continue;
         const unsigned scene = it.scene_aux & 0xFFFFFFu;
         const int light = (int)(it.scene_aux >> 24);
-        const slhip_scene* sc = scenes + scene;
         const slhip_draw* dr = draws + it.draw;
-        float OM[16], T[16];
-        mm4(dr->object_to_world, dr->mesh_to_object, OM);
-        mm4(sc->shadow_mat[light], OM, T);
         const unsigned tri = it.tri_sub;
         const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
         float c[3][4];
+        const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) shadow_clip(pool, T, dr->vtx_base + ip[k], c[k]);
+        for (int k = 0; k < 3; ++k) {
+            const float4 c4 = plane[ip[k]];
+            c[k][0] = c4.x; c[k][1] = c4.y; c[k][2] = c4.z; c[k][3] = c4.w;
+        }
         Setup t;
         if (!setup_tri(c[0], c[1], c[2], S, S, t)) continue;
         const int px = (int)((it.tile & 0xFFFFu) << 3) + (int)(lane & 7);
@@ -818,7 +881,8 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                                                const slhip_draw* __restrict__ draws, ShadeParams prm,
                                                const unsigned long long* __restrict__ vis,
                                                slhip_render_out out, float* __restrict__ hdr,
-                                               const float* __restrict__ shadow, float* __restrict__ lum_part)
+                                               const float* __restrict__ shadow, float* __restrict__ lum_part,
+                                               const float4* __restrict__ clipbuf)
 {
     const int W = prm.W, H = prm.H;
     const size_t P = (size_t)W * H;
@@ -852,8 +916,8 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 vertex_full(pool, sc, dr, dr->vtx_base + vi[k], vo[k]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) cv[k].clip[c] = vo[k].clip[c];
+                const float4 c4 = clipbuf[dr->clip_base + vi[k]];   // identical to what the raster used
+                cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
                 cv[k].bary[0] = k == 0 ? 1.0f : 0.0f;
                 cv[k].bary[1] = k == 1 ? 1.0f : 0.0f;
                 cv[k].bary[2] = k == 2 ? 1.0f : 0.0f;
@@ -1168,7 +1232,8 @@ extern "C" int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uin
 }
 
 extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_scenes, const slhip_draw* d_draws,
-                            const slhip_chunk* d_chunks, uint32_t n_scenes, uint32_t n_chunks, uint32_t width,
+                            const slhip_chunk* d_chunks, uint32_t n_scenes, uint32_t n_draws, uint32_t n_chunks,
+                            uint32_t width,
                             uint32_t height, uint32_t flags, const float* d_depth_peel,
                             const slhip_render_out* out, const slhip_render_scratch* scratch, void* stream_)
 {
@@ -1198,6 +1263,11 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
     const unsigned pix_blocks = blocks_per_scene * n_scenes;
     const int S = (int)scratch->shadow_res;
+    if (n_chunks > 0 && (!scratch->d_clip || scratch->n_clip_verts == 0)) {
+        slhip::set_error("slhip_render: d_clip scratch (n_clip_verts x 16 B x planes) is required");
+        return -1;
+    }
+    const float4* clipbuf = reinterpret_cast<const float4*>(scratch->d_clip);
 
     if (ssao) {
         int dev = 0;
@@ -1216,6 +1286,13 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
         if (fst != 0) return fst;
         for (int i = 0; i <= kNumPhases; ++i) g_ev_recorded[i] = false;
     }
+    // vertex transform on the matrix cores: camera clip + (if shadows) the three light clips
+    if (n_chunks > 0) {
+        k_vertex_xform<<<dim3(32, n_draws), 256, 0, stream>>>(*pool, d_scenes, d_draws,
+                                                                      reinterpret_cast<float4*>(scratch->d_clip),
+                                                                      scratch->n_clip_verts, shadows ? 1 : 0);
+        SLHIP_LAUNCH_CHECK();
+    }
     // shadow pass
     if (shadows && n_chunks > 0) {
         mark(0, stream);
@@ -1224,11 +1301,11 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
         SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
         k_shadow_raster<<<dim3(n_chunks, SLHIP_NUM_LIGHTS), 256, 0, stream>>>(
             *pool, d_scenes, d_draws, d_chunks, S, reinterpret_cast<unsigned*>(scratch->d_shadow),
-            scratch->d_queue, scratch->queue_capacity);
+            scratch->d_queue, scratch->queue_capacity, clipbuf, scratch->n_clip_verts);
         mark(1, stream);
         k_shadow_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, S,
                                                  reinterpret_cast<unsigned*>(scratch->d_shadow), scratch->d_queue,
-                                                 scratch->queue_capacity);
+                                                 scratch->queue_capacity, clipbuf, scratch->n_clip_verts);
         SLHIP_LAUNCH_CHECK();
     }
 
@@ -1239,11 +1316,11 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     if (n_chunks > 0) {
         k_raster<<<n_chunks, 256, 0, stream>>>(*pool, d_scenes, d_draws, d_chunks, W, H, d_depth_peel,
                                                reinterpret_cast<unsigned long long*>(scratch->d_vis),
-                                               scratch->d_queue, scratch->queue_capacity);
+                                               scratch->d_queue, scratch->queue_capacity, clipbuf);
         mark(3, stream);
         k_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, W, H,
                                           reinterpret_cast<unsigned long long*>(scratch->d_vis), scratch->d_queue,
-                                          scratch->queue_capacity);
+                                          scratch->queue_capacity, clipbuf);
         SLHIP_LAUNCH_CHECK();
     }
 
@@ -1259,7 +1336,7 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     mark(4, stream);
     k_shade<<<pix_blocks, 256, 0, stream>>>(*pool, d_scenes, d_draws, prm,
                                             reinterpret_cast<const unsigned long long*>(scratch->d_vis), *out, hdr0,
-                                            shadows ? scratch->d_shadow : nullptr, scratch->d_lum);
+                                            shadows ? scratch->d_shadow : nullptr, scratch->d_lum, clipbuf);
     SLHIP_LAUNCH_CHECK();
 
     if (want_rgb) {
