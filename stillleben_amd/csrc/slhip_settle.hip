@@ -508,12 +508,19 @@ __device__ float reduce_candidates(const Cand5& c, v3 nrm, RawContacts& out)
     return mins;
 }
 
-// hull pair -> up to 4 raw contacts; returns min separation (or +inf)
-__device__ float hull_pair_contacts(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
-                                    const f3* __restrict__ hv, const slhip_settle_params& prm, float margin,
-                                    RawContacts& out)
+// ---- narrowphase of one hull pair, split in three stages so that the four tilt runs of every
+// ---- contact pair can execute on separate lanes (same arithmetic as the oracle's
+// ---- hull_pair_contacts, which runs them one after the other)
+struct MainResult {       // stage 1: plain GJK
+    int type;             // 0 none, 1 contact pair (tilt runs follow), 2 overlap (single fallback contact)
+    v3 n, pa, pb;
+    float dist;           // distance (type 1) or fallback separation (type 2)
+};
+
+__device__ void pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
+                          const f3* __restrict__ hv, float margin, MainResult& r)
 {
-    out.count = 0;
+    r.type = 0;
     Shape A, B;
     make_shape(wa, ha, A);
     make_shape(wb, hb, B);
@@ -522,20 +529,31 @@ __device__ float hull_pair_contacts(const WBody& wa, const WBody& wb, const Hull
     v3 pa, pb, n;
     float dist;
     const int code = gjk_distance(A, B, hv, sub(ca, cb), margin, &pa, &pb, &dist);
-    if (code == 2) return kInf;
+    if (code == 2) return;
     if (code == 0) {
         float sep;
         overlap_fallback(A, B, hv, ca, cb, &n, &sep, &pa, &pb);
         if (sep > 0.0f) sep = 0.0f;
-        out.n = n; out.pa[0] = pa; out.pb[0] = pb; out.sep[0] = sep; out.count = 1;
-        return sep;
+        r.type = 2; r.n = n; r.pa = pa; r.pb = pb; r.dist = sep;
+        return;
     }
-    if (dist > margin) return kInf;
-    n = scale(sub(pa, pb), 1.0f / dist);
+    if (dist > margin) return;
+    r.type = 1;
+    r.n = scale(sub(pa, pb), 1.0f / dist);
+    r.pa = pa; r.pb = pb; r.dist = dist;
+}
 
-    Cand5 c;
-    c.p[0] = pa; c.q[0] = pb; c.s[0] = dist; c.ok[0] = true;
-
+// stage 2: tilt run k (0..3) of a contact pair -> candidate (qa, qb, sp); returns false if rejected
+// before the duplicate test
+__device__ bool pair_tilt(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
+                          const f3* __restrict__ hv, const slhip_settle_params& prm, float margin, v3 n, int k, v3* qa_out,
+                          v3* qb_out, float* sp_out)
+{
+    Shape A, B;
+    make_shape(wa, ha, A);
+    make_shape(wb, hb, B);
+    const v3 ca = add(m3_mul(wa.R, ha.sc), wa.t);
+    const v3 cb = add(m3_mul(wb.R, hb.sc), wb.t);
     const bool tilt_a = ha.sr <= hb.sr;
     const float radius = tilt_a ? ha.sr : hb.sr;
     float ang = 2.0f * prm.contact_offset / radius;
@@ -546,48 +564,54 @@ __device__ float hull_pair_contacts(const WBody& wa, const WBody& wb, const Hull
     v3 t1, t2;
     tangents(n, &t1, &t2);
     const WBody& wt = tilt_a ? wa : wb;
+    const v3 ax = (k == 0) ? t1 : (k == 1) ? t2 : (k == 2) ? neg(t1) : neg(t2);
+    quat dq; dq.x = ax.x * sh; dq.y = ax.y * sh; dq.z = ax.z * sh; dq.w = ch;
+    const quat q2 = quat_normalize(quat_mul(dq, wt.q));
+    Shape T = tilt_a ? A : B;
+    quat_to_m3(q2, T.R);
+    const v3 cl = tilt_a ? ha.sc : hb.sc;
+    v3 cw = tilt_a ? ca : cb;
+    cw = madd(cw, n, tilt_a ? lift : -lift);
+    T.t = sub(cw, m3_mul(T.R, cl));
+    v3 qa, qb;
+    float d2;
+    const int ok = tilt_a ? gjk_distance(T, B, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2)
+                          : gjk_distance(A, T, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2);
+    if (ok != 1) return false;
+    if (tilt_a) {
+        const v3 loc = m3_tmul(T.R, sub(qa, T.t));
+        qa = add(m3_mul(A.R, loc), A.t);
+    } else {
+        const v3 loc = m3_tmul(T.R, sub(qb, T.t));
+        qb = add(m3_mul(B.R, loc), B.t);
+    }
+    const float sp = dot(sub(qa, qb), n);
+    if (sp > margin) return false;
+    const v3 lat = sub(sub(qa, qb), scale(n, sp));
+    if (dot(lat, lat) > 4.0f * margin * margin) return false;
+    *qa_out = qa; *qb_out = qb; *sp_out = sp;
+    return true;
+}
+
+// stage 3: duplicate rejection in slot order + manifold reduction
+__device__ float pair_finish(const MainResult& m, Cand5& c, float radius, RawContacts& out)
+{
+    c.p[0] = m.pa; c.q[0] = m.pb; c.s[0] = m.dist; c.ok[0] = true;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        c.ok[k + 1] = false;
-        c.p[k + 1] = V(0, 0, 0); c.q[k + 1] = V(0, 0, 0); c.s[k + 1] = 0.0f;
-        const v3 ax = (k == 0) ? t1 : (k == 1) ? t2 : (k == 2) ? neg(t1) : neg(t2);
-        quat dq; dq.x = ax.x * sh; dq.y = ax.y * sh; dq.z = ax.z * sh; dq.w = ch;
-        const quat q2 = quat_normalize(quat_mul(dq, wt.q));
-        Shape T = tilt_a ? A : B;
-        quat_to_m3(q2, T.R);
-        const v3 cl = tilt_a ? ha.sc : hb.sc;
-        v3 cw = tilt_a ? ca : cb;
-        cw = madd(cw, n, tilt_a ? lift : -lift);
-        T.t = sub(cw, m3_mul(T.R, cl));
-        v3 qa, qb;
-        float d2;
-        const int ok = tilt_a ? gjk_distance(T, B, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2)
-                              : gjk_distance(A, T, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2);
-        if (ok != 1) continue;
-        if (tilt_a) {
-            const v3 loc = m3_tmul(T.R, sub(qa, T.t));
-            qa = add(m3_mul(A.R, loc), A.t);
-        } else {
-            const v3 loc = m3_tmul(T.R, sub(qb, T.t));
-            qb = add(m3_mul(B.R, loc), B.t);
-        }
-        const float sp = dot(sub(qa, qb), n);
-        if (sp > margin) continue;
-        const v3 lat = sub(sub(qa, qb), scale(n, sp));
-        if (dot(lat, lat) > 4.0f * margin * margin) continue;
+        if (!c.ok[k + 1]) continue;
         bool dup = false;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            if (j > k) continue;  // only earlier slots
+            if (j > k) continue;
             if (!c.ok[j]) continue;
-            const v3 dd = sub(c.p[j], qa);
+            const v3 dd = sub(c.p[j], c.p[k + 1]);
             if (dot(dd, dd) < 2.5e-3f * radius * radius) dup = true;
         }
-        if (dup) continue;
-        c.p[k + 1] = qa; c.q[k + 1] = qb; c.s[k + 1] = sp; c.ok[k + 1] = true;
+        if (dup) c.ok[k + 1] = false;
     }
-    out.n = n;
-    return reduce_candidates(c, n, out);
+    out.n = m.n;
+    return reduce_candidates(c, m.n, out);
 }
 
 // body vs table plane: four order-independent selections over all hull vertices in the band
@@ -933,11 +957,12 @@ __device__ __forceinline__ int wave_excl_scan(int v, int& total)
 // ---------------------------------------------------------------------------------------------
 struct LdsLayout {
     int nb_cap, lh_cap, hv_cap;   // bodies, local hulls, hull vertices (0 = vertices stay global)
-    int off_wb, off_lh, off_body_lh, off_hv, off_contacts, off_hp, off_hp_off, off_groups, off_misc;
+    int off_wb, off_lh, off_body_lh, off_hv, off_contacts, off_hp, off_hp_off, off_hp_cnt, off_cp, off_groups, off_misc;
     int total;
 };
 
 struct HpEntry { unsigned short ba, bb, la, lb; };
+struct CPair { unsigned short k, type; v3 n, pa, pb; float dist; };   // main GJK result of a contact pair
 struct Group { short a, b; short begin, end; int color; };
 
 __host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_cap)
@@ -953,6 +978,8 @@ __host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_
     L.off_contacts = take(kMaxActive * (int)sizeof(Contact));
     L.off_hp = take(SLHIP_MAX_HULL_PAIRS * (int)sizeof(HpEntry));
     L.off_hp_off = take((SLHIP_MAX_HULL_PAIRS + 1) * 2);
+    L.off_hp_cnt = take(SLHIP_MAX_HULL_PAIRS);
+    L.off_cp = take(64 * (int)sizeof(CPair));
     int g_cap = nb_cap + nb_cap * (nb_cap - 1) / 2;   // plane groups + body pairs
     if (g_cap > kMaxGroups) g_cap = kMaxGroups;
     L.off_groups = take(g_cap * (int)sizeof(Group));
@@ -974,6 +1001,8 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
     Contact* ac = reinterpret_cast<Contact*>(smem + L.off_contacts);
     HpEntry* hp = reinterpret_cast<HpEntry*>(smem + L.off_hp);
     unsigned short* hp_off = reinterpret_cast<unsigned short*>(smem + L.off_hp_off);
+    unsigned char* hp_cnt = reinterpret_cast<unsigned char*>(smem + L.off_hp_cnt);
+    CPair* cp = reinterpret_cast<CPair*>(smem + L.off_cp);
     Group* groups = reinterpret_cast<Group*>(smem + L.off_groups);
     unsigned long long* used = reinterpret_cast<unsigned long long*>(smem + L.off_misc);
     int* wake = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 8);
@@ -1089,6 +1118,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                 }
             }
             const int n_plane_groups = n_groups;
+            const int n_active_before_pairs = n_active;
             PROF(1);
 
             // (c) broadphase: body pairs in (i<j) order -> hull pairs, ballot-compacted in order
@@ -1166,42 +1196,115 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             PROF(2);
             PROF_COUNT(0, n_hp);
 
-            // (d) narrowphase: one lane per hull pair; contacts compacted into LDS in pair order
+            // (d) narrowphase in windows of 64 hull pairs:
+            //   d1  lane = hull pair: plain GJK (most pairs leave through the margin early-out);
+            //       contact pairs are compacted (in order) into the cpair list
+            //   d2  lane = (contact pair, tilt run): the four tilted GJK runs of 16 pairs per pass
+            //   d3  the tilt-0 lane of every pair gathers the candidates with shuffles, rejects
+            //       duplicates, reduces the manifold and appends the contacts in pair order
+            for (int k = lane; k < n_hp; k += 64) hp_cnt[k] = 0;
+            __syncthreads();
             for (int base = 0; base < n_hp; base += 64) {
                 const int k = base + lane;
-                RawContacts rc;
-                rc.count = 0;
-                float smin = kInf;
-                int i = 0, j = 0;
+                MainResult mr;
+                mr.type = 0;
                 if (k < n_hp) {
                     const HpEntry e = hp[k];
-                    i = e.ba; j = e.bb;
-                    const v3 dv = sub(wb[i].v, wb[j].v);
+                    const v3 dv = sub(wb[e.ba].v, wb[e.bb].v);
                     const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
-                    smin = hull_pair_contacts(wb[i], wb[j], lh[e.la], lh[e.lb], hv, prm, margin, rc);
-                    // min over hull pairs is order independent: float -> monotone int key
-                    int key = __float_as_int(smin);
-                    key = key >= 0 ? key : key ^ 0x7fffffff;
-                    atomicMin(&sep_key[i], key);
-                    atomicMin(&sep_key[j], key);
+                    pair_main(wb[e.ba], wb[e.bb], lh[e.la], lh[e.lb], hv, margin, mr);
                 }
-                int total;
-                const int off = n_active + wave_excl_scan(rc.count, total);
-                if (k < n_hp) {
-                    hp_off[k] = (unsigned short)min(off, kMaxActive);
-                    const float rest = 2.0f * prm.rest_offset;
-                    const float mu_s = 0.5f * (bodies[i].mu_s + bodies[j].mu_s);
-                    const float mu_d = 0.5f * (bodies[i].mu_d + bodies[j].mu_d);
-                    const float e = 0.5f * (bodies[i].restitution + bodies[j].restitution);
+                const int slot = compact_slot(mr.type != 0, 0);
+                const int ncp = __popcll(__ballot(mr.type != 0));
+                if (mr.type != 0) {
+                    CPair cpd;
+                    cpd.k = (unsigned short)k; cpd.type = (unsigned short)mr.type;
+                    cpd.n = mr.n; cpd.pa = mr.pa; cpd.pb = mr.pb; cpd.dist = mr.dist;
+                    cp[slot] = cpd;
+                }
+                __syncthreads();
+                for (int ib = 0; ib < 4 * ncp; ib += 64) {
+                    const int item = ib + lane;
+                    const int m = item >> 2, t = item & 3;
+                    bool have = false;
+                    v3 qa = V(0, 0, 0), qb = V(0, 0, 0);
+                    float sp = 0.0f;
+                    CPair cpd;
+                    cpd.type = 0; cpd.k = 0;
+                    int bi = 0, bj = 0;
+                    float margin = 0.0f, radius = 1.0f;
+                    if (m < ncp) {
+                        cpd = cp[m];
+                        const HpEntry e = hp[cpd.k];
+                        bi = e.ba; bj = e.bb;
+                        const v3 dv = sub(wb[bi].v, wb[bj].v);
+                        margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
+                        const HullRef& ha = lh[e.la];
+                        const HullRef& hb = lh[e.lb];
+                        radius = ha.sr <= hb.sr ? ha.sr : hb.sr;
+                        if (cpd.type == 1) have = pair_tilt(wb[bi], wb[bj], ha, hb, hv, prm, margin, cpd.n, t, &qa, &qb, &sp);
+                    }
+                    // gather the four candidates of a pair into its tilt-0 lane
+                    Cand5 c;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (c < rc.count && off + c < kMaxActive)
-                            fill_contact(&ac[off + c], i, j, wb[i], &wb[j], rc.pa[c], rc.pb[c], rc.n, rc.sep[c], rest, mu_s,
-                                         mu_d, e);
+                    for (int q = 0; q < 4; ++q) {
+                        const int src = (lane & ~3) + q;
+                        c.p[q + 1] = V(__shfl(qa.x, src, 64), __shfl(qa.y, src, 64), __shfl(qa.z, src, 64));
+                        c.q[q + 1] = V(__shfl(qb.x, src, 64), __shfl(qb.y, src, 64), __shfl(qb.z, src, 64));
+                        c.s[q + 1] = __shfl(sp, src, 64);
+                        c.ok[q + 1] = __shfl(have ? 1 : 0, src, 64) != 0;
+                    }
+                    RawContacts rc;
+                    rc.count = 0;
+                    if (m < ncp && t == 0) {
+                        MainResult mm;
+                        mm.type = cpd.type; mm.n = cpd.n; mm.pa = cpd.pa; mm.pb = cpd.pb; mm.dist = cpd.dist;
+                        float smin;
+                        if (cpd.type == 2) {
+                            rc.n = cpd.n; rc.pa[0] = cpd.pa; rc.pb[0] = cpd.pb; rc.sep[0] = cpd.dist; rc.count = 1;
+                            smin = cpd.dist;
+                        } else {
+                            smin = pair_finish(mm, c, radius, rc);
+                        }
+                        int key = __float_as_int(smin);
+                        key = key >= 0 ? key : key ^ 0x7fffffff;
+                        atomicMin(&sep_key[bi], key);
+                        atomicMin(&sep_key[bj], key);
+                    }
+                    int total;
+                    const int off = n_active + wave_excl_scan(rc.count, total);
+                    if (rc.count > 0) {
+                        const float rest = 2.0f * prm.rest_offset;
+                        const float mu_s = 0.5f * (bodies[bi].mu_s + bodies[bj].mu_s);
+                        const float mu_d = 0.5f * (bodies[bi].mu_d + bodies[bj].mu_d);
+                        const float e = 0.5f * (bodies[bi].restitution + bodies[bj].restitution);
+                        int written = 0;
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc)
+                            if (cc < rc.count && off + cc < kMaxActive) {
+                                fill_contact(&ac[off + cc], bi, bj, wb[bi], &wb[bj], rc.pa[cc], rc.pb[cc], rc.n, rc.sep[cc], rest,
+                                             mu_s, mu_d, e);
+                                ++written;
+                            }
+                        hp_cnt[cpd.k] = (unsigned char)written;
+                    }
+                    n_active = min(n_active + total, kMaxActive);
                 }
-                n_active = min(n_active + total, kMaxActive);
+                __syncthreads();
             }
-            if (lane == 0) hp_off[n_hp] = (unsigned short)n_active;
+            // contact offsets per hull pair (exclusive prefix of the counts)
+            {
+                int run = n_active_before_pairs;
+                for (int base = 0; base < n_hp; base += 64) {
+                    const int k = base + lane;
+                    const int cnt = k < n_hp ? (int)hp_cnt[k] : 0;
+                    int total;
+                    const int off = run + wave_excl_scan(cnt, total);
+                    if (k < n_hp) hp_off[k] = (unsigned short)off;
+                    run += total;
+                }
+                if (lane == 0) hp_off[n_hp] = (unsigned short)run;
+            }
             __syncthreads();
             PROF(3);
             // pair groups: hull-pair range -> contact range; min separation per body
