@@ -813,6 +813,82 @@ __device__ void solve_contact(Contact* cp, WBody* wbs, const slhip_settle_params
     cp->ln = c.ln; cp->lt1 = c.lt1; cp->lt2 = c.lt2;
 }
 
+// Gauss-Seidel sweep over the contacts of ONE group (all share the same two bodies): the bodies'
+// velocities, inverse inertia and masses are held in registers for the whole group and written
+// back once, which removes an LDS round trip per contact.  Arithmetic and order are exactly
+// those of solve_contact applied to the group's contacts in sequence.
+struct BodyRegs {
+    v3 v, w;
+    m3 Iinv;
+    float inv_mass;
+    bool dynamic;
+};
+
+__device__ __forceinline__ void load_regs(const WBody& b, BodyRegs& r)
+{
+    r.v = b.v; r.w = b.w; r.Iinv = b.Iinv_w; r.inv_mass = b.inv_mass; r.dynamic = b.dynamic != 0;
+}
+
+__device__ __forceinline__ v3 vel_at_r(const BodyRegs& b, v3 r) { return add(b.v, cross(b.w, r)); }
+
+__device__ __forceinline__ void apply_regs(BodyRegs& a, BodyRegs& b, bool has_b, v3 ra, v3 rb, v3 J)
+{
+    if (a.dynamic) {
+        a.v = madd(a.v, J, a.inv_mass);
+        a.w = add(a.w, m3_mul(a.Iinv, cross(ra, J)));
+    }
+    if (has_b && b.dynamic) {
+        b.v = madd(b.v, J, -b.inv_mass);
+        b.w = sub(b.w, m3_mul(b.Iinv, cross(rb, J)));
+    }
+}
+
+__device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, WBody* wbs, float inv_dt, bool biased)
+{
+    if (begin >= end) return;
+    BodyRegs A, B;
+    load_regs(wbs[ia], A);
+    const bool has_b = ib >= 0;
+    if (has_b) load_regs(wbs[ib], B);
+    else { B.v = V(0, 0, 0); B.w = V(0, 0, 0); B.inv_mass = 0.0f; B.dynamic = false; }
+    if (!A.dynamic && !B.dynamic) return;  // the oracle invalidates such contacts in prep
+    for (int ci = begin; ci < end; ++ci) {
+        Contact c = ac[ci];
+        v3 rel = vel_at_r(A, c.ra);
+        if (has_b) rel = sub(rel, vel_at_r(B, c.rb));
+        const float vn = dot(rel, c.n);
+        const float err = c.err;
+        float target;
+        if (err > 0.0f) target = -err * inv_dt;
+        else target = biased ? -0.8f * err * inv_dt : 0.0f;
+        if (c.bounce > target) target = c.bounce;
+        float dl = (target - vn) * c.kn;
+        float ln = c.ln + dl;
+        if (ln < 0.0f) ln = 0.0f;
+        dl = ln - c.ln;
+        c.ln = ln;
+        apply_regs(A, B, has_b, c.ra, c.rb, scale(c.n, dl));
+        rel = vel_at_r(A, c.ra);
+        if (has_b) rel = sub(rel, vel_at_r(B, c.rb));
+        v3 t1, t2;
+        tangents(c.n, &t1, &t2);
+        float l1 = c.lt1 - dot(rel, t1) * c.kt1;
+        float l2 = c.lt2 - dot(rel, t2) * c.kt2;
+        const float mag2 = fmaf(l2, l2, l1 * l1);
+        const float lim_s = c.mu_s * c.ln;
+        if (mag2 > lim_s * lim_s) {
+            const float mag = sqrtf(mag2);
+            const float k = (c.mu_d * c.ln) / mag;
+            l1 *= k; l2 *= k;
+        }
+        const float d1 = l1 - c.lt1, d2 = l2 - c.lt2;
+        apply_regs(A, B, has_b, c.ra, c.rb, madd(scale(t1, d1), t2, d2));
+        ac[ci].ln = c.ln; ac[ci].lt1 = l1; ac[ci].lt2 = l2;
+    }
+    if (A.dynamic) { wbs[ia].v = A.v; wbs[ia].w = A.w; }
+    if (has_b && B.dynamic) { wbs[ib].v = B.v; wbs[ib].w = B.w; }
+}
+
 // D6 joint drive of ManipulationSim (same arithmetic as the oracle's solve_drive)
 __device__ void solve_drive(const slhip_body& b, WBody& w, const slhip_settle_params& prm, bool biased)
 {
@@ -1376,12 +1452,13 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             PROF_COUNT(2, n_groups); PROF_COUNT(3, ncol); PROF_COUNT(1, n_active);
 
             // (h) position iterations
+            const float inv_dt = 1.0f / prm.dt;
             for (unsigned it = 0; it < prm.pos_iters; ++it) {
                 for (int col = 0; col < ncol; ++col) {
                     for (int g = lane; g < n_groups; g += 64) {
                         const Group G = groups[g];
                         if (G.color != col) continue;
-                        for (int c = G.begin; c < G.end; ++c) solve_contact(&ac[c], wb, prm, true);
+                        solve_group(ac, G.begin, G.end, G.a, G.b, wb, inv_dt, true);
                     }
                     __syncthreads();
                 }
@@ -1416,7 +1493,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     for (int g = lane; g < n_groups; g += 64) {
                         const Group G = groups[g];
                         if (G.color != col) continue;
-                        for (int c = G.begin; c < G.end; ++c) solve_contact(&ac[c], wb, prm, false);
+                        solve_group(ac, G.begin, G.end, G.a, G.b, wb, inv_dt, false);
                     }
                     __syncthreads();
                 }
