@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                                                const unsigned long long* __restrict__ vis,
                                                slhip_render_out out, float* __restrict__ hdr,
                                                const float* __restrict__ shadow, float* __restrict__ lum_part,
-                                               const float4* __restrict__ clipbuf)
+                                               const float4* __restrict__ clipbuf, float* __restrict__ zplane)
 {
     const int W = prm.W, H = prm.H;
     const size_t P = (size_t)W * H;
@@ -983,6 +983,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
         if (out.d_vertex_idx) reinterpret_cast<uint4*>(out.d_vertex_idx)[gp] = make_uint4(vidx[0], vidx[1], vidx[2], vidx[3]);
         if (out.d_bary) reinterpret_cast<float4*>(out.d_bary)[gp] = make_float4(bary[0], bary[1], bary[2], bary[3]);
         if (out.d_cam_coord) reinterpret_cast<float4*>(out.d_cam_coord)[gp] = make_float4(camc[0], camc[1], camc[2], camc[3]);
+        if (zplane) zplane[gp] = camc[2];
         if (prm.inline_tonemap) {
             if (out.d_rgb) reinterpret_cast<uchar4*>(out.d_rgb)[gp] = tone_map_px(color, sc->manual_exposure, 0.0f);
         } else if (hdr) {
@@ -1020,15 +1021,17 @@ __device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, 
     int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
     x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
     y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
-    const float a = img[4 * ((size_t)y0 * W + x0) + 2], b = img[4 * ((size_t)y0 * W + x1) + 2];
-    const float c = img[4 * ((size_t)y1 * W + x0) + 2], d = img[4 * ((size_t)y1 * W + x1) + 2];
+    // `img` is the compact camera-z plane written by k_shade (same values as channel 2 of the
+    // camCoordinates target, 4 B/px instead of 16 B/px: the 64-tap gather stays L2 resident)
+    const float a = img[(size_t)y0 * W + x0], b = img[(size_t)y0 * W + x1];
+    const float c = img[(size_t)y1 * W + x0], d = img[(size_t)y1 * W + x1];
     const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - c, c);
     return fmaf(ay, bot - top, top);
 }
 
 __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ scenes, int W, int H,
                                               const float* __restrict__ cam, const float* __restrict__ nrm,
-                                              float* __restrict__ ao)
+                                              const float* __restrict__ zplane, float* __restrict__ ao)
 {
     const size_t P = (size_t)W * H;
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
@@ -1036,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
     const unsigned pix = (blockIdx.x % blocks_per_scene) * 256 + threadIdx.x;
     if (pix >= P) return;
     const float* proj = scenes[scene].proj;
-    const float* camS = cam + 4 * (size_t)scene * P;
+    const float* camS = zplane + (size_t)scene * P;
     const size_t gp = (size_t)scene * P + pix;
     const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
     const float4 n4 = reinterpret_cast<const float4*>(nrm)[gp];
@@ -1073,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
 }
 
 __global__ __launch_bounds__(256) void k_ssao_apply(int W, int H, const float* __restrict__ hdr_in,
-                                                    const float* __restrict__ ao, const float* __restrict__ cam,
+                                                    const float* __restrict__ ao, const float* __restrict__ zplane,
                                                     float* __restrict__ hdr_out)
 {
     const size_t P = (size_t)W * H;
@@ -1081,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_ssao_apply(int W, int H, const float* _
     const unsigned scene = blockIdx.x / blocks_per_scene;
     const unsigned pix = (blockIdx.x % blocks_per_scene) * 256 + threadIdx.x;
     if (pix >= P) return;
-    const float* camS = cam + 4 * (size_t)scene * P;
+    const float* camS = zplane + (size_t)scene * P;
     const float* aoS = ao + (size_t)scene * P;
     const size_t gp = (size_t)scene * P + pix;
     const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
@@ -1147,10 +1150,16 @@ __global__ __launch_bounds__(256) void k_tonemap(const slhip_scene* __restrict__
     reinterpret_cast<uchar4*>(rgb)[gp] = tone_map_px(c, manual, (manual >= 0.0f) ? 0.0f : s_lum);
 }
 
-__global__ void k_fill_u32(unsigned* p, unsigned v, size_t n)
+// clears the shadow maps of the ACTIVE lights only (blockIdx.y = scene * NUM_LIGHTS + light)
+__global__ __launch_bounds__(256) void k_clear_shadow(const slhip_scene* __restrict__ scenes, unsigned* __restrict__ shadow,
+                                                      int S)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+    const unsigned scene = blockIdx.y / SLHIP_NUM_LIGHTS, light = blockIdx.y % SLHIP_NUM_LIGHTS;
+    if (!light_active(scenes + scene, (int)light)) return;
+    uint4* p = reinterpret_cast<uint4*>(shadow + (size_t)blockIdx.y * S * S);
+    const size_t n4 = (size_t)S * S / 4;
+    const uint4 v = make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 
 bool g_ssao_tables_uploaded[16] = {};
@@ -1224,7 +1233,7 @@ extern "C" int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uin
     const uint64_t blocks = (P + 255) / 256;
     bytes_out[0] = B * P * 8;                                              // d_vis
     bytes_out[1] = 2 * B * P * 16;                                         // d_hdr (two planes)
-    bytes_out[2] = B * P * 4;                                              // d_ao
+    bytes_out[2] = 2 * B * P * 4;                                          // d_ao + camera-z plane
     bytes_out[3] = B * SLHIP_NUM_LIGHTS * (uint64_t)shadow_res * shadow_res * 4;  // d_shadow
     bytes_out[4] = 16 + (uint64_t)queue_capacity * 16;                     // d_queue
     bytes_out[5] = B * blocks * 16;                                        // d_lum
@@ -1296,8 +1305,8 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     // shadow pass
     if (shadows && n_chunks > 0) {
         mark(0, stream);
-        const size_t n = (size_t)n_scenes * SLHIP_NUM_LIGHTS * S * S;
-        k_fill_u32<<<2048, 256, 0, stream>>>(reinterpret_cast<unsigned*>(scratch->d_shadow), 0x3F800000u, n);
+        k_clear_shadow<<<dim3(64, n_scenes * SLHIP_NUM_LIGHTS), 256, 0, stream>>>(
+            d_scenes, reinterpret_cast<unsigned*>(scratch->d_shadow), S);
         SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
         k_shadow_raster<<<dim3(n_chunks, SLHIP_NUM_LIGHTS), 256, 0, stream>>>(
             *pool, d_scenes, d_draws, d_chunks, S, reinterpret_cast<unsigned*>(scratch->d_shadow),
@@ -1336,16 +1345,18 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     mark(4, stream);
     k_shade<<<pix_blocks, 256, 0, stream>>>(*pool, d_scenes, d_draws, prm,
                                             reinterpret_cast<const unsigned long long*>(scratch->d_vis), *out, hdr0,
-                                            shadows ? scratch->d_shadow : nullptr, scratch->d_lum, clipbuf);
+                                            shadows ? scratch->d_shadow : nullptr, scratch->d_lum, clipbuf,
+                                            ssao ? scratch->d_ao + (size_t)n_scenes * P : nullptr);
     SLHIP_LAUNCH_CHECK();
 
     if (want_rgb) {
         const float* tm_in = hdr0;
         if (ssao) {
             mark(5, stream);
-            k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, W, H, out->d_cam_coord, out->d_normals, scratch->d_ao);
+            const float* zpl = scratch->d_ao + (size_t)n_scenes * P;   // second half of d_ao
+            k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, W, H, out->d_cam_coord, out->d_normals, zpl, scratch->d_ao);
             mark(6, stream);
-            k_ssao_apply<<<pix_blocks, 256, 0, stream>>>(W, H, hdr0, scratch->d_ao, out->d_cam_coord, hdr1);
+            k_ssao_apply<<<pix_blocks, 256, 0, stream>>>(W, H, hdr0, scratch->d_ao, zpl, hdr1);
             tm_in = hdr1;
         }
         mark(7, stream);
