@@ -392,8 +392,10 @@ struct MainTarget {
         if (!(z >= 0.0f && z <= 1.0f)) return;
         const unsigned long long key = ((unsigned long long)depth24(z) << 32) | prim;
         unsigned long long* slot = vis + (size_t)py * W + px;
-        // cheap monotone pre-test: keys only ever decrease, a stale read is conservative
-        if (__builtin_nontemporal_load(slot) <= key) return;
+        // monotone pre-test only where the (rare, expensive) discard tests follow: keys only ever
+        // decrease, so a stale read is conservative.  The plain path fires the atomic without
+        // waiting on a read (a memory round trip per fragment costs more than a lost atomic).
+        if (need_attr && __builtin_nontemporal_load(slot) <= key) return;
         if (need_attr) {
             const float pw0 = l[0] * t.invw[0], pw1 = l[1] * t.invw[1], pw2 = l[2] * t.invw[2];
             const float sw = (pw0 + pw1) + pw2;
@@ -427,7 +429,8 @@ struct ShadowTarget {
         if (!(z >= 0.0f && z <= 1.0f)) return;
         unsigned* slot = sm + (size_t)py * W + px;
         const unsigned bits = __float_as_uint(z);  // z >= 0: uint order == float order
-        if (__builtin_nontemporal_load(slot) <= bits) return;
+        // fire-and-forget: front faces are culled, so almost every fragment wins anyway; a
+        // pre-read would only serialise the loop on a memory round trip
         atomicMin(slot, bits);
     }
 };
