@@ -106,21 +106,24 @@ __device__ __forceinline__ quat quat_mul(quat a, quat b)
 struct WBody {
     v3 x; quat q; m3 R; v3 t; v3 v, w; m3 Iinv_w;
     float inv_mass; int dynamic;
-    float dl[3], da[3];   // accumulated drive impulses
+    float mu_s, mu_d;     // friction of the body (combined per group in the solver)
 };
 
+// accumulated drive impulses of ManipulationSim bodies (global scratch: only driven bodies touch it)
+struct DriveAcc { float dl[3], da[3]; };
+
 // solver contact, compacted in LDS (plane contacts first, then hull-pair contacts in pair order).
-// 80 bytes: the tangent basis is a pure function of n and is recomputed in the solver, the
-// restitution target is folded into `bounce` (-inf = none).
+// 68 bytes: the bodies and the friction coefficients come from the contact's group, the tangent
+// basis is a pure function of n and is recomputed in the solver, the restitution target is folded
+// into `bounce` (-inf = none).  Between fill_contact and prep_contact the fields ln / lt1 / bounce
+// carry the body indices (as integer bits) and the restitution.
 struct Contact {
-    short a, b;
     v3 ra, rb, n;
     float err;            // sep - rest
     float kn, kt1, kt2, ln, lt1, lt2;
     float bounce;         // required rebound velocity (-e * vn0) or a large negative number
-    float mu_s, mu_d;
-    float e;              // restitution (consumed by prep)
 };
+static_assert(sizeof(Contact) == 68, "Contact layout");
 
 // raw narrowphase result of one hull pair / one body-vs-plane test (registers)
 struct RawContacts {
@@ -408,17 +411,17 @@ __device__ void overlap_fallback(const Shape& A, const Shape& B, const f3* __res
 // hull description resolved for this scene: vertices either in LDS (copied once per settle) or
 // in the global pool
 struct HullRef {
-    const float4* g;
-    int lds;
+    int src;        // >= 0: first vertex (float4 index) in the global pool; < 0: ~src = first vertex of the LDS copy
     int count;
     v3 sc;          // bounding sphere centre (object frame)
     float sr;
 };
+static_assert(sizeof(HullRef) == 24, "HullRef layout");
 
-__device__ __forceinline__ void make_shape(const WBody& wb, const HullRef& h, Shape& s)
+__device__ __forceinline__ void make_shape(const WBody& wb, const HullRef& h, const float4* __restrict__ gv, Shape& s)
 {
-    s.g = h.g;
-    s.lds = h.lds;
+    s.g = gv + (h.src >= 0 ? h.src : 0);
+    s.lds = h.src >= 0 ? -1 : ~h.src;
     s.count = h.count;
     s.R = wb.R;
     s.t = wb.t;
@@ -518,12 +521,12 @@ struct MainResult {       // stage 1: plain GJK
 };
 
 __device__ void pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
-                          const f3* __restrict__ hv, float margin, MainResult& r)
+                          const f3* __restrict__ hv, const float4* __restrict__ gv, float margin, MainResult& r)
 {
     r.type = 0;
     Shape A, B;
-    make_shape(wa, ha, A);
-    make_shape(wb, hb, B);
+    make_shape(wa, ha, gv, A);
+    make_shape(wb, hb, gv, B);
     const v3 ca = add(m3_mul(wa.R, ha.sc), wa.t);
     const v3 cb = add(m3_mul(wb.R, hb.sc), wb.t);
     v3 pa, pb, n;
@@ -546,12 +549,12 @@ __device__ void pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, c
 // stage 2: tilt run k (0..3) of a contact pair -> candidate (qa, qb, sp); returns false if rejected
 // before the duplicate test
 __device__ bool pair_tilt(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
-                          const f3* __restrict__ hv, const slhip_settle_params& prm, float margin, v3 n, int k, v3* qa_out,
+                          const f3* __restrict__ hv, const float4* __restrict__ gv, const slhip_settle_params& prm, float margin, v3 n, int k, v3* qa_out,
                           v3* qb_out, float* sp_out)
 {
     Shape A, B;
-    make_shape(wa, ha, A);
-    make_shape(wb, hb, B);
+    make_shape(wa, ha, gv, A);
+    make_shape(wb, hb, gv, B);
     const v3 ca = add(m3_mul(wa.R, ha.sc), wa.t);
     const v3 cb = add(m3_mul(wb.R, hb.sc), wb.t);
     const bool tilt_a = ha.sr <= hb.sr;
@@ -615,47 +618,110 @@ __device__ float pair_finish(const MainResult& m, Cand5& c, float radius, RawCon
 }
 
 // body vs table plane: four order-independent selections over all hull vertices in the band
-// (same rule as the oracle's plane_contacts)
-__device__ __forceinline__ float4 hull_vertex(const HullRef& h, const f3* __restrict__ hv, int i)
+// (same rule as the oracle's plane_contacts, oracle/settle_ref.c)
+__device__ __forceinline__ float4 hull_vertex(const HullRef& h, const f3* __restrict__ hv, const float4* __restrict__ gv, int i)
 {
-    if (h.lds >= 0) {
-        const f3 q = hv[h.lds + i];
+    if (h.src < 0) {
+        const f3 q = hv[~h.src + i];
         return make_float4(q.x, q.y, q.z, 1.0f);
     }
-    return h.g[i];
+    return gv[h.src + i];
 }
 
-__device__ void plane_contacts(const WBody& w, const HullRef* lh, const f3* __restrict__ hv, int lh_begin, int lh_end,
-                               float plane_z, float margin, RawContacts& out)
+// ---- cooperative variant: one 16-lane sub-group per body (four bodies per wave round) ----------
+// Every arg-min/arg-max is taken over (value, band ordinal)
+// with the lower ordinal winning ties, which is exactly what the serial strict compares pick.
+struct BandPt { v3 p; float d; };
+constexpr int kBandCap = 32;   // in-band vertices cached per body; beyond that the passes re-walk the hulls
+
+__device__ __forceinline__ void sg16_argmin(float& val, int& idx)
 {
-    out.count = 0;
-    out.n = V(0, 0, 1);
-    bool have0 = false; v3 p0 = V(0, 0, 0); float s0 = 0.0f;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        const float ov = __shfl_xor(val, m, 64);
+        const int oi = __shfl_xor(idx, m, 64);
+        if (ov < val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+    }
+}
+
+// broadcast the winning lane's point within the 16-lane sub-group
+__device__ __forceinline__ void sg16_fetch(bool mine, int sg, v3& p, float& d)
+{
+    const unsigned om = (unsigned)(__ballot(mine) >> (16 * sg)) & 0xffffu;
+    const int owner = 16 * sg + (om ? __ffs(om) - 1 : 0);
+    p.x = __shfl(p.x, owner, 64); p.y = __shfl(p.y, owner, 64); p.z = __shfl(p.z, owner, 64);
+    d = __shfl(d, owner, 64);
+}
+
+// f(p, d, ordinal) for every in-band vertex of the body, ordinals in hull/vertex order
+template <class F>
+__device__ __forceinline__ int sg16_walk_band(const WBody& w, const HullRef* lh, const f3* __restrict__ hv,
+                                              const float4* __restrict__ gv, int lh_begin,
+                                              int lh_end, float plane_z, float margin, int sg, int sl, F&& f)
+{
+    int ord = 0;
     for (int h = lh_begin; h < lh_end; ++h) {
         const HullRef H = lh[h];
-#pragma unroll 4
-        for (int i = 0; i < H.count; ++i) {
-            const float4 q = hull_vertex(H, hv, i);
-            const v3 p = add(m3_mul(w.R, V(q.x, q.y, q.z)), w.t);
-            const float d = p.z - plane_z;
-            if (!(d <= margin)) continue;
-            if (!have0 || d < s0) { have0 = true; p0 = p; s0 = d; }
+        for (int i0 = 0; i0 < H.count; i0 += 16) {
+            const int i = i0 + sl;
+            bool in = false;
+            v3 p = V(0, 0, 0);
+            float d = 0.0f;
+            if (i < H.count) {
+                const float4 q = hull_vertex(H, hv, gv, i);
+                p = add(m3_mul(w.R, V(q.x, q.y, q.z)), w.t);
+                d = p.z - plane_z;
+                in = d <= margin;
+            }
+            const unsigned sm = (unsigned)(__ballot(in) >> (16 * sg)) & 0xffffu;
+            if (in) f(p, d, ord + (int)__popc(sm & ((1u << sl) - 1u)));
+            ord += (int)__popc(sm);
         }
     }
-    if (!have0) return;
-    bool have1 = false; v3 p1 = V(0, 0, 0); float s1 = 0.0f, best = 0.0f;
-    for (int h = lh_begin; h < lh_end; ++h) {
-        const HullRef H = lh[h];
-#pragma unroll 4
-        for (int i = 0; i < H.count; ++i) {
-            const float4 q = hull_vertex(H, hv, i);
-            const v3 p = add(m3_mul(w.R, V(q.x, q.y, q.z)), w.t);
-            const float d = p.z - plane_z;
-            if (!(d <= margin)) continue;
-            const v3 dd = sub(p, p0);
-            const float score = sqrtf(dot(dd, dd)) - kDepthWeight * (d - s0);
-            if (score > 0.0f && (!have1 || score > best)) { have1 = true; best = score; p1 = p; s1 = d; }
-        }
+    return ord;
+}
+
+__device__ void plane_contacts_sg16(const WBody& w, const HullRef* lh, const f3* __restrict__ hv,
+                                    const float4* __restrict__ gv, int lh_begin, int lh_end,
+                                    float plane_z, float margin, BandPt* band, int sg, int sl, RawContacts& out)
+{
+    constexpr int kNone = 0x7fffffff;
+    out.count = 0;
+    out.n = V(0, 0, 1);
+    // pass 0: deepest in-band vertex; the band is cached in LDS on the way
+    float bv = kInf; int bi = kNone; v3 bp = V(0, 0, 0);
+    const int band_n = sg16_walk_band(w, lh, hv, gv, lh_begin, lh_end, plane_z, margin, sg, sl,
+                                      [&](v3 p, float d, int ord) {
+                                          if (d < bv || bi == kNone) { bv = d; bi = ord; bp = p; }
+                                          if (ord < kBandCap) { BandPt b; b.p = p; b.d = d; band[ord] = b; }
+                                      });
+    if (band_n == 0) return;
+    const bool cached = band_n <= kBandCap;
+    float s0; v3 p0;
+    {
+        float v = bi == kNone ? kInf : bv; int idx = bi;
+        sg16_argmin(v, idx);
+        s0 = bv; p0 = bp;
+        sg16_fetch(bi == idx, sg, p0, s0);
+    }
+    // pass 1: farthest from p0, deep points preferred
+    float b1 = kInf; int i1 = kNone; v3 p1 = V(0, 0, 0); float s1 = 0.0f;
+    auto f1 = [&](v3 p, float d, int ord) {
+        const v3 dd = sub(p, p0);
+        const float score = sqrtf(dot(dd, dd)) - kDepthWeight * (d - s0);
+        if (score > 0.0f && (i1 == kNone || -score < b1)) { b1 = -score; i1 = ord; p1 = p; s1 = d; }
+    };
+    if (cached) {
+        for (int k = sl; k < band_n; k += 16) { const BandPt b = band[k]; f1(b.p, b.d, k); }
+    } else {
+        sg16_walk_band(w, lh, hv, gv, lh_begin, lh_end, plane_z, margin, sg, sl, f1);
+    }
+    bool have1;
+    {
+        float v = b1; int idx = i1;
+        sg16_argmin(v, idx);
+        have1 = idx != kNone;
+        sg16_fetch(have1 && i1 == idx, sg, p1, s1);
     }
     int nk = 1;
     out.pa[0] = p0; out.sep[0] = s0;
@@ -663,21 +729,26 @@ __device__ void plane_contacts(const WBody& w, const HullRef* lh, const f3* __re
         out.pa[1] = p1; out.sep[1] = s1; nk = 2;
         const v3 e = sub(p1, p0);
         const float el = sqrtf(dot(e, e));
-        bool have2 = false, have3 = false; v3 p2 = V(0, 0, 0), p3 = V(0, 0, 0); float s2 = 0, s3 = 0, mx = 0.0f, mn = 0.0f;
-        for (int h = lh_begin; h < lh_end; ++h) {
-            const HullRef H = lh[h];
-#pragma unroll 4
-            for (int i = 0; i < H.count; ++i) {
-                const float4 q = hull_vertex(H, hv, i);
-                const v3 p = add(m3_mul(w.R, V(q.x, q.y, q.z)), w.t);
-                const float d = p.z - plane_z;
-                if (!(d <= margin)) continue;
-                const float a = dot(cross(e, sub(p, p0)), out.n);
-                const float pen = kDepthWeight * (d - s0) * el;
-                if (a - pen > mx) { mx = a - pen; have2 = true; p2 = p; s2 = d; }
-                if (a + pen < mn) { mn = a + pen; have3 = true; p3 = p; s3 = d; }
-            }
+        float b2 = kInf, b3 = kInf; int i2 = kNone, i3 = kNone;
+        v3 p2 = V(0, 0, 0), p3 = V(0, 0, 0); float s2 = 0.0f, s3 = 0.0f;
+        auto f2 = [&](v3 p, float d, int ord) {
+            const float a = dot(cross(e, sub(p, p0)), out.n);
+            const float pen = kDepthWeight * (d - s0) * el;
+            const float hi = a - pen, lo = a + pen;
+            if (hi > 0.0f && (i2 == kNone || -hi < b2)) { b2 = -hi; i2 = ord; p2 = p; s2 = d; }
+            if (lo < 0.0f && (i3 == kNone || lo < b3)) { b3 = lo; i3 = ord; p3 = p; s3 = d; }
+        };
+        if (cached) {
+            for (int k = sl; k < band_n; k += 16) { const BandPt b = band[k]; f2(b.p, b.d, k); }
+        } else {
+            sg16_walk_band(w, lh, hv, gv, lh_begin, lh_end, plane_z, margin, sg, sl, f2);
         }
+        float v2 = b2, v3_ = b3; int x2 = i2, x3 = i3;
+        sg16_argmin(v2, x2);
+        sg16_argmin(v3_, x3);
+        const bool have2 = x2 != kNone, have3 = x3 != kNone;
+        sg16_fetch(have2 && i2 == x2, sg, p2, s2);
+        sg16_fetch(have3 && i3 == x3, sg, p3, s3);
         if (have2) { out.pa[2] = p2; out.sep[2] = s2; nk = 3; }
         if (have3) {
             if (have2) { out.pa[3] = p3; out.sep[3] = s3; nk = 4; }
@@ -690,18 +761,17 @@ __device__ void plane_contacts(const WBody& w, const HullRef* lh, const f3* __re
 }
 
 __device__ __forceinline__ void fill_contact(Contact* c, int a, int b, const WBody& wa, const WBody* wbb, v3 pa, v3 pb,
-                                             v3 n, float sep, float rest, float mu_s, float mu_d, float e)
+                                             v3 n, float sep, float rest, float e)
 {
     Contact k;
-    k.a = (short)a; k.b = (short)b;
     k.ra = sub(pa, wa.x);
     k.rb = wbb ? sub(pb, wbb->x) : V(0, 0, 0);
     k.n = n;
     k.err = sep - rest;
     k.kn = k.kt1 = k.kt2 = 0.0f;
-    k.ln = k.lt1 = k.lt2 = 0.0f;
-    k.bounce = -3.0e38f;
-    k.mu_s = mu_s; k.mu_d = mu_d; k.e = e;
+    k.ln = __int_as_float(a); k.lt1 = __int_as_float(b);   // consumed (and zeroed) by prep_contact
+    k.lt2 = 0.0f;
+    k.bounce = e;                                          // restitution until prep_contact
     *c = k;
 }
 
@@ -745,8 +815,10 @@ __device__ __forceinline__ float eff_mass(const WBody& a, const WBody* b, v3 ra,
 __device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_threshold)
 {
     Contact c = *cp;
-    const WBody& a = wbs[c.a];
-    const WBody* b = c.b >= 0 ? &wbs[c.b] : nullptr;
+    const int ia = __float_as_int(c.ln), ib = __float_as_int(c.lt1);
+    const float e = c.bounce;
+    const WBody& a = wbs[ia];
+    const WBody* b = ib >= 0 ? &wbs[ib] : nullptr;
     v3 t1, t2;
     tangents(c.n, &t1, &t2);
     c.kn = eff_mass(a, b, c.ra, c.rb, c.n);
@@ -757,66 +829,15 @@ __device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_thresho
     const float vn0 = dot(rel, c.n);
     // the oracle tests (vn0 < -threshold && e > 0) in every solve; fold it once
     float bounce = -3.0e38f;
-    if (vn0 < -bounce_threshold && c.e > 0.0f) bounce = -c.e * vn0;
+    if (vn0 < -bounce_threshold && e > 0.0f) bounce = -e * vn0;
     cp->kn = c.kn; cp->kt1 = c.kt1; cp->kt2 = c.kt2; cp->bounce = bounce;
-}
-
-__device__ __forceinline__ void apply_impulse(WBody& a, WBody* b, const Contact& c, v3 J)
-{
-    if (a.dynamic) {
-        a.v = madd(a.v, J, a.inv_mass);
-        a.w = add(a.w, m3_mul(a.Iinv_w, cross(c.ra, J)));
-    }
-    if (b && b->dynamic) {
-        b->v = madd(b->v, J, -b->inv_mass);
-        b->w = sub(b->w, m3_mul(b->Iinv_w, cross(c.rb, J)));
-    }
-}
-
-__device__ void solve_contact(Contact* cp, WBody* wbs, const slhip_settle_params& prm, bool biased)
-{
-    Contact c = *cp;
-    WBody& a = wbs[c.a];
-    WBody* b = c.b >= 0 ? &wbs[c.b] : nullptr;
-    if (!a.dynamic && !(b && b->dynamic)) return;  // the oracle invalidates such contacts in prep
-    const float inv_dt = 1.0f / prm.dt;
-    v3 rel = vel_at(a, c.ra);
-    if (b) rel = sub(rel, vel_at(*b, c.rb));
-    const float vn = dot(rel, c.n);
-    const float err = c.err;
-    float target;
-    if (err > 0.0f) target = -err * inv_dt;
-    else target = biased ? -0.8f * err * inv_dt : 0.0f;
-    if (c.bounce > target) target = c.bounce;
-    float dl = (target - vn) * c.kn;
-    float ln = c.ln + dl;
-    if (ln < 0.0f) ln = 0.0f;
-    dl = ln - c.ln;
-    c.ln = ln;
-    apply_impulse(a, b, c, scale(c.n, dl));
-    rel = vel_at(a, c.ra);
-    if (b) rel = sub(rel, vel_at(*b, c.rb));
-    v3 t1, t2;
-    tangents(c.n, &t1, &t2);
-    float l1 = c.lt1 - dot(rel, t1) * c.kt1;
-    float l2 = c.lt2 - dot(rel, t2) * c.kt2;
-    const float mag2 = fmaf(l2, l2, l1 * l1);
-    const float lim_s = c.mu_s * c.ln;
-    if (mag2 > lim_s * lim_s) {
-        const float mag = sqrtf(mag2);
-        const float k = (c.mu_d * c.ln) / mag;
-        l1 *= k; l2 *= k;
-    }
-    const float d1 = l1 - c.lt1, d2 = l2 - c.lt2;
-    c.lt1 = l1; c.lt2 = l2;
-    apply_impulse(a, b, c, madd(scale(t1, d1), t2, d2));
-    cp->ln = c.ln; cp->lt1 = c.lt1; cp->lt2 = c.lt2;
+    cp->ln = 0.0f; cp->lt1 = 0.0f;
 }
 
 // Gauss-Seidel sweep over the contacts of ONE group (all share the same two bodies): the bodies'
 // velocities, inverse inertia and masses are held in registers for the whole group and written
 // back once, which removes an LDS round trip per contact.  Arithmetic and order are exactly
-// those of solve_contact applied to the group's contacts in sequence.
+// those of the oracle's solve_contact applied to the group's contacts in sequence.
 struct BodyRegs {
     v3 v, w;
     m3 Iinv;
@@ -843,7 +864,8 @@ __device__ __forceinline__ void apply_regs(BodyRegs& a, BodyRegs& b, bool has_b,
     }
 }
 
-__device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, WBody* wbs, float inv_dt, bool biased)
+__device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, WBody* wbs, float inv_dt, bool biased,
+                            float plane_mu_s, float plane_mu_d)
 {
     if (begin >= end) return;
     BodyRegs A, B;
@@ -852,6 +874,8 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, WBo
     if (has_b) load_regs(wbs[ib], B);
     else { B.v = V(0, 0, 0); B.w = V(0, 0, 0); B.inv_mass = 0.0f; B.dynamic = false; }
     if (!A.dynamic && !B.dynamic) return;  // the oracle invalidates such contacts in prep
+    const float mu_s = 0.5f * (wbs[ia].mu_s + (has_b ? wbs[ib].mu_s : plane_mu_s));
+    const float mu_d = 0.5f * (wbs[ia].mu_d + (has_b ? wbs[ib].mu_d : plane_mu_d));
     for (int ci = begin; ci < end; ++ci) {
         Contact c = ac[ci];
         v3 rel = vel_at_r(A, c.ra);
@@ -875,10 +899,10 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, WBo
         float l1 = c.lt1 - dot(rel, t1) * c.kt1;
         float l2 = c.lt2 - dot(rel, t2) * c.kt2;
         const float mag2 = fmaf(l2, l2, l1 * l1);
-        const float lim_s = c.mu_s * c.ln;
+        const float lim_s = mu_s * c.ln;
         if (mag2 > lim_s * lim_s) {
             const float mag = sqrtf(mag2);
-            const float k = (c.mu_d * c.ln) / mag;
+            const float k = (mu_d * c.ln) / mag;
             l1 *= k; l2 *= k;
         }
         const float d1 = l1 - c.lt1, d2 = l2 - c.lt2;
@@ -890,7 +914,7 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, WBo
 }
 
 // D6 joint drive of ManipulationSim (same arithmetic as the oracle's solve_drive)
-__device__ void solve_drive(const slhip_body& b, WBody& w, const slhip_settle_params& prm, bool biased)
+__device__ void solve_drive(const slhip_body& b, WBody& w, DriveAcc& acc, const slhip_settle_params& prm, bool biased)
 {
     if (!(b.drive_flags & 1u) || !w.dynamic) return;
     const float dt = prm.dt;
@@ -911,12 +935,12 @@ __device__ void solve_drive(const slhip_body& b, WBody& w, const slhip_settle_pa
         const float meff = 1.0f / (K + gamma);
         const float u = dot(vel_at(w, r), ax);
         const float C = dot(err, ax);
-        float dlam = -meff * (u + (beta / dt) * C + gamma * w.dl[a]);
-        float lam = w.dl[a] + dlam;
+        float dlam = -meff * (u + (beta / dt) * C + gamma * acc.dl[a]);
+        float lam = acc.dl[a] + dlam;
         if (lam > flim) lam = flim;
         if (lam < -flim) lam = -flim;
-        dlam = lam - w.dl[a];
-        w.dl[a] = lam;
+        dlam = lam - acc.dl[a];
+        acc.dl[a] = lam;
         const v3 Jimp = scale(ax, dlam);
         w.v = madd(w.v, Jimp, w.inv_mass);
         w.w = add(w.w, m3_mul(w.Iinv_w, cross(r, Jimp)));
@@ -933,7 +957,7 @@ __device__ void solve_drive(const slhip_body& b, WBody& w, const slhip_settle_pa
         if (!(K > 0.0f)) continue;
         const float bias = biased ? 0.8f * dot(theta, ax) / dt : 0.0f;
         const float dlam = -(dot(w.w, ax) + bias) / K;
-        w.da[a] += dlam;
+        acc.da[a] += dlam;
         w.w = add(w.w, m3_mul(w.Iinv_w, scale(ax, dlam)));
     }
 }
@@ -950,8 +974,7 @@ __device__ void load_body(const slhip_body& b, WBody& w)
     w.w = V(b.ang_vel[0], b.ang_vel[1], b.ang_vel[2]);
     w.inv_mass = b.inv_mass;
     w.dynamic = (!(b.flags & (SLHIP_BODY_STATIC | SLHIP_BODY_ASLEEP)) && b.inv_mass > 0.0f) ? 1 : 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { w.dl[k] = 0.0f; w.da[k] = 0.0f; }
+    w.mu_s = b.mu_s; w.mu_d = b.mu_d;
 }
 
 __device__ void update_world_inertia(const slhip_body& b, WBody& w)
@@ -1033,13 +1056,29 @@ __device__ __forceinline__ int wave_excl_scan(int v, int& total)
 // ---------------------------------------------------------------------------------------------
 struct LdsLayout {
     int nb_cap, lh_cap, hv_cap;   // bodies, local hulls, hull vertices (0 = vertices stay global)
-    int off_wb, off_lh, off_body_lh, off_hv, off_contacts, off_hp, off_hp_off, off_hp_cnt, off_cp, off_groups, off_misc;
+    int off_wb, off_lh, off_body_lh, off_hv, off_contacts, off_hp, off_hp_off, off_groups, off_misc;
     int total;
 };
 
-struct HpEntry { unsigned short ba, bb, la, lb; };
-struct CPair { unsigned short k, type; v3 n, pa, pb; float dist; };   // main GJK result of a contact pair
-struct Group { short a, b; short begin, end; int color; };
+// candidate hull pair, 32 bits: body a [0,6) | body b [6,12) | hull of a [12,22) | hull of b [22,32)
+// (hull numbers are local to their body: at most 1024 hulls per body)
+constexpr int kMaxHullsPerBody = 1024;
+__device__ __forceinline__ unsigned hp_pack(int ba, int bb, int ha, int hb)
+{
+    return (unsigned)ba | ((unsigned)bb << 6) | ((unsigned)ha << 12) | ((unsigned)hb << 22);
+}
+__device__ __forceinline__ int hp_ba(unsigned e) { return (int)(e & 63u); }
+__device__ __forceinline__ int hp_bb(unsigned e) { return (int)((e >> 6) & 63u); }
+__device__ __forceinline__ int hp_ha(unsigned e) { return (int)((e >> 12) & 1023u); }
+__device__ __forceinline__ int hp_hb(unsigned e) { return (int)(e >> 22); }
+
+// solver group = all contacts between one body pair (b = 0xff: body a against the plane);
+// [begin, end) is its range in the contact list (<= 160, fits a byte)
+struct Group { unsigned char a, b, begin, end, color; };
+constexpr int kNoBody = 0xff;
+static_assert(sizeof(Group) == 5, "Group layout");
+static_assert(SLHIP_MAX_ACTIVE_CONTACTS < 256 && SLHIP_MAX_BODIES <= 64, "byte-sized group fields");
+static_assert(SLHIP_MAX_HULL_PAIRS * 4 >= 4 * kBandCap * (int)sizeof(BandPt), "the plane phase's band cache aliases the hull-pair list");
 
 __host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_cap)
 {
@@ -1050,24 +1089,22 @@ __host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_
     L.off_wb = take(nb_cap * (int)sizeof(WBody));
     L.off_lh = take(lh_cap * (int)sizeof(HullRef));
     L.off_body_lh = take((nb_cap + 1) * 4);
-    L.off_hv = take(hv_cap * 12);
     L.off_contacts = take(kMaxActive * (int)sizeof(Contact));
-    L.off_hp = take(SLHIP_MAX_HULL_PAIRS * (int)sizeof(HpEntry));
-    L.off_hp_off = take((SLHIP_MAX_HULL_PAIRS + 1) * 2);
-    L.off_hp_cnt = take(SLHIP_MAX_HULL_PAIRS);
-    L.off_cp = take(64 * (int)sizeof(CPair));
+    L.off_hp = take(SLHIP_MAX_HULL_PAIRS * 4);
+    L.off_hp_off = take(SLHIP_MAX_HULL_PAIRS + 1);
     int g_cap = nb_cap + nb_cap * (nb_cap - 1) / 2;   // plane groups + body pairs
     if (g_cap > kMaxGroups) g_cap = kMaxGroups;
     L.off_groups = take(g_cap * (int)sizeof(Group));
-    L.off_misc = take(nb_cap * 8 + nb_cap * 4 + nb_cap * 4 + 64);
+    L.off_misc = take(nb_cap * 8 + nb_cap * 4 + nb_cap * 4 + 64 + 64 + 64);
+    L.off_hv = take(hv_cap * 12);
     L.total = o;
     return L;
 }
 
-__global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restrict__ scenes, slhip_body* bodies_all,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_settle(const slhip_settle_scene* __restrict__ scenes, slhip_body* bodies_all,
                                                const slhip_hull* __restrict__ hulls,
                                                const float* __restrict__ hull_verts, slhip_settle_params prm,
-                                               LdsLayout L, ProfScratch* prof_all)
+                                               LdsLayout L, ProfScratch* prof_all, DriveAcc* drive_all)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WBody* wb = reinterpret_cast<WBody*>(smem + L.off_wb);
@@ -1075,15 +1112,18 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
     int* body_lh = reinterpret_cast<int*>(smem + L.off_body_lh);
     f3* hv = reinterpret_cast<f3*>(smem + L.off_hv);
     Contact* ac = reinterpret_cast<Contact*>(smem + L.off_contacts);
-    HpEntry* hp = reinterpret_cast<HpEntry*>(smem + L.off_hp);
-    unsigned short* hp_off = reinterpret_cast<unsigned short*>(smem + L.off_hp_off);
-    unsigned char* hp_cnt = reinterpret_cast<unsigned char*>(smem + L.off_hp_cnt);
-    CPair* cp = reinterpret_cast<CPair*>(smem + L.off_cp);
+    unsigned* hp = reinterpret_cast<unsigned*>(smem + L.off_hp);
+    unsigned char* hp_off = reinterpret_cast<unsigned char*>(smem + L.off_hp_off);   // contacts per pair, then their prefix
     Group* groups = reinterpret_cast<Group*>(smem + L.off_groups);
     unsigned long long* used = reinterpret_cast<unsigned long long*>(smem + L.off_misc);
     int* wake = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 8);
     int* sep_key = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 12);   // min separation, ordered-int
     int* counters = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 16);  // [0]=n_groups [1]=n_colors
+    unsigned char* plist = reinterpret_cast<unsigned char*>(smem + L.off_misc + L.nb_cap * 16 + 64);   // bodies near the plane
+    unsigned char* cpl = plist + 64;                 // lanes of the contact pairs of a narrowphase window
+    BandPt* band = reinterpret_cast<BandPt*>(hp);    // plane phase only: 4 x kBandCap cached in-band vertices
+    const float4* gv = reinterpret_cast<const float4*>(hull_verts);
+    DriveAcc* drv = drive_all + (size_t)blockIdx.x * SLHIP_MAX_BODIES;
 
     const slhip_settle_scene sc = scenes[blockIdx.x];
     slhip_body* bodies = bodies_all + sc.body_begin;
@@ -1105,12 +1145,11 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             if (lane == 0) body_lh[i] = n_lh;
             for (int h = h0; h < h1; ++h) {
                 const int cnt = (int)hulls[h].vtx_count;
-                if (n_lh >= L.lh_cap) { fits = false; break; }
+                if (n_lh >= L.lh_cap || h1 - h0 > kMaxHullsPerBody) { fits = false; break; }
                 const bool in_lds = n_hv + cnt <= L.hv_cap;
                 if (lane == 0) {
                     HullRef r;
-                    r.g = reinterpret_cast<const float4*>(hull_verts) + hulls[h].vtx_begin;
-                    r.lds = in_lds ? n_hv : -1;
+                    r.src = in_lds ? ~n_hv : (int)hulls[h].vtx_begin;
                     r.count = cnt;
                     r.sc = V(hulls[h].sphere[0], hulls[h].sphere[1], hulls[h].sphere[2]);
                     r.sr = hulls[h].sphere[3];
@@ -1147,6 +1186,11 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     if (damp < 0.0f) damp = 0.0f;
                     wb[i].w = scale(wb[i].w, damp);
                 }
+                if (bodies[i].drive_flags & 1u) {
+                    DriveAcc z;
+                    z.dl[0] = z.dl[1] = z.dl[2] = z.da[0] = z.da[1] = z.da[2] = 0.0f;
+                    drv[i] = z;
+                }
                 wake[i] = 0;
                 sep_key[i] = 0x7f7fffff;  // ordered key of the largest finite float (>= kInf)
             }
@@ -1156,42 +1200,59 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             int n_groups = 0;  // wave-uniform running counters
             int n_active = 0;
 
-            // (b) plane contacts first: one lane per body, groups + contacts appended in body order
+            // (b) plane contacts first, groups + contacts appended in body order.  Lanes = bodies for the
+            // bounding-sphere test; the survivors are then handled four at a time, one 16-lane
+            // sub-group per body (plane_contacts_sg16)
             if (sc.has_plane) {
+                int off_run = n_active;
                 for (int base = 0; base < nb; base += 64) {
                     const int i = base + lane;
                     bool pass = false;
-                    float margin = 0.0f;
                     if (i < nb && wb[i].dynamic) {
                         const v3 ci = add(m3_mul(wb[i].R, V(bodies[i].bsphere[0], bodies[i].bsphere[1], bodies[i].bsphere[2])), wb[i].t);
                         const float vz = wb[i].v.z < 0.0f ? -wb[i].v.z * dt : 0.0f;
-                        margin = prm.contact_offset + vz;
-                        pass = !(ci.z - bodies[i].bsphere[3] - sc.plane_z > margin);
+                        pass = !(ci.z - bodies[i].bsphere[3] - sc.plane_z > prm.contact_offset + vz);
                     }
-                    RawContacts rc;
-                    rc.count = 0;
-                    if (pass) plane_contacts(wb[i], lh, hv, body_lh[i], body_lh[i + 1], sc.plane_z, margin, rc);
-                    int total;
-                    const int off = n_active + wave_excl_scan(rc.count, total);
-                    const int g = compact_slot(pass, n_groups);
-                    if (pass) {
-                        const float mu_s = 0.5f * (bodies[i].mu_s + prm.plane_mu_s);
-                        const float mu_d = 0.5f * (bodies[i].mu_d + prm.plane_mu_d);
-                        const float e = 0.5f * (bodies[i].restitution + prm.plane_restitution);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (k < rc.count && off + k < kMaxActive)
-                                fill_contact(&ac[off + k], i, -1, wb[i], nullptr, rc.pa[k], rc.pb[k], rc.n, rc.sep[k],
-                                             prm.rest_offset, mu_s, mu_d, e);
-                        Group G;
-                        G.a = (short)i; G.b = -1;
-                        G.begin = (short)min(off, kMaxActive); G.end = (short)min(off + rc.count, kMaxActive);
-                        G.color = 0;
-                        groups[g] = G;
+                    const int rank = compact_slot(pass, 0);
+                    const int n_pass = __popcll(__ballot(pass));
+                    if (pass) plist[rank] = (unsigned char)lane;
+                    __syncthreads();
+                    const int sg = lane >> 4, sl = lane & 15;
+                    for (int r0 = 0; r0 < n_pass; r0 += 4) {
+                        const bool on = r0 + sg < n_pass;
+                        const int bi = on ? base + (int)plist[r0 + sg] : 0;
+                        RawContacts rc;
+                        rc.count = 0;
+                        if (on) {
+                            const float vz = wb[bi].v.z < 0.0f ? -wb[bi].v.z * dt : 0.0f;
+                            plane_contacts_sg16(wb[bi], lh, hv, gv, body_lh[bi], body_lh[bi + 1], sc.plane_z,
+                                                prm.contact_offset + vz, band + sg * kBandCap, sg, sl, rc);
+                        }
+                        const int c0 = __shfl(rc.count, 0, 64), c1 = __shfl(rc.count, 16, 64), c2 = __shfl(rc.count, 32, 64);
+                        const int c3 = __shfl(rc.count, 48, 64);
+                        const int off = off_run + (sg > 0 ? c0 : 0) + (sg > 1 ? c1 : 0) + (sg > 2 ? c2 : 0);
+                        if (on) {
+                            if (sl < rc.count && off + sl < kMaxActive) {
+                                const float e = 0.5f * (bodies[bi].restitution + prm.plane_restitution);
+                                const v3 pa = sl == 0 ? rc.pa[0] : sl == 1 ? rc.pa[1] : sl == 2 ? rc.pa[2] : rc.pa[3];
+                                const float sp = sl == 0 ? rc.sep[0] : sl == 1 ? rc.sep[1] : sl == 2 ? rc.sep[2] : rc.sep[3];
+                                fill_contact(&ac[off + sl], bi, -1, wb[bi], nullptr, pa, V(pa.x, pa.y, sc.plane_z), rc.n, sp,
+                                             prm.rest_offset, e);
+                            }
+                            if (sl == 0) {
+                                Group G;
+                                G.a = (unsigned char)bi; G.b = (unsigned char)kNoBody;
+                                G.begin = (unsigned char)min(off, kMaxActive); G.end = (unsigned char)min(off + rc.count, kMaxActive);
+                                G.color = 0;
+                                groups[n_groups + r0 + sg] = G;
+                            }
+                        }
+                        off_run += c0 + c1 + c2 + c3;
+                        __syncthreads();   // the band cache is reused by the next round
                     }
-                    n_active = min(n_active + total, kMaxActive);
-                    n_groups += __popcll(__ballot(pass));
+                    n_groups += n_pass;
                 }
+                n_active = min(off_run, kMaxActive);
             }
             const int n_plane_groups = n_groups;
             const int n_active_before_pairs = n_active;
@@ -1247,19 +1308,14 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                                 if (ok) ok = aabb_overlap(wb[i], hulls[ga0 + a], wb[j], hulls[gb0 + b], margin);
                             }
                             const int slot = compact_slot(ok, n_hp);
-                            if (ok && slot < SLHIP_MAX_HULL_PAIRS) {
-                                HpEntry e;
-                                e.ba = (unsigned short)i; e.bb = (unsigned short)j;
-                                e.la = (unsigned short)(la0 + a); e.lb = (unsigned short)(lb0 + b);
-                                hp[slot] = e;
-                            }
+                            if (ok && slot < SLHIP_MAX_HULL_PAIRS) hp[slot] = hp_pack(i, j, a, b);
                             n_hp = min(n_hp + (int)__popcll(__ballot(ok)), (int)SLHIP_MAX_HULL_PAIRS);
                         }
                         if (n_hp > first) {
                             if (lane == 0) {
                                 Group G;
-                                G.a = (short)i; G.b = (short)j;
-                                G.begin = (short)first; G.end = (short)n_hp;  // hull-pair range for now
+                                G.a = (unsigned char)i; G.b = (unsigned char)j;
+                                G.begin = 0; G.end = 0;   // contact range: filled in after the narrowphase
                                 G.color = 0;
                                 groups[n_groups] = G;
                             }
@@ -1273,72 +1329,75 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
             PROF_COUNT(0, n_hp);
 
             // (d) narrowphase in windows of 64 hull pairs:
-            //   d1  lane = hull pair: plain GJK (most pairs leave through the margin early-out);
-            //       contact pairs are compacted (in order) into the cpair list
-            //   d2  lane = (contact pair, tilt run): the four tilted GJK runs of 16 pairs per pass
+            //   d1  lane = hull pair: plain GJK (most pairs leave through the margin early-out); the
+            //       result stays in the lane's registers, the lanes of the contact pairs are listed
+            //       (in order) in cpl
+            //   d2  lane = (contact pair, tilt run): fetches the pair's main result with shuffles and
+            //       does one of the four tilted GJK runs, 16 pairs per pass
             //   d3  the tilt-0 lane of every pair gathers the candidates with shuffles, rejects
             //       duplicates, reduces the manifold and appends the contacts in pair order
-            for (int k = lane; k < n_hp; k += 64) hp_cnt[k] = 0;
+            for (int k = lane; k <= n_hp; k += 64) hp_off[k] = 0;
             __syncthreads();
             for (int base = 0; base < n_hp; base += 64) {
                 const int k = base + lane;
                 MainResult mr;
-                mr.type = 0;
+                mr.type = 0; mr.dist = 0.0f;
+                mr.n = V(0, 0, 0); mr.pa = V(0, 0, 0); mr.pb = V(0, 0, 0);
                 if (k < n_hp) {
-                    const HpEntry e = hp[k];
-                    const v3 dv = sub(wb[e.ba].v, wb[e.bb].v);
+                    const unsigned e = hp[k];
+                    const int ba = hp_ba(e), bb = hp_bb(e);
+                    const v3 dv = sub(wb[ba].v, wb[bb].v);
                     const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
-                    pair_main(wb[e.ba], wb[e.bb], lh[e.la], lh[e.lb], hv, margin, mr);
+                    pair_main(wb[ba], wb[bb], lh[body_lh[ba] + hp_ha(e)], lh[body_lh[bb] + hp_hb(e)], hv, gv, margin, mr);
                 }
                 const int slot = compact_slot(mr.type != 0, 0);
                 const int ncp = __popcll(__ballot(mr.type != 0));
-                if (mr.type != 0) {
-                    CPair cpd;
-                    cpd.k = (unsigned short)k; cpd.type = (unsigned short)mr.type;
-                    cpd.n = mr.n; cpd.pa = mr.pa; cpd.pb = mr.pb; cpd.dist = mr.dist;
-                    cp[slot] = cpd;
-                }
+                if (mr.type != 0) cpl[slot] = (unsigned char)lane;
                 __syncthreads();
                 for (int ib = 0; ib < 4 * ncp; ib += 64) {
                     const int item = ib + lane;
                     const int m = item >> 2, t = item & 3;
+                    const bool on = m < ncp;
+                    const int src = on ? (int)cpl[m] : lane;
+                    MainResult mm;
+                    mm.type = __shfl(mr.type, src, 64);
+                    mm.n = V(__shfl(mr.n.x, src, 64), __shfl(mr.n.y, src, 64), __shfl(mr.n.z, src, 64));
+                    mm.pa = V(__shfl(mr.pa.x, src, 64), __shfl(mr.pa.y, src, 64), __shfl(mr.pa.z, src, 64));
+                    mm.pb = V(__shfl(mr.pb.x, src, 64), __shfl(mr.pb.y, src, 64), __shfl(mr.pb.z, src, 64));
+                    mm.dist = __shfl(mr.dist, src, 64);
+                    const int kk = base + src;   // hull pair of this item
                     bool have = false;
                     v3 qa = V(0, 0, 0), qb = V(0, 0, 0);
                     float sp = 0.0f;
-                    CPair cpd;
-                    cpd.type = 0; cpd.k = 0;
                     int bi = 0, bj = 0;
                     float margin = 0.0f, radius = 1.0f;
-                    if (m < ncp) {
-                        cpd = cp[m];
-                        const HpEntry e = hp[cpd.k];
-                        bi = e.ba; bj = e.bb;
+                    if (on) {
+                        const unsigned e = hp[kk];
+                        bi = hp_ba(e); bj = hp_bb(e);
                         const v3 dv = sub(wb[bi].v, wb[bj].v);
                         margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
-                        const HullRef& ha = lh[e.la];
-                        const HullRef& hb = lh[e.lb];
+                        const HullRef& ha = lh[body_lh[bi] + hp_ha(e)];
+                        const HullRef& hb = lh[body_lh[bj] + hp_hb(e)];
                         radius = ha.sr <= hb.sr ? ha.sr : hb.sr;
-                        if (cpd.type == 1) have = pair_tilt(wb[bi], wb[bj], ha, hb, hv, prm, margin, cpd.n, t, &qa, &qb, &sp);
+                        if (mm.type == 1) have = pair_tilt(wb[bi], wb[bj], ha, hb, hv, gv, prm, margin, mm.n, t, &qa, &qb, &sp);
                     }
                     // gather the four candidates of a pair into its tilt-0 lane
                     Cand5 c;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int src = (lane & ~3) + q;
-                        c.p[q + 1] = V(__shfl(qa.x, src, 64), __shfl(qa.y, src, 64), __shfl(qa.z, src, 64));
-                        c.q[q + 1] = V(__shfl(qb.x, src, 64), __shfl(qb.y, src, 64), __shfl(qb.z, src, 64));
-                        c.s[q + 1] = __shfl(sp, src, 64);
-                        c.ok[q + 1] = __shfl(have ? 1 : 0, src, 64) != 0;
+                        const int from = (lane & ~3) + q;
+                        c.p[q + 1] = V(__shfl(qa.x, from, 64), __shfl(qa.y, from, 64), __shfl(qa.z, from, 64));
+                        c.q[q + 1] = V(__shfl(qb.x, from, 64), __shfl(qb.y, from, 64), __shfl(qb.z, from, 64));
+                        c.s[q + 1] = __shfl(sp, from, 64);
+                        c.ok[q + 1] = __shfl(have ? 1 : 0, from, 64) != 0;
                     }
                     RawContacts rc;
                     rc.count = 0;
-                    if (m < ncp && t == 0) {
-                        MainResult mm;
-                        mm.type = cpd.type; mm.n = cpd.n; mm.pa = cpd.pa; mm.pb = cpd.pb; mm.dist = cpd.dist;
+                    if (on && t == 0) {
                         float smin;
-                        if (cpd.type == 2) {
-                            rc.n = cpd.n; rc.pa[0] = cpd.pa; rc.pb[0] = cpd.pb; rc.sep[0] = cpd.dist; rc.count = 1;
-                            smin = cpd.dist;
+                        if (mm.type == 2) {
+                            rc.n = mm.n; rc.pa[0] = mm.pa; rc.pb[0] = mm.pb; rc.sep[0] = mm.dist; rc.count = 1;
+                            smin = mm.dist;
                         } else {
                             smin = pair_finish(mm, c, radius, rc);
                         }
@@ -1351,44 +1410,53 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     const int off = n_active + wave_excl_scan(rc.count, total);
                     if (rc.count > 0) {
                         const float rest = 2.0f * prm.rest_offset;
-                        const float mu_s = 0.5f * (bodies[bi].mu_s + bodies[bj].mu_s);
-                        const float mu_d = 0.5f * (bodies[bi].mu_d + bodies[bj].mu_d);
                         const float e = 0.5f * (bodies[bi].restitution + bodies[bj].restitution);
                         int written = 0;
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc)
                             if (cc < rc.count && off + cc < kMaxActive) {
-                                fill_contact(&ac[off + cc], bi, bj, wb[bi], &wb[bj], rc.pa[cc], rc.pb[cc], rc.n, rc.sep[cc], rest,
-                                             mu_s, mu_d, e);
+                                fill_contact(&ac[off + cc], bi, bj, wb[bi], &wb[bj], rc.pa[cc], rc.pb[cc], rc.n, rc.sep[cc], rest, e);
                                 ++written;
                             }
-                        hp_cnt[cpd.k] = (unsigned char)written;
+                        hp_off[kk] = (unsigned char)written;
                     }
                     n_active = min(n_active + total, kMaxActive);
                 }
                 __syncthreads();
             }
-            // contact offsets per hull pair (exclusive prefix of the counts)
+            // contact offsets per hull pair: exclusive prefix of the counts, in place
             {
                 int run = n_active_before_pairs;
                 for (int base = 0; base < n_hp; base += 64) {
                     const int k = base + lane;
-                    const int cnt = k < n_hp ? (int)hp_cnt[k] : 0;
+                    const int cnt = k < n_hp ? (int)hp_off[k] : 0;
                     int total;
                     const int off = run + wave_excl_scan(cnt, total);
-                    if (k < n_hp) hp_off[k] = (unsigned short)off;
+                    if (k < n_hp) hp_off[k] = (unsigned char)off;
                     run += total;
                 }
-                if (lane == 0) hp_off[n_hp] = (unsigned short)run;
+                if (lane == 0) hp_off[n_hp] = (unsigned char)run;
             }
             __syncthreads();
             PROF(3);
-            // pair groups: hull-pair range -> contact range; min separation per body
-            for (int g = n_plane_groups + lane; g < n_groups; g += 64) {
-                Group G = groups[g];
-                G.begin = (short)hp_off[G.begin];
-                G.end = (short)hp_off[G.end];
-                groups[g] = G;
+            // pair groups were appended in hull-pair order: a group's contact range runs from the
+            // offset of its first hull pair to the end of its last one; min separation per body
+            {
+                int gi = n_plane_groups;
+                for (int base = 0; base < n_hp; base += 64) {
+                    const int k = base + lane;
+                    bool first = false, last = false;
+                    if (k < n_hp) {
+                        const unsigned key = hp[k] & 0xfffu;
+                        first = k == 0 || (hp[k - 1] & 0xfffu) != key;
+                        last = k == n_hp - 1 || (hp[k + 1] & 0xfffu) != key;
+                    }
+                    const unsigned long long fm = __ballot(first);
+                    const int gk = gi + (int)__popcll(fm & ((2ull << lane) - 1ull)) - 1;
+                    if (first) groups[gk].begin = hp_off[k];
+                    if (last) groups[gk].end = hp_off[k + 1];
+                    gi += (int)__popcll(fm);
+                }
             }
             for (int i = lane; i < nb; i += 64) {
                 int key = sep_key[i];
@@ -1410,7 +1478,7 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     (void)touch;
                     if (!touching) continue;
                     for (int s = 0; s < 2; ++s) {
-                        const int me = s ? G.b : G.a, other = s ? G.a : G.b;
+                        const int me = s ? G.b : G.a, other = s ? G.a : G.b;   // pair groups: both are bodies
                         if ((bodies[me].flags & SLHIP_BODY_ASLEEP) && wb[other].dynamic) {
                             const float en = 0.5f * dot(wb[other].v, wb[other].v);
                             if (en > prm.sleep_threshold) wake[me] = 1;
@@ -1434,12 +1502,12 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                 for (int i = 0; i < nb; ++i) used[i] = 0ull;
                 int ncol = 0;
                 for (int g = 0; g < n_groups; ++g) {
-                    const int a = groups[g].a, b = groups[g].b;
+                    const int a = groups[g].a, b = groups[g].b == kNoBody ? -1 : (int)groups[g].b;
                     unsigned long long m = used[a];
                     if (b >= 0) m |= used[b];
                     int c = 0;
                     while (c < 63 && ((m >> c) & 1ull)) ++c;
-                    groups[g].color = c;
+                    groups[g].color = (unsigned char)c;
                     used[a] |= 1ull << c;
                     if (b >= 0) used[b] |= 1ull << c;
                     if (c + 1 > ncol) ncol = c + 1;
@@ -1458,11 +1526,11 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     for (int g = lane; g < n_groups; g += 64) {
                         const Group G = groups[g];
                         if (G.color != col) continue;
-                        solve_group(ac, G.begin, G.end, G.a, G.b, wb, inv_dt, true);
+                        solve_group(ac, G.begin, G.end, G.a, G.b == kNoBody ? -1 : (int)G.b, wb, inv_dt, true, prm.plane_mu_s, prm.plane_mu_d);
                     }
                     __syncthreads();
                 }
-                for (int i = lane; i < nb; i += 64) solve_drive(bodies[i], wb[i], prm, true);
+                for (int i = lane; i < nb; i += 64) solve_drive(bodies[i], wb[i], drv[i], prm, true);
                 __syncthreads();
             }
             PROF(8);
@@ -1493,11 +1561,11 @@ __global__ __launch_bounds__(64) void k_settle(const slhip_settle_scene* __restr
                     for (int g = lane; g < n_groups; g += 64) {
                         const Group G = groups[g];
                         if (G.color != col) continue;
-                        solve_group(ac, G.begin, G.end, G.a, G.b, wb, inv_dt, false);
+                        solve_group(ac, G.begin, G.end, G.a, G.b == kNoBody ? -1 : (int)G.b, wb, inv_dt, false, prm.plane_mu_s, prm.plane_mu_d);
                     }
                     __syncthreads();
                 }
-                for (int i = lane; i < nb; i += 64) solve_drive(bodies[i], wb[i], prm, false);
+                for (int i = lane; i < nb; i += 64) solve_drive(bodies[i], wb[i], drv[i], prm, false);
                 __syncthreads();
             }
             PROF(10);
@@ -1565,19 +1633,18 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
             if (dot(d, d) > rr * rr) continue;
             for (unsigned ha = b[i].hull_begin; ha < b[i].hull_end && !hit; ++ha)
                 for (unsigned hb = b[j].hull_begin; hb < b[j].hull_end && !hit; ++hb) {
-                    HullRef ra, rb;
-                    ra.g = reinterpret_cast<const float4*>(hull_verts) + hulls[ha].vtx_begin; ra.lds = -1; ra.count = (int)hulls[ha].vtx_count;
-                    ra.sc = V(hulls[ha].sphere[0], hulls[ha].sphere[1], hulls[ha].sphere[2]); ra.sr = hulls[ha].sphere[3];
-                    rb.g = reinterpret_cast<const float4*>(hull_verts) + hulls[hb].vtx_begin; rb.lds = -1; rb.count = (int)hulls[hb].vtx_count;
-                    rb.sc = V(hulls[hb].sphere[0], hulls[hb].sphere[1], hulls[hb].sphere[2]); rb.sr = hulls[hb].sphere[3];
-                    Shape A, B;
-                    make_shape(wb[i], ra, A);
-                    make_shape(wb[j], rb, B);
-                    const v3 ca = add(m3_mul(wb[i].R, ra.sc), wb[i].t);
-                    const v3 cb = add(m3_mul(wb[j].R, rb.sc), wb[j].t);
+                    const v3 sa = V(hulls[ha].sphere[0], hulls[ha].sphere[1], hulls[ha].sphere[2]);
+                    const v3 sb = V(hulls[hb].sphere[0], hulls[hb].sphere[1], hulls[hb].sphere[2]);
+                    const v3 ca = add(m3_mul(wb[i].R, sa), wb[i].t);
+                    const v3 cb = add(m3_mul(wb[j].R, sb), wb[j].t);
                     const v3 dd = sub(ca, cb);
-                    const float r2 = ra.sr + rb.sr;
+                    const float r2 = hulls[ha].sphere[3] + hulls[hb].sphere[3];
                     if (dot(dd, dd) > r2 * r2) continue;
+                    Shape A, B;
+                    A.g = reinterpret_cast<const float4*>(hull_verts) + hulls[ha].vtx_begin; A.lds = -1;
+                    A.count = (int)hulls[ha].vtx_count; A.R = wb[i].R; A.t = wb[i].t;
+                    B.g = reinterpret_cast<const float4*>(hull_verts) + hulls[hb].vtx_begin; B.lds = -1;
+                    B.count = (int)hulls[hb].vtx_count; B.R = wb[j].R; B.t = wb[j].t;
                     v3 pa, pb;
                     float dist;
                     if (gjk_distance(A, B, (const f3*)nullptr, dd, 0.0f, &pa, &pb, &dist) == 0) hit = true;
@@ -1599,9 +1666,15 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
 
 }  // namespace
 
+// per-scene scratch: [n_scenes x ProfScratch][n_scenes x SLHIP_MAX_BODIES x DriveAcc]
+static uint64_t settle_scratch_bytes(uint32_t n_scenes)
+{
+    return (uint64_t)n_scenes * (sizeof(ProfScratch) + SLHIP_MAX_BODIES * sizeof(DriveAcc)) + 256;
+}
+
 extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, uint64_t* bytes_out)
 {
-    *bytes_out = (uint64_t)n_scenes * sizeof(ProfScratch) + 256;
+    *bytes_out = settle_scratch_bytes(n_scenes);
     return 0;
 }
 
@@ -1615,35 +1688,39 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         return -1;
     }
     if (n_scenes == 0) return 0;
-    if (scratch_bytes < (uint64_t)n_scenes * sizeof(ProfScratch)) {
+    if (scratch_bytes < settle_scratch_bytes(n_scenes)) {
         slhip::set_error("slhip_settle: scratch too small");
         return -1;
     }
-    // LDS layout from the batch maxima; hull vertices go to LDS when the whole working set
-    // stays <= 52 KB (3 scenes per CU), otherwise they are read from the global pool
     int nb_cap = params->max_bodies_per_scene ? (int)params->max_bodies_per_scene : SLHIP_MAX_BODIES;
     if (nb_cap > SLHIP_MAX_BODIES) {
         slhip::set_error("slhip_settle: at most %d bodies per scene", SLHIP_MAX_BODIES);
         return -1;
     }
-    int lh_cap = params->max_hulls_per_scene ? (int)params->max_hulls_per_scene : 1024;
-    int hv_cap = (int)params->max_hull_verts_per_scene;
-    LdsLayout L = make_layout(nb_cap, lh_cap, hv_cap);
-    const int kLdsBudget = 40 * 1024;  // 4 scenes per CU (160 KiB LDS)
-    if (L.total > kLdsBudget) {
-        const int over = L.total - kLdsBudget;
-        hv_cap = hv_cap - (over + 11) / 12;
-        if (hv_cap < 0) hv_cap = 0;
-        L = make_layout(nb_cap, lh_cap, hv_cap);
-    }
-    if (L.total > 160 * 1024) {
-        slhip::set_error("slhip_settle: scene too large for LDS (%d bytes)", L.total);
+    // LDS layout from the batch maxima.  The kernel is bound by the latency of its dependent
+    // instruction chains, so residency comes first: 8 single-wave workgroups per CU (two per
+    // SIMD, the VGPR limit) when the fixed part of the layout fits 160 KiB / 8, fewer otherwise.
+    // Whatever is left of the per-scene share caches hull vertices; the rest are read from the
+    // global pool (L2).
+    const int lh_cap = params->max_hulls_per_scene ? (int)params->max_hulls_per_scene : 1024;
+    const int fixed = make_layout(nb_cap, lh_cap, 0).total;
+    const int kLdsPerCu = 160 * 1024, kGranule = 1280;
+    if (fixed > kLdsPerCu) {
+        slhip::set_error("slhip_settle: scene too large for LDS (%d bytes)", fixed);
         return -1;
     }
+    int resident = kLdsPerCu / fixed;
+    if (resident > 8) resident = 8;
+    int share = (kLdsPerCu / kGranule / resident) * kGranule;
+    if (share < fixed) share = fixed;
+    int hv_cap = (int)params->max_hull_verts_per_scene;
+    if (hv_cap > (share - fixed) / 12) hv_cap = (share - fixed) / 12;
+    const LdsLayout L = make_layout(nb_cap, lh_cap, hv_cap);
     SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_settle), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     L.total));
-    k_settle<<<n_scenes, 64, L.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, L,
-                                                reinterpret_cast<ProfScratch*>(d_scratch));
+    ProfScratch* prof = reinterpret_cast<ProfScratch*>(d_scratch);
+    DriveAcc* drive = reinterpret_cast<DriveAcc*>(prof + n_scenes);
+    k_settle<<<n_scenes, 64, L.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, L, prof, drive);
     SLHIP_LAUNCH_CHECK();
     return 0;
 }
