@@ -33,7 +33,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=768, help="scenes per GPU per step (one settle launch; 768 = 256 CUs x 3 resident scenes)")
+    ap.add_argument("--batch", type=int, default=2048,
+                    help="scenes per GPU per step (one settle launch; 2048 = 256 CUs x 8 resident scenes)")
     ap.add_argument("--render-chunk", type=int, default=128, help="scenes per render launch sequence")
     ap.add_argument("--no-ssao", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -234,10 +235,14 @@ def main():
 
     n_items = args.warmup + args.steps
     items = []
+    t_prep = time.perf_counter()
     for k in range(n_items):
         base = (rank * n_items + k) * args.batch
         items.append(pipe.prepare([make_scene(sl, meshes, base + i) for i in range(args.batch)], seed=base))
     torch.cuda.synchronize()
+    if rank == 0:
+        print("[bench] prepared %d batches of %d scenes in %.1f s (untimed set-up)" % (n_items, args.batch, time.perf_counter() - t_prep),
+              file=sys.stderr)
 
     from stillleben_amd.parallel import BatchGatherer
 

@@ -34,10 +34,19 @@ for i in range(B):
     s.choose_random_camera_pose()
     s.choose_random_light_direction()
     scenes.append(s)
+import ctypes as C  # noqa: E402
+
 eng = engine()
-bufs = None
+bufs = eng.render(scenes, _abi.OUT_GT6, ssao=True, shadows=True, buffers=None)   # warm-up
+torch.cuda.synchronize()
+eng.L.slhip_timing_enable(1)
+ms = (C.c_float * 8)()
+eng.L.slhip_render_timings(C.byref(ms))
 for _ in range(REPS):
     bufs = eng.render(scenes, _abi.OUT_GT6, ssao=True, shadows=True, buffers=bufs)
 torch.cuda.synchronize()
+if eng.L.slhip_render_timings(C.byref(ms)) == 0:
+    names = ["shadow_raster", "shadow_large", "vis_raster", "vis_large", "shade", "ssao", "ssao_apply", "tonemap"]
+    print("phase ms per render of %d scenes:" % B, {n: round(v / REPS, 2) for n, v in zip(names, ms)})
 inst = bufs.instance.cpu().numpy()
 print("rendered", B, "scenes x", REPS, "; covered pixels per scene: %.0f" % ((inst != 0).sum() / B))
