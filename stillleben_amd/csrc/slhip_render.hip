@@ -295,6 +295,15 @@ __device__ __forceinline__ void vertex_full(const slhip_mesh_pool& pool, const s
 // ---------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// a light with zero colour or zero direction casts no shadow and adds no radiance
+__device__ __forceinline__ bool light_active(const slhip_scene* sc, int l)
+{
+    const float* lc = sc->light_color[l];
+    const float* ld = sc->light_dir[l];
+    return !((lc[0] == 0.0f && lc[1] == 0.0f && lc[2] == 0.0f) ||
+             (ld[0] == 0.0f && ld[1] == 0.0f && ld[2] == 0.0f));
+}
+
 __global__ __launch_bounds__(256) void k_vertex_xform(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                       const slhip_draw* __restrict__ draws, float4* __restrict__ clip,
                                                       unsigned n_clip_verts, int with_lights)
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(256) void k_vertex_xform(slhip_mesh_pool pool, cons
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc, 0, 0, 0);
         // lane holds rows (lane>>4)*4 + 0..3 of column lane&15 = the float4 of plane (lane>>4)
         const unsigned plane = lane >> 4;
-        if (v0 + (lane & 15) < nv && (plane == 0 || with_lights))
+        if (v0 + (lane & 15) < nv && (plane == 0 || (with_lights && light_active(sc, (int)plane - 1))))
             clip[(size_t)plane * n_clip_verts + dr->clip_base + v0 + (lane & 15)] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
@@ -624,14 +633,6 @@ __global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip
 // ---------------------------------------------------------------------------------------------
 // shadow pass (render_pass.cpp:408-460): depth only, front faces culled
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool light_active(const slhip_scene* sc, int l)
-{
-    const float* lc = sc->light_color[l];
-    const float* ld = sc->light_dir[l];
-    return !((lc[0] == 0.0f && lc[1] == 0.0f && lc[2] == 0.0f) ||
-             (ld[0] == 0.0f && ld[1] == 0.0f && ld[2] == 0.0f));
-}
-
 __device__ __forceinline__ void shadow_clip(const slhip_mesh_pool& pool, const float* T, unsigned v, float* clip)
 {
     const float4 p = reinterpret_cast<const float4*>(pool.d_pos)[v];
@@ -654,28 +655,28 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
                                                        unsigned n_clip_verts)
 {
     const slhip_chunk ch = chunks[blockIdx.x];
-    const int light = blockIdx.y;
     if (threadIdx.x >= ch.count) return;
     const slhip_scene* sc = scenes + ch.scene;
     const slhip_draw* dr = draws + ch.draw;
     if (!(dr->flags & SLHIP_DRAW_CASTS_SHADOW)) return;
-    if (!light_active(sc, light)) return;
     const unsigned tri = ch.first_tri + threadIdx.x;
     const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
-    float c[3][4];
-    const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float4 c4 = plane[ip[k]];
-        c[k][0] = c4.x; c[k][1] = c4.y; c[k][2] = c4.z; c[k][3] = c4.w;
+    const unsigned i0 = ip[0], i1 = ip[1], i2 = ip[2];
+    // one block per chunk, the (few) active lights in a loop: the index fetch is shared and no
+    // workgroups are launched for lights that are off
+    for (int light = 0; light < SLHIP_NUM_LIGHTS; ++light) {
+        if (!light_active(sc, light)) continue;
+        const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
+        const float4 a4 = plane[i0], b4 = plane[i1], c4 = plane[i2];
+        const float c0[4] = {a4.x, a4.y, a4.z, a4.w}, c1[4] = {b4.x, b4.y, b4.z, b4.w}, c2[4] = {c4.x, c4.y, c4.z, c4.w};
+        Setup t;
+        if (!setup_tri(c0, c1, c2, S, S, t)) continue;
+        if (t.flipped) continue;  // front face culled
+        ShadowTarget tgt;
+        tgt.sm = shadow + ((size_t)ch.scene * SLHIP_NUM_LIGHTS + light) * S * S;
+        tgt.W = S;
+        raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene | ((unsigned)light << 24));
     }
-    Setup t;
-    if (!setup_tri(c[0], c[1], c[2], S, S, t)) return;
-    if (t.flipped) return;  // front face culled
-    ShadowTarget tgt;
-    tgt.sm = shadow + ((size_t)ch.scene * SLHIP_NUM_LIGHTS + light) * S * S;
-    tgt.W = S;
-    raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene | ((unsigned)light << 24));
 }
 
 __global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
@@ -872,8 +873,22 @@ __device__ __forceinline__ uchar4 tone_map_px(const float* c, float manual_expos
 // ---------------------------------------------------------------------------------------------
 // k_shade: deferred resolve, one thread per pixel
 // ---------------------------------------------------------------------------------------------
+// Per-pixel kernels: block -> (scene, 256-pixel block).  Consecutive blocks are observed to land on
+// consecutive XCDs (block b on XCD b % 8, MI355X_MICROARCH.md "Workgroup dispatch"), and every XCD has
+// its own L2: all blocks of a scene get the same b % 8, so the scene's vertices, shadow map, z plane
+// and AO plane are fetched into ONE L2 instead of eight.  Placement only affects speed.
+// Grid = 8 * ceil(n_scenes / 8) * blocks_per_scene.
+__device__ __forceinline__ bool scene_block(unsigned blocks_per_scene, unsigned n_scenes, unsigned& scene, unsigned& blk)
+{
+    const unsigned x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    scene = x + 8u * (j / blocks_per_scene);
+    blk = j % blocks_per_scene;
+    return scene < n_scenes;
+}
+
 struct ShadeParams {
     int W, H;
+    unsigned n_scenes;
     unsigned flags;
     int S;
     int inline_tonemap;  // 1: no SSAO and manual exposure -> write rgb directly
@@ -890,8 +905,9 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
     const int W = prm.W, H = prm.H;
     const size_t P = (size_t)W * H;
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
-    const unsigned scene = blockIdx.x / blocks_per_scene;
-    const unsigned pix = (blockIdx.x % blocks_per_scene) * 256 + threadIdx.x;
+    unsigned scene, blk;
+    if (!scene_block(blocks_per_scene, prm.n_scenes, scene, blk)) return;
+    const unsigned pix = blk * 256 + threadIdx.x;
     const bool active = pix < P;
     const slhip_scene* sc = scenes + scene;
     const size_t gp = (size_t)scene * P + pix;
@@ -1006,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
             }
             __syncthreads();
         }
-        if (threadIdx.x < 4) lum_part[(size_t)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+        if (threadIdx.x < 4) lum_part[((size_t)scene * blocks_per_scene + blk) * 4 + threadIdx.x] = red[threadIdx.x][0];
     }
 }
 
@@ -1032,14 +1048,15 @@ __device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, 
     return fmaf(ay, bot - top, top);
 }
 
-__global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ scenes, int W, int H,
+__global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
                                               const float* __restrict__ cam, const float* __restrict__ nrm,
                                               const float* __restrict__ zplane, float* __restrict__ ao)
 {
     const size_t P = (size_t)W * H;
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
-    const unsigned scene = blockIdx.x / blocks_per_scene;
-    const unsigned pix = (blockIdx.x % blocks_per_scene) * 256 + threadIdx.x;
+    unsigned scene, blk;
+    if (!scene_block(blocks_per_scene, n_scenes, scene, blk)) return;
+    const unsigned pix = blk * 256 + threadIdx.x;
     if (pix >= P) return;
     const float* proj = scenes[scene].proj;
     const float* camS = zplane + (size_t)scene * P;
@@ -1078,14 +1095,15 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
     ao[gp] = 1.0f - occlusion / 64.0f;
 }
 
-__global__ __launch_bounds__(256) void k_ssao_apply(int W, int H, const float* __restrict__ hdr_in,
+__global__ __launch_bounds__(256) void k_ssao_apply(unsigned n_scenes, int W, int H, const float* __restrict__ hdr_in,
                                                     const float* __restrict__ ao, const float* __restrict__ zplane,
                                                     float* __restrict__ hdr_out)
 {
     const size_t P = (size_t)W * H;
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
-    const unsigned scene = blockIdx.x / blocks_per_scene;
-    const unsigned pix = (blockIdx.x % blocks_per_scene) * 256 + threadIdx.x;
+    unsigned scene, blk;
+    if (!scene_block(blocks_per_scene, n_scenes, scene, blk)) return;
+    const unsigned pix = blk * 256 + threadIdx.x;
     if (pix >= P) return;
     const float* camS = zplane + (size_t)scene * P;
     const float* aoS = ao + (size_t)scene * P;
@@ -1111,14 +1129,15 @@ __global__ __launch_bounds__(256) void k_ssao_apply(int W, int H, const float* _
     reinterpret_cast<float4*>(hdr_out)[gp] = make_float4(h.x * a, h.y * a, h.z * a, h.w);
 }
 
-__global__ __launch_bounds__(256) void k_tonemap(const slhip_scene* __restrict__ scenes, int W, int H,
+__global__ __launch_bounds__(256) void k_tonemap(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
                                                  const float* __restrict__ hdr, const float* __restrict__ lum_part,
                                                  uint8_t* __restrict__ rgb)
 {
     const size_t P = (size_t)W * H;
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
-    const unsigned scene = blockIdx.x / blocks_per_scene;
-    const unsigned pix = (blockIdx.x % blocks_per_scene) * 256 + threadIdx.x;
+    unsigned scene, blk;
+    if (!scene_block(blocks_per_scene, n_scenes, scene, blk)) return;
+    const unsigned pix = blk * 256 + threadIdx.x;
     const float manual = scenes[scene].manual_exposure;
     __shared__ float s_lum;
     if (!(manual >= 0.0f)) {
@@ -1273,7 +1292,7 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     const int W = (int)width, H = (int)height;
     const size_t P = (size_t)W * H;
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
-    const unsigned pix_blocks = blocks_per_scene * n_scenes;
+    const unsigned pix_blocks = blocks_per_scene * 8u * ((n_scenes + 7u) / 8u);   // see scene_block()
     const int S = (int)scratch->shadow_res;
     if (n_chunks > 0 && (!scratch->d_clip || scratch->n_clip_verts == 0)) {
         slhip::set_error("slhip_render: d_clip scratch (n_clip_verts x 16 B x planes) is required");
@@ -1311,7 +1330,7 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
         k_clear_shadow<<<dim3(64, n_scenes * SLHIP_NUM_LIGHTS), 256, 0, stream>>>(
             d_scenes, reinterpret_cast<unsigned*>(scratch->d_shadow), S);
         SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
-        k_shadow_raster<<<dim3(n_chunks, SLHIP_NUM_LIGHTS), 256, 0, stream>>>(
+        k_shadow_raster<<<n_chunks, 256, 0, stream>>>(
             *pool, d_scenes, d_draws, d_chunks, S, reinterpret_cast<unsigned*>(scratch->d_shadow),
             scratch->d_queue, scratch->queue_capacity, clipbuf, scratch->n_clip_verts);
         mark(1, stream);
@@ -1340,7 +1359,7 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     // knows whether ANY post pass is needed, so inline tone mapping is used only when the
     // caller guarantees manual exposure through the flag below.
     ShadeParams prm;
-    prm.W = W; prm.H = H; prm.flags = flags; prm.S = S;
+    prm.W = W; prm.H = H; prm.n_scenes = n_scenes; prm.flags = flags; prm.S = S;
     prm.inline_tonemap = 0;
     prm.want_lum = want_rgb ? 1 : 0;
     float* hdr0 = want_rgb ? scratch->d_hdr : nullptr;
@@ -1357,13 +1376,13 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
         if (ssao) {
             mark(5, stream);
             const float* zpl = scratch->d_ao + (size_t)n_scenes * P;   // second half of d_ao
-            k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, W, H, out->d_cam_coord, out->d_normals, zpl, scratch->d_ao);
+            k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, out->d_cam_coord, out->d_normals, zpl, scratch->d_ao);
             mark(6, stream);
-            k_ssao_apply<<<pix_blocks, 256, 0, stream>>>(W, H, hdr0, scratch->d_ao, zpl, hdr1);
+            k_ssao_apply<<<pix_blocks, 256, 0, stream>>>(n_scenes, W, H, hdr0, scratch->d_ao, zpl, hdr1);
             tm_in = hdr1;
         }
         mark(7, stream);
-        k_tonemap<<<pix_blocks, 256, 0, stream>>>(d_scenes, W, H, tm_in, scratch->d_lum, out->d_rgb);
+        k_tonemap<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, tm_in, scratch->d_lum, out->d_rgb);
         SLHIP_LAUNCH_CHECK();
     }
     mark(kNumPhases, stream);
