@@ -581,7 +581,9 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
     }
 }
 
-// k_large: one wave per (triangle, 8x8 tile); lane == pixel
+// k_large: one wave per (triangle, 8x8 tile); lane == pixel.  Every wave takes a CONTIGUOUS run of
+// queue items: the tiles of one triangle sit next to each other in the queue, so the fetch, the
+// near-plane clip and the setup are done once per run of equal triangles, not once per tile.
 __global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                const slhip_draw* __restrict__ draws, int W, int H,
                                                unsigned long long* __restrict__ vis,
@@ -593,27 +595,36 @@ __global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip
     const unsigned lane = threadIdx.x & 63;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned i = wave; i < count; i += n_waves) {
+    const unsigned per = (count + n_waves - 1) / n_waves;
+    const unsigned i0 = wave * per, i1 = min(i0 + per, count);
+    unsigned p_draw = 0xFFFFFFFFu, p_tri = 0u, p_scene = 0u, prim = 0u;
+    bool ok = false;
+    Setup t;
+    for (unsigned i = i0; i < i1; ++i) {
         const QItem it = items[i];
         if (it.draw == 0xFFFFFFFFu) continue;
-        const slhip_scene* sc = scenes + it.scene_aux;
-        const slhip_draw* dr = draws + it.draw;
-        const unsigned tri = it.tri_sub & 0x7FFFFFFFu;
-        const int sub = (int)(it.tri_sub >> 31);
-        const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
-        ClipVert cv[3];
+        if (it.draw != p_draw || it.tri_sub != p_tri || it.scene_aux != p_scene) {
+            p_draw = it.draw; p_tri = it.tri_sub; p_scene = it.scene_aux;
+            ok = false;
+            const slhip_draw* dr = draws + it.draw;
+            const unsigned tri = it.tri_sub & 0x7FFFFFFFu;
+            const int sub = (int)(it.tri_sub >> 31);
+            const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
+            ClipVert cv[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float4 c4 = clipbuf[dr->clip_base + ip[k]];
-            cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
-            cv[k].bary[0] = cv[k].bary[1] = cv[k].bary[2] = 0.0f;
+            for (int k = 0; k < 3; ++k) {
+                const float4 c4 = clipbuf[dr->clip_base + ip[k]];
+                cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
+                cv[k].bary[0] = cv[k].bary[1] = cv[k].bary[2] = 0.0f;
+            }
+            ClipVert poly[4];
+            const int n = clip_near(cv, poly);
+            if (sub > n - 3) continue;
+            if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
+            prim = dr->prim_base + tri;
+            ok = true;
         }
-        (void)sc;
-        ClipVert poly[4];
-        const int n = clip_near(cv, poly);
-        if (sub > n - 3) continue;
-        Setup t;
-        if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
+        if (!ok) continue;
         const int px = (int)((it.tile & 0xFFFFu) << 3) + (int)(lane & 7);
         const int py = (int)((it.tile >> 16) << 3) + (int)(lane >> 3);
         if (px < t.xmin || px > t.xmax || py < t.ymin || py > t.ymax) continue;
@@ -623,7 +634,7 @@ __global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip
         tgt.vis = vis + (size_t)it.scene_aux * W * H;
         tgt.peel = nullptr;
         tgt.W = W;
-        tgt.prim = dr->prim_base + tri;
+        tgt.prim = prim;
         tgt.need_attr = false;
         tgt.tex = nullptr;
         tgt.emit(t, px, py, l);
@@ -690,23 +701,33 @@ __global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, cons
     const unsigned lane = threadIdx.x & 63;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned i = wave; i < count; i += n_waves) {
+    // contiguous runs per wave, setup shared by the tiles of one triangle (see k_large)
+    const unsigned per = (count + n_waves - 1) / n_waves;
+    const unsigned i0 = wave * per, i1 = min(i0 + per, count);
+    unsigned p_draw = 0xFFFFFFFFu, p_tri = 0u, p_scene = 0u;
+    bool ok = false;
+    Setup t;
+    for (unsigned i = i0; i < i1; ++i) {
         const QItem it = items[i];
         if (it.draw == 0xFFFFFFFFu) continue;
         const unsigned scene = it.scene_aux & 0xFFFFFFu;
         const int light = (int)(it.scene_aux >> 24);
-        const slhip_draw* dr = draws + it.draw;
-        const unsigned tri = it.tri_sub;
-        const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
-        float c[3][4];
-        const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
+        if (it.draw != p_draw || it.tri_sub != p_tri || it.scene_aux != p_scene) {
+            p_draw = it.draw; p_tri = it.tri_sub; p_scene = it.scene_aux;
+            ok = false;
+            const slhip_draw* dr = draws + it.draw;
+            const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)it.tri_sub;
+            float c[3][4];
+            const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float4 c4 = plane[ip[k]];
-            c[k][0] = c4.x; c[k][1] = c4.y; c[k][2] = c4.z; c[k][3] = c4.w;
+            for (int k = 0; k < 3; ++k) {
+                const float4 c4 = plane[ip[k]];
+                c[k][0] = c4.x; c[k][1] = c4.y; c[k][2] = c4.z; c[k][3] = c4.w;
+            }
+            if (!setup_tri(c[0], c[1], c[2], S, S, t)) continue;
+            ok = true;
         }
-        Setup t;
-        if (!setup_tri(c[0], c[1], c[2], S, S, t)) continue;
+        if (!ok) continue;
         const int px = (int)((it.tile & 0xFFFFu) << 3) + (int)(lane & 7);
         const int py = (int)((it.tile >> 16) << 3) + (int)(lane >> 3);
         if (px < t.xmin || px > t.xmax || py < t.ymin || py > t.ymax) continue;
@@ -757,6 +778,58 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ sm, int S,
     return fmaf(ay, bot - top, top);
 }
 
+// 4x4 PCF of bilinear depth compares (render_shader.frag:181-221).  The sixteen taps of
+// shadow_tap() touch a 5x5 texel window; when the per-axis tap coordinates are consecutive (always,
+// except where rounding makes two taps share a texel) the window is fetched once and every tap is
+// evaluated from registers with exactly the arithmetic and summation order of the tap-by-tap form.
+__device__ __forceinline__ float shadow_pcf16(const float* __restrict__ sm, int S, float px, float py, float ref)
+{
+    const float scale = 1.0f / (float)S;
+    int ix[4], iy[4];
+    float ax[4], ay[4];
+    bool regular = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float o = (-1.5f + (float)k) * scale;
+        const float x = fmaf(px + o, (float)S, -0.5f), y = fmaf(py + o, (float)S, -0.5f);
+        const float fx = floorf(x), fy = floorf(y);
+        ax[k] = x - fx; ay[k] = y - fy;
+        ix[k] = (int)fx; iy[k] = (int)fy;
+        if (k > 0 && (ix[k] != ix[0] + k || iy[k] != iy[0] + k)) regular = false;
+    }
+    float acc = 0.0f;
+    if (regular) {
+        const float r = clampf(ref, 0.0f, 1.0f);
+        unsigned off_y[5];
+        int cx[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            cx[k] = min(max(ix[0] + k, 0), S - 1);
+            off_y[k] = (unsigned)min(max(iy[0] + k, 0), S - 1) * (unsigned)S;
+        }
+        float c[5][5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) c[j][i] = r <= sm[off_y[j] + (unsigned)cx[i]] ? 1.0f : 0.0f;
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+            for (int xx = 0; xx < 4; ++xx) {
+                const float top = fmaf(ax[xx], c[yy][xx + 1] - c[yy][xx], c[yy][xx]);
+                const float bot = fmaf(ax[xx], c[yy + 1][xx + 1] - c[yy + 1][xx], c[yy + 1][xx]);
+                acc += fmaf(ay[yy], bot - top, top);
+            }
+    } else {
+        for (int yy = 0; yy < 4; ++yy)
+            for (int xx = 0; xx < 4; ++xx) {
+                const float ox = (-1.5f + (float)xx) * scale, oy = (-1.5f + (float)yy) * scale;
+                acc += shadow_tap(sm, S, px + ox, py + oy, ref);
+            }
+    }
+    return acc / 16.0f;
+}
+
 __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ sc, const slhip_draw* __restrict__ dr,
                                                const float* base, const float* world, const float* nrm_in,
                                                bool front_facing, const float* __restrict__ shadow, int S,
@@ -795,14 +868,7 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
             const float py = 0.5f * (pc[1] / pc[3]) + 0.5f;
             const float pz = 0.5f * (pc[2] / pc[3]) + 0.5f;
             const float* sm = shadow + (size_t)i * S * S;
-            const float scale = 1.0f / (float)S;
-            float acc = 0.0f;
-            for (int yy = 0; yy < 4; ++yy)
-                for (int xx = 0; xx < 4; ++xx) {
-                    const float ox = (-1.5f + (float)xx) * scale, oy = (-1.5f + (float)yy) * scale;
-                    acc += shadow_tap(sm, S, px + ox, py + oy, pz - 0.00003f);
-                }
-            inverse_shadow = acc / 16.0f;
+            inverse_shadow = shadow_pcf16(sm, S, px, py, pz - 0.00003f);
         }
         float L[3] = {-ld[0], -ld[1], -ld[2]};
         normalize3(L);
@@ -911,6 +977,11 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
     const bool active = pix < P;
     const slhip_scene* sc = scenes + scene;
     const size_t gp = (size_t)scene * P + pix;
+    // the block's pixels belong to one scene: its draws' first primitive ids go to LDS once
+    __shared__ unsigned s_prim_base[64];
+    const unsigned n_scene_draws = sc->draw_end - sc->draw_begin;
+    if (threadIdx.x < 64 && threadIdx.x < n_scene_draws) s_prim_base[threadIdx.x] = draws[sc->draw_begin + threadIdx.x].prim_base;
+    __syncthreads();
 
     float color[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (active) {
@@ -924,8 +995,13 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
         if (key != kVisEmpty) {
             const unsigned prim = (unsigned)(key & 0xFFFFFFFFull);
             unsigned d = sc->draw_begin;
-            for (unsigned i = sc->draw_begin + 1; i < sc->draw_end; ++i)
-                if (prim >= draws[i].prim_base) d = i;
+            if (n_scene_draws <= 64) {
+                for (unsigned i = 1; i < n_scene_draws; ++i)
+                    if (prim >= s_prim_base[i]) d = sc->draw_begin + i;
+            } else {
+                for (unsigned i = sc->draw_begin + 1; i < sc->draw_end; ++i)
+                    if (prim >= draws[i].prim_base) d = i;
+            }
             const slhip_draw* dr = draws + d;
             const unsigned tri = prim - dr->prim_base;
             const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
