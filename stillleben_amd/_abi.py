@@ -128,7 +128,8 @@ class RenderScratch(C.Structure):
 
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libslhip.so")
+# SLHIP_LIB selects another build of the same library (developer A/B runs); there is no fallback
+_LIB_PATH = os.environ.get("SLHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libslhip.so")
 
 
 class SlhipError(RuntimeError):

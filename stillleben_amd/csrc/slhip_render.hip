@@ -30,7 +30,7 @@ static_assert(sizeof(slhip_chunk) == 16, "slhip_chunk layout");
 constexpr float kInvalid = 3000.0f;  // render_pass.cpp:316
 constexpr float kPi = 3.141592653589793f;
 constexpr unsigned long long kVisEmpty = ~0ull;
-constexpr int kSmallArea = 16;  // bbox pixels a single thread rasterises itself
+constexpr int kSmallArea = 128;  // bbox pixels a single thread rasterises itself (larger boxes: tile queue)
 
 // ---------------------------------------------------------------------------------------------
 // fixed-order arithmetic (R1)
@@ -452,6 +452,50 @@ struct QItem {
     unsigned tile;      // tx | ty << 16   (8x8 pixel tiles)
 };
 
+// All pixels of the triangle's bounding box by one thread.  The edge functions are exact integers,
+// so walking them incrementally (E(px+1) = E(px) - 256 dY, E(py+1) = E(py) + 256 dX) gives the very
+// values coverage() computes from scratch -- at three 64-bit adds per pixel instead of six 64-bit
+// multiplies.  The top-left bias is folded in: a pixel is covered iff all three biased values are
+// >= 0, i.e. iff the sign bit of their OR is clear.
+template <class Target>
+__device__ __forceinline__ void raster_bbox(const Setup& t, const Target& tgt)
+{
+    const long long cx = 256ll * t.xmin + 128, cy = 256ll * t.ymin + 128;
+    long long row[3], sx[3], sy[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int a = (i + 1) % 3, b = (i + 2) % 3;
+        const long long A = t.X[b] - t.X[a], B = t.Y[b] - t.Y[a];
+        long long e = A * (cy - t.Y[a]) - B * (cx - t.X[a]);
+        long long dx = -256ll * B, dy = 256ll * A;
+        if (t.flipped) { e = -e; dx = -dx; dy = -dy; }
+        row[i] = e + t.bias[i]; sx[i] = dx; sy[i] = dy;
+    }
+    const float fa = (float)t.area2;
+    // ONE flat loop over the box: the lanes of a wave hold boxes of different shapes, and a nested
+    // loop would run (max height) x (max width) iterations instead of (max area)
+    const int bw = t.xmax - t.xmin + 1, n = bw * (t.ymax - t.ymin + 1);
+    long long e0 = row[0], e1 = row[1], e2 = row[2];
+    int px = t.xmin, py = t.ymin;
+    for (int k = 0; k < n; ++k) {
+        if ((e0 | e1 | e2) >= 0) {
+            float l[3];
+            l[0] = (float)(e0 - t.bias[0]) / fa;
+            l[1] = (float)(e1 - t.bias[1]) / fa;
+            l[2] = (float)(e2 - t.bias[2]) / fa;
+            tgt.emit(t, px, py, l);
+        }
+        if (px == t.xmax) {
+            px = t.xmin; ++py;
+            row[0] += sy[0]; row[1] += sy[1]; row[2] += sy[2];
+            e0 = row[0]; e1 = row[1]; e2 = row[2];
+        } else {
+            ++px;
+            e0 += sx[0]; e1 += sx[1]; e2 += sx[2];
+        }
+    }
+}
+
 // Rasterise one sub-triangle: small ones in place, larger ones to the queue (or in place if
 // the queue is full).
 template <class Target>
@@ -487,13 +531,7 @@ __device__ __forceinline__ void raster_or_enqueue(const Setup& t, const Target& 
             in_place = true;
         }
     }
-    if (in_place) {
-        for (int py = t.ymin; py <= t.ymax; ++py)
-            for (int px = t.xmin; px <= t.xmax; ++px) {
-                float l[3];
-                if (coverage(t, px, py, l)) tgt.emit(t, px, py, l);
-            }
-    }
+    if (in_place) raster_bbox(t, tgt);
 }
 
 // ---------------------------------------------------------------------------------------------
