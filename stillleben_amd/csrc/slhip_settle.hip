@@ -163,28 +163,37 @@ __device__ __forceinline__ v3 support(const Shape& s, const f3* __restrict__ hv,
     const v3 dl = m3_tmul(s.R, d);
     int best = 0;
     float bd = -3.0e38f;
-    float4 bp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int n = s.count;
-    for (int base = 0; base < n; base += 8) {
-        float4 p[8];
-        if (s.lds >= 0) {
+    // Only (value, index) are tracked; the winner is fetched again at the end.  Slots past the last
+    // vertex repeat vertex n-1: their dot product equals one already seen, and the strict compare
+    // never lets a repeat win, so no bounds test is needed in the chain.
+    if (s.lds >= 0) {
+        const f3* v = hv + s.lds;
+        for (int base = 0; base < n; base += 8) {
+            f3 p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = v[min(base + j, n - 1)];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const f3 q = hv[s.lds + min(base + j, n - 1)];
-                p[j] = make_float4(q.x, q.y, q.z, 1.0f);
+                const float dd = dot(V(p[j].x, p[j].y, p[j].z), dl);
+                if (dd > bd) { bd = dd; best = base + j; }
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) p[j] = s.g[min(base + j, n - 1)];
         }
+        const f3 q = v[best];
+        return add(m3_mul(s.R, V(q.x, q.y, q.z)), s.t);
+    }
+    for (int base = 0; base < n; base += 8) {
+        float4 p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = s.g[min(base + j, n - 1)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float dd = dot(V(p[j].x, p[j].y, p[j].z), dl);
-            if (base + j < n && dd > bd) { bd = dd; best = base + j; bp = p[j]; }
+            if (dd > bd) { bd = dd; best = base + j; }
         }
     }
-    (void)best;
-    return add(m3_mul(s.R, V(bp.x, bp.y, bp.z)), s.t);
+    const float4 q = s.g[best];
+    return add(m3_mul(s.R, V(q.x, q.y, q.z)), s.t);
 }
 
 struct SV { v3 w, a, b; };
