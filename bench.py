@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=2048,
                     help="scenes per GPU per step (one settle launch; 2048 = 256 CUs x 8 resident scenes)")
     ap.add_argument("--render-chunk", type=int, default=128, help="scenes per render launch sequence")
+    ap.add_argument("--settle-streams", type=int, default=3,
+                    help="settle launches kept in flight: scenes settle in very different times, and a second "
+                         "launch on its own stream back-fills the CUs the tail of the first one leaves idle")
     ap.add_argument("--no-ssao", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes of the bounded CPU-baseline sample")
@@ -70,7 +73,7 @@ class Pipeline:
         self.ssao = ssao
         self.mask = _abi.OUT_GT6
         self.buffers = []
-        self.s_settle = torch.cuda.Stream(device=self.eng.device)
+        self.s_settle = [torch.cuda.Stream(device=self.eng.device)]
         self.s_render = torch.cuda.Stream(device=self.eng.device)
         self.render_chunk = 128
         self.t_step_host = []
@@ -108,12 +111,14 @@ class Pipeline:
         self.eng.pool_abi()
         return item
 
-    def launch_settle(self, item):
-        """Asynchronous: slhip_settle on the settle stream, then the 288 B/object read-back into
-        pinned host memory; returns immediately."""
+    def launch_settle(self, item, slot=0):
+        """Asynchronous: slhip_settle on one of the settle streams, then the 288 B/object read-back
+        into pinned host memory; returns immediately."""
         from stillleben_amd import _settle_batch as SB
 
-        with torch.cuda.stream(self.s_settle):
+        while len(self.s_settle) <= slot:
+            self.s_settle.append(torch.cuda.Stream(device=self.eng.device))
+        with torch.cuda.stream(self.s_settle[slot]):
             item["ev0"] = torch.cuda.Event(enable_timing=True)
             item["ev1"] = torch.cuda.Event(enable_timing=True)
             item["ev0"].record()
@@ -260,10 +265,12 @@ def main():
         settle AND render (and gather) complete inside the call."""
         if not seq:
             return
-        pipe.launch_settle(seq[0])
+        ahead = max(1, args.settle_streams)
+        for k in range(min(ahead, len(seq))):
+            pipe.launch_settle(seq[k], k % ahead)
         for k in range(len(seq)):
-            if k + 1 < len(seq):
-                pipe.launch_settle(seq[k + 1])
+            if k + ahead < len(seq):
+                pipe.launch_settle(seq[k + ahead], (k + ahead) % ahead)
             outs = pipe.finish(seq[k], timed)
             if dist is not None:
                 pipe.s_render.synchronize()

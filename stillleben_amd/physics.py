@@ -25,7 +25,8 @@ class SettleEngine:
         self.eng = eng
         self.pool = SB.HullPool()
         self._dev = None
-        self._scratch = None
+        self._scratch = {}
+        self._keep = {}
 
     def hulls_dev(self):
         if self.pool.dirty or self._dev is None:
@@ -34,12 +35,15 @@ class SettleEngine:
             self.pool.dirty = False
         return self._dev
 
-    def scratch(self, n_scenes):
+    def scratch(self, n_scenes, stream=0):
+        """Scratch per stream: launches on different streams may run concurrently."""
         need = C.c_uint64()
         self.eng.L.slhip_settle_scratch_bytes(n_scenes, C.byref(need))
-        if self._scratch is None or self._scratch.numel() < need.value:
-            self._scratch = torch.empty(int(need.value), dtype=torch.uint8, device=self.eng.device)
-        return self._scratch
+        cur = self._scratch.get(stream)
+        if cur is None or cur.numel() < need.value:
+            cur = torch.empty(int(need.value), dtype=torch.uint8, device=self.eng.device)
+            self._scratch[stream] = cur
+        return cur
 
     def run(self, srec, bodies, params):
         """Runs slhip_settle on numpy records; returns the updated bodies (numpy)."""
@@ -53,16 +57,16 @@ class SettleEngine:
         d_s = eng.upload_records(srec)
         if d_bodies is None:
             d_bodies = eng.upload_records(bodies)
-        scratch = self.scratch(len(srec))
+        stream = torch.cuda.current_stream(eng.device).cuda_stream
+        scratch = self.scratch(len(srec), stream)
         if bodies is not None:
             params = SB.sizing_hints(params, srec, bodies, self.pool.arrays()[0])
         prm = np.ascontiguousarray(params)
-        stream = torch.cuda.current_stream(eng.device).cuda_stream
         with torch.cuda.device(eng.device):
             st = eng.L.slhip_settle(_abi_ptr(d_s), len(srec), _abi_ptr(d_bodies), _abi_ptr(d_hulls), _abi_ptr(d_verts),
                                     C.c_void_p(prm.ctypes.data), _abi_ptr(scratch), scratch.numel(), C.c_void_p(stream))
         _abi.check(st, "slhip_settle")
-        self._keep = (d_s, prm)
+        self._keep[stream] = (d_s, prm)   # alive until the next launch on the same stream
         return d_bodies
 
     def overlap(self, srec, bodies):

@@ -24,7 +24,8 @@ planes = [(physics.prepare_tabletop(s), physics.PLANE_HALF_Z) for s in scenes]
 srec, bodies = SB.build_settle_batch(scenes, se.pool, planes)
 prm = SB.sizing_hints(SB.default_params(tabletop=True, frames=FRAMES), srec, bodies, se.pool.arrays()[0])
 print("hints: bodies %d hull verts %d hulls %d" % (prm["max_bodies_per_scene"], prm["max_hull_verts_per_scene"], prm["max_hulls_per_scene"]))
-se.scratch(B).zero_()
+scr = se.scratch(B, torch.cuda.current_stream().cuda_stream)
+scr.zero_()
 d = se.eng.upload_records(bodies)
 torch.cuda.synchronize()
 t = time.perf_counter()
@@ -32,7 +33,7 @@ se.run_device(srec, None, prm, d_bodies=d)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
 print("B=%d frames=%d: %.1f ms  (%.3f ms per scene-step-batch, %.0f scene-steps/s)" % (B, FRAMES, dt * 1e3, dt * 1e3 / (FRAMES * 4), B * FRAMES * 4 / dt))
-sc = se._scratch.cpu().numpy()
+sc = scr.cpu().numpy()
 if os.environ.get("SLHIP_SETTLE_PROFILE"):
     tot = np.zeros(16)
     cnt = np.zeros(16)
