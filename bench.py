@@ -41,7 +41,7 @@ def parse():
                          "launch on its own stream back-fills the CUs the tail of the first one leaves idle")
     ap.add_argument("--no-ssao", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes per host thread of the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -180,37 +180,64 @@ class Pipeline:
         self.t_step_host.append(item["t_post"])
 
 
-def cpu_baseline(sl, meshes, n_scenes, ssao):
-    """The oracle (scalar C restatement, 1 thread) timed on the host cores on a bounded sample
-    of the same workload: n_scenes x {400-step settle + 640x480 render}."""
+def cpu_baseline(sl, meshes, scenes_per_thread, ssao, max_threads=32):
+    """The oracle (scalar C restatement) timed on the host cores on a bounded sample of the same
+    workload: every thread takes `scenes_per_thread` scenes through {400-step settle + 640x480
+    render}.  Scenes are independent, so the threads mirror the reference's JobQueue workers
+    (job_queue.cpp:35-40); the C calls release the GIL and share no state."""
+    from concurrent.futures import ThreadPoolExecutor
+
     import oracle
     from stillleben_amd import _abi, physics
     from stillleben_amd import _settle_batch as SB
     from stillleben_amd._batch import HostPool, build_batch
 
-    scenes = [make_scene(sl, meshes, 900000 + i) for i in range(n_scenes)]
-    pool_h = SB.HullPool()
-    planes = [(physics.prepare_tabletop(s), physics.PLANE_HALF_Z) for s in scenes]
-    srec, bodies = SB.build_settle_batch(scenes, pool_h, planes)
-    hulls, verts = pool_h.arrays()
-    t0 = time.perf_counter()
-    oracle.settle(srec, bodies, hulls, verts, SB.default_params(tabletop=True))
-    t1 = time.perf_counter()
-    SB.write_back(scenes, bodies)
-    for s in scenes:
-        s.choose_random_camera_pose()
-        s.choose_random_light_direction()
-    pool = HostPool()
+    threads = max(1, min(os.cpu_count() or 1, max_threads))
     flags = _abi.OUT_GT6 | _abi.RENDER_SHADOWS | (_abi.RENDER_SSAO if ssao else 0) | _abi.OUT_CAM_COORD
-    rs, rd, _ = build_batch(scenes, pool, with_shadows=True)
-    t2 = time.perf_counter()
-    oracle.render(pool.arrays(), rs, rd, RESOLUTION[0], RESOLUTION[1], flags)
-    t3 = time.perf_counter()
-    total = (t1 - t0) + (t3 - t2)
+    prm = SB.default_params(tabletop=True)
+    jobs = []
+    for t in range(threads):   # untimed set-up, as for the GPU path
+        scenes = [make_scene(sl, meshes, 900000 + t * scenes_per_thread + i) for i in range(scenes_per_thread)]
+        pool_h = SB.HullPool()
+        planes = [(physics.prepare_tabletop(s), physics.PLANE_HALF_Z) for s in scenes]
+        srec, bodies = SB.build_settle_batch(scenes, pool_h, planes)
+        jobs.append((scenes, srec, bodies, pool_h.arrays()))
+
+    def settle(job):
+        scenes, srec, bodies, (hulls, verts) = job
+        t0 = time.perf_counter()
+        oracle.settle(srec, bodies, hulls, verts, prm)
+        return time.perf_counter() - t0
+
+    def render(job):
+        pool, rs, rd = job
+        t0 = time.perf_counter()
+        oracle.render(pool.arrays(), rs, rd, RESOLUTION[0], RESOLUTION[1], flags)
+        return time.perf_counter() - t0
+
+    with ThreadPoolExecutor(threads) as ex:
+        w0 = time.perf_counter()
+        t_settle = list(ex.map(settle, jobs))
+        w1 = time.perf_counter()
+        rjobs = []
+        for scenes, srec, bodies, _ in jobs:   # camera / light placement + draw records: untimed host glue
+            SB.write_back(scenes, bodies)
+            for s in scenes:
+                s.choose_random_camera_pose()
+                s.choose_random_light_direction()
+            pool = HostPool()
+            rs, rd, _c = build_batch(scenes, pool, with_shadows=True)
+            rjobs.append((pool, rs, rd))
+        w2 = time.perf_counter()
+        t_render = list(ex.map(render, rjobs))
+        w3 = time.perf_counter()
+    n = threads * scenes_per_thread
+    wall = (w1 - w0) + (w3 - w2)
     return {
-        "value": n_scenes / total, "unit": "scenes/s", "cores": 1, "kind": "port",
-        "sample": "%d scenes: settle %.2f s + render %.2f s (oracle/, 1 thread, same C2 workload)"
-                  % (n_scenes, t1 - t0, t3 - t2),
+        "value": n / wall, "unit": "scenes/s", "cores": threads, "kind": "port",
+        "sample": "%d scenes on %d threads (host has %d cores): settle %.2f s + render %.2f s wall; per scene on one "
+                  "thread: settle %.3f s, render %.3f s (oracle/, same C2 workload)"
+                  % (n, threads, os.cpu_count() or 0, w1 - w0, w3 - w2, sum(t_settle) / n, sum(t_render) / n),
     }
 
 
@@ -342,21 +369,28 @@ def main():
             roof_render["frac"] = roof_render["achieved"] / roof_render["peak"]
         # HBM traffic from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes on
         # the same workload, committed under profiles/): bytes per scene x scenes per launch
-        pmc = os.path.join(ROOT, "profiles", "r01", "render_pmc_b64.json")
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+        pmc_k = {}
         if os.path.exists(pmc):
             with open(pmc) as f:
-                per_scene = json.load(f)["kernels"]["k_shade"]["hbm_bytes_per_scene"]
-            roof_render["traffic"] = per_scene * args.render_chunk
-            roof_render["traffic_source"] = "profiles/r01/render_pmc_b64.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                pmc_k = json.load(f)["kernels"]
+        if "k_shade" in pmc_k:
+            roof_render["traffic"] = pmc_k["k_shade"]["hbm_bytes_per_scene"] * args.render_chunk
+            roof_render["traffic_source"] = "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
             roof_render["algorithmic_bytes_per_launch"] = shade_bytes / n_chunks
         # settle: hull vertices + body state are read once and written once per scene (HBM),
         # everything else lives in LDS/L2: an HBM fraction is reported for completeness only
-        settle_bytes = args.batch * (N_OBJECTS * 240 * 2 + 20 * 64 * 16)
+        # per scene: body records in + out (288 B each), hull records (64 B) and hull vertices (16 B) once
+        hulls_per_scene, verts_per_scene = 68, 1456   # C2 maxima (sizing hints of the batches)
+        settle_bytes = args.batch * (N_OBJECTS * 288 * 2 + hulls_per_scene * 64 + verts_per_scene * 16)
         roof_settle = {
             "bound": "hbm", "kernel": "k_settle", "achieved": settle_bytes / (t_settle * 1e-3) / 1e9, "peak": 8000.0,
-            "unit": "GB/s", "traffic": None,
-            "note": "latency-bound persistent kernel (400 dependent steps/scene in LDS); HBM fraction is not "
-                    "meaningful -- see steps_scenes_per_s",
+            "unit": "GB/s", "traffic": pmc_k["k_settle"]["hbm_bytes_per_scene"] * args.batch if "k_settle" in pmc_k else None,
+            "algorithmic_bytes_per_launch": settle_bytes,
+            "measured": "HIP events around each slhip_settle launch; up to --settle-streams launches share the GPU, "
+                        "so a launch's duration is longer than when it runs alone",
+            "note": "latency-bound persistent kernel (400 dependent steps/scene in LDS, ~10 cycles per dependent "
+                    "instruction); an HBM fraction is not meaningful -- see steps_scenes_per_s",
             "steps_scenes_per_s": args.batch * 400 / (t_settle * 1e-3),
         }
         roof_settle["frac"] = roof_settle["achieved"] / roof_settle["peak"]
