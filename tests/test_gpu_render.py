@@ -197,3 +197,24 @@ def test_batch_equals_single_scene_renders(sl, eng):
         one = eng.render([s], _abi.OUT_ALL, ssao=True, shadows=True)
         for name in ("rgb", "coord", "cls", "instance", "normals", "vertex_idx", "bary", "cam_coord"):
             assert torch.equal(getattr(batch, name)[i], getattr(one, name)[0]), (name, i)
+
+
+def test_c2_bench_workload_end_to_end(sl, oracle, eng):
+    """BASELINE config C2 exactly as bench.py drives it: 20 procedural YCB-like objects (8k vertices /
+    16k triangles, textured) per scene, settled on the GPU, random camera + light, 640x480, shadows +
+    SSAO, auto exposure -- rendered in one launch and compared with the oracle: every geometric
+    output bit for bit (instance mask included), rgb to the 8-bit tolerance."""
+    import bench
+    from stillleben_amd import physics, synthetic
+
+    meshes = synthetic.ycb_like_meshes(seed=0, tex_size=256)
+    scs = [bench.make_scene(sl, meshes, 777 + i) for i in range(3)]
+    physics.settle_batch(scs)
+    for s in scs:
+        s.choose_random_camera_pose()
+        s.choose_random_light_direction()
+    bufs, ref = both(eng, oracle, scs, mask=_abi.OUT_GT6 | _abi.OUT_CAM_COORD)
+    assert (ref.instance != 0).mean() > 0.02   # the heap is small in the YCB camera (f = 1067 px)
+    assert len(np.unique(ref.instance[0])) > 10   # most of the 20 objects are visible
+    assert_geometry_equal(bufs, ref, mask=_abi.OUT_GT6 | _abi.OUT_CAM_COORD)
+    assert_rgb_close(bufs, ref)
