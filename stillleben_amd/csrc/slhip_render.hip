@@ -1156,8 +1156,10 @@ __device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, 
     y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
     // `img` is the compact camera-z plane written by k_shade (same values as channel 2 of the
     // camCoordinates target, 4 B/px instead of 16 B/px: the 64-tap gather stays L2 resident)
-    const float a = img[(size_t)y0 * W + x0], b = img[(size_t)y0 * W + x1];
-    const float c = img[(size_t)y1 * W + x0], d = img[(size_t)y1 * W + x1];
+    // 32-bit offsets from the (wave-uniform) plane base: one scalar base + one VGPR offset per load
+    const unsigned r0 = (unsigned)y0 * (unsigned)W, r1 = (unsigned)y1 * (unsigned)W;
+    const float a = img[r0 + (unsigned)x0], b = img[r0 + (unsigned)x1];
+    const float c = img[r1 + (unsigned)x0], d = img[r1 + (unsigned)x1];
     const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - c, c);
     return fmaf(ay, bot - top, top);
 }
@@ -1202,9 +1204,17 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
         const float ox = (off[0] / off[3]) * 0.5f + 0.5f;
         const float oy = (off[1] / off[3]) * 0.5f + 0.5f;
         const float sd = rect_bilinear_z(camS, W, H, ox * (float)W, oy * (float)H);
-        const float tt = clampf(radius / fabsf(frag[2] - sd), 0.0f, 1.0f);
-        const float rc = tt * tt * (3.0f - 2.0f * tt);
-        occlusion += (sd <= sp[2] - bias ? 1.0f : 0.0f) * rc;
+        // range check smoothstep(clamp(radius / |dz|)): exactly 1 whenever |dz| <= radius, and
+        // irrelevant for taps that do not occlude -- the division runs only where it matters
+        // (on open surfaces whole waves skip it)
+        const bool occludes = sd <= sp[2] - bias;
+        const float adz = fabsf(frag[2] - sd);
+        float rc = 1.0f;
+        if (occludes && adz > radius) {
+            const float tt = clampf(radius / adz, 0.0f, 1.0f);
+            rc = tt * tt * (3.0f - 2.0f * tt);
+        }
+        occlusion += occludes ? rc : 0.0f;
     }
     ao[gp] = 1.0f - occlusion / 64.0f;
 }
@@ -1225,13 +1235,37 @@ __global__ __launch_bounds__(256) void k_ssao_apply(unsigned n_scenes, int W, in
     const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
     const float sigma = 3.0f * 0.5f;
     const float falloff = 1.0f / (2.0f * sigma * sigma);
-    const float cd = rect_bilinear_z(camS, W, H, (float)i, (float)j);
+    // The 16 taps (and the centre) sample the z plane at integer coordinates of a LINEAR rect
+    // sampler, i.e. at the corner between 4 texels with weights exactly 1/2: together they touch
+    // the 5x5 texels around (i-3..i+1, j-3..j+1) (clamped).  Fetch them once; every tap is then
+    // rect_bilinear_z()'s arithmetic on registers.
+    unsigned rowo[5];
+    int colx[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        colx[k] = min(max(i - 3 + k, 0), W - 1);
+        rowo[k] = (unsigned)min(max(j - 3 + k, 0), H - 1) * (unsigned)W;
+    }
+    float z[5][5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) z[r][c] = camS[rowo[r] + (unsigned)colx[c]];
+    // corner value at (i + x, j + y), x, y in -2..1: texels (i+x-1, i+x) x (j+y-1, j+y) = window [y+2..y+3][x+2..x+3]
+    auto corner = [&](int x, int y) {
+        const float a = z[y + 2][x + 2], b = z[y + 2][x + 3], c = z[y + 3][x + 2], d = z[y + 3][x + 3];
+        const float top = fmaf(0.5f, b - a, a), bot = fmaf(0.5f, d - c, c);
+        return fmaf(0.5f, bot - top, top);
+    };
+    const float cd = corner(0, 0);
     float result = 0.0f, wt = 0.0f;
+#pragma unroll
     for (int x = -2; x < 2; ++x)
+#pragma unroll
         for (int y = -2; y < 2; ++y) {
             const int xi = min(max(i + x, 0), W - 1), yj = min(max(j + y, 0), H - 1);
-            const float c = aoS[(size_t)yj * W + xi];
-            const float dz = rect_bilinear_z(camS, W, H, (float)(i + x), (float)(j + y));
+            const float c = aoS[(unsigned)yj * (unsigned)W + (unsigned)xi];
+            const float dz = corner(x, y);
             const float r = sqrtf((float)(x * x + y * y));
             const float dd = (dz - cd) * 300.0f;
             const float w = exp2f(-r * r * falloff - dd * dd);
