@@ -76,6 +76,8 @@ class Pipeline:
         self.s_settle = [torch.cuda.Stream(device=self.eng.device)]
         self.s_render = torch.cuda.Stream(device=self.eng.device)
         self.render_chunk = 128
+        self.gatherer = None      # N > 1: BatchGatherer, one asynchronous RCCL all-gather per rendered chunk
+        self.pending = {}         # chunk slot -> outstanding collectives reading that slot's render buffers
         self.t_step_host = []
         self.t_settle = []
         self.t_host = []
@@ -148,6 +150,8 @@ class Pipeline:
                 s0 = ci * self.render_chunk
                 s1 = s0 + t.n_scenes
                 o0, o1 = item["obj_off"][s0], item["obj_off"][s1]
+                for w in self.pending.pop(ci, []):
+                    w.wait()      # stream-level: this slot's previous gather must finish before it is re-rendered
                 th0 = time.perf_counter()
                 cam = FB.camera_poses(t, poses[o0:o1], item["az"][s0:s1], item["el"][s0:s1])
                 ld = FB.light_directions(cam, item["nrm"][s0:s1])
@@ -158,6 +162,11 @@ class Pipeline:
                 buf = self.eng.render_records(srec, drec, t.crec, W, H, self.mask, ssao=self.ssao, shadows=True,
                                               buffers=self.buffers[ci] if ci < len(self.buffers) else None)
                 e1.record()
+                if self.gatherer is not None:
+                    # ordered after the chunk's kernels, runs on RCCL's stream while the next chunks render
+                    _, works = self.gatherer([t for t in (buf.rgb, buf.coord, buf.cls, buf.instance, buf.normals)
+                                              if t is not None], async_op=True)
+                    self.pending[ci] = works
                 if ci >= len(self.buffers):
                     self.buffers.append(buf)
                 outs.append(buf)
@@ -251,8 +260,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("SLHIP_BENCH_ONE_DEVICE"):
+            # developer hook: exercise the N > 1 code path on a 1-GPU box (all ranks on cuda:0, gloo
+            # moves the bytes through the host) -- functional check only, never a measurement
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import stillleben_amd as sl
     from stillleben_amd import _settle_batch as SB
@@ -278,13 +294,10 @@ def main():
 
     from stillleben_amd.parallel import BatchGatherer
 
-    gatherer = BatchGatherer(dist, world)
-
-    def gather(outs):
-        # RCCL all-gather of the rendered batches, one collective per dtype buffer and chunk
-        if dist is None:
-            return
-        gatherer([t for b in outs for t in (b.rgb, b.coord, b.cls, b.instance, b.normals) if t is not None])
+    if dist is not None:
+        # every rank receives every rendered chunk: RCCL all-gather per dtype buffer into a ring of
+        # [world, chunk, ...] staging buffers, overlapped with the rendering of the following chunks
+        pipe.gatherer = BatchGatherer(dist, world, depth=2)
 
     def run(seq, timed):
         """Software pipeline over a sequence of batches: while the GPU settles batch k+1 (settle
@@ -298,10 +311,11 @@ def main():
         for k in range(len(seq)):
             if k + ahead < len(seq):
                 pipe.launch_settle(seq[k + ahead], (k + ahead) % ahead)
-            outs = pipe.finish(seq[k], timed)
-            if dist is not None:
-                pipe.s_render.synchronize()
-                gather(outs)
+            pipe.finish(seq[k], timed)
+        for works in pipe.pending.values():
+            for w in works:
+                w.wait()
+        pipe.pending.clear()
         torch.cuda.synchronize()
 
     run(items[:args.warmup], False)

@@ -17,20 +17,44 @@ def shard_scenes(n_scenes, rank, world):
 
 
 class BatchGatherer:
-    """all_gather_into_tensor of a list of per-rank tensors into persistent [world, ...] buffers."""
+    """all_gather_into_tensor of a list of per-rank tensors into a small ring of persistent
+    [world, ...] staging buffers (`depth` sets per distinct shape signature).
 
-    def __init__(self, dist, world):
-        self.dist, self.world = dist, world
-        self.buffers = None
+    Synchronous use: ``views = gather(tensors)``.
+    Overlapped use (bench.py): ``views, works = gather(tensors, async_op=True)`` right after the
+    producer kernels were enqueued on the current stream -- the collective is ordered after them on
+    RCCL's own stream; call ``w.wait()`` on the stream that will overwrite `tensors` (or read the
+    views) to order that stream after the collective.  Collectives are issued in program order, which
+    is the same on every rank.  A staging set is reused after `depth` further calls with the same
+    shapes; consumers read it before that (the collectives themselves are serialised on the RCCL
+    stream, so a reuse never races with an earlier gather into the same set)."""
 
-    def __call__(self, tensors):
-        if self.dist is None or self.world == 1:
-            return [t.unsqueeze(0) for t in tensors]
-        if self.buffers is None:
+    def __init__(self, dist, world, depth=2):
+        self.dist, self.world, self.depth = dist, world, max(1, int(depth))
+        self.rings = {}
+
+    def _staging(self, tensors):
+        key = tuple((tuple(t.shape), t.dtype, str(t.device)) for t in tensors)
+        ring = self.rings.get(key)
+        if ring is None:
             # concatenated layout [world * B, ...] (accepted by both RCCL and gloo), viewed as [world, B, ...]
-            self.buffers = [torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-                            for t in tensors]
-        for t, g in zip(tensors, self.buffers):
+            ring = {"next": 0, "sets": [[torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
+                                                     device=t.device) for t in tensors] for _ in range(self.depth)]}
+            self.rings[key] = ring
+        bufs = ring["sets"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % self.depth
+        return bufs
+
+    def __call__(self, tensors, async_op=False):
+        if self.dist is None or self.world == 1:
+            views = [t.unsqueeze(0) for t in tensors]
+            return (views, []) if async_op else views
+        bufs = self._staging(tensors)
+        works = []
+        for t, g in zip(tensors, bufs):
             # an all-gather is type-agnostic: move bytes (RCCL/gloo have no int16 datatype)
-            self.dist.all_gather_into_tensor(g.view(torch.uint8), t.contiguous().view(torch.uint8))
-        return [g.view((self.world, -1) + tuple(g.shape[1:])) for g in self.buffers]
+            w = self.dist.all_gather_into_tensor(g.view(torch.uint8), t.contiguous().view(torch.uint8), async_op=async_op)
+            if async_op:
+                works.append(w)
+        views = [g.view((self.world, -1) + tuple(g.shape[1:])) for g in bufs]
+        return (views, works) if async_op else views

@@ -33,6 +33,21 @@ def _worker(rank, world, port, q):
             exp = _fake_batch(parallel.shard_seeds(r, world, n_items, batch)[k])
             for a, b in zip(allb, exp):
                 ok = ok and torch.equal(a[r], b)
+    # overlapped form used by bench.py: asynchronous collectives into a 2-deep staging ring; the
+    # third call reuses the first set, the views of the last `depth` calls stay valid
+    agather = parallel.BatchGatherer(dist, world, depth=2)
+    keep = []
+    for k in range(n_items):
+        views, works = agather(_fake_batch(seeds[k]), async_op=True)
+        for w in works:
+            w.wait()
+        keep.append(views)
+    ok = ok and keep[0][0].data_ptr() == keep[2][0].data_ptr() and keep[0][0].data_ptr() != keep[1][0].data_ptr()
+    for k in (1, 2):
+        for r in range(world):
+            exp = _fake_batch(parallel.shard_seeds(r, world, n_items, batch)[k])
+            for a, b in zip(keep[k], exp):
+                ok = ok and torch.equal(a[r], b)
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
