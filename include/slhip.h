@@ -309,6 +309,32 @@ int slhip_diff_pose_backward(const uint8_t* d_rgb, const float* d_coord, const i
                              double* d_acc, float* d_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Camera model ('next' row f4 of SURVEY.md 8f): the step after the render in every data-generation
+ * loop.  Replaces python/stillleben/camera_model.py:222-263 (process_deterministic): chromatic
+ * aberration (:47-74, affine_grid + bilinear grid_sample, reflection padding) -> 5x5 Gaussian blur
+ * (:77-118, zero padding) -> re-exposure (:120-130) -> Poissonian-Gaussian noise (:132-163) ->
+ * clamp -> hue jitter (:165-220) -> 5x5 post blur (sigma 0.4) -> clamp, fused into two kernels.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float translation[6];   /* (tx, ty) of R, G, B in normalised [-1,1] image coordinates          */
+    float scaling[3];       /* scale of R, G, B                                                    */
+    float blur_kernel[25];  /* 5x5 weights of the first blur, row-major (camera_model.py:77-104);
+                               used when blur_enabled                                             */
+    float post_kernel[25];  /* 5x5 weights of the post blur (sigma = 0.4)                          */
+    float exposure_gain;    /* exp(deltaS), rounded to f32 (camera_model.py:130)                   */
+    float noise_a, noise_b; /* signal-dependent variance factor, signal-independent std            */
+    float hue_shift;        /* -0.5 .. 0.5                                                         */
+    uint32_t blur_enabled;  /* blur_sigma > 0                                                      */
+    uint32_t noise_enabled; /* do_noise                                                            */
+    uint32_t seed_lo, seed_hi; /* counter-based RNG key of this image (noise stage)               */
+} slhip_camera_params;      /* 268 bytes */
+
+/* d_in / d_out: f32 [n_images, 3, H, W] (the reference's CHW layout, values in [0,1]); d_tmp:
+ * scratch of the same size; d_params: DEVICE array of n_images records.  d_out may alias d_in.   */
+int slhip_camera_model(const float* d_in, float* d_out, float* d_tmp, uint32_t n_images, int H, int W,
+                       const slhip_camera_params* d_params, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Library
  * ------------------------------------------------------------------------------------------- */
 int slhip_abi_version(void);

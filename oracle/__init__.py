@@ -191,3 +191,20 @@ def apply_pose_delta(pose, delta, orthonormalize=True):
             u, _, vt = np.linalg.svd(out[b, :3, :3].astype(np.float64))
             out[b, :3, :3] = (u @ vt).astype(np.float32)
     return out
+
+
+def camera_model(rgb, params, stage=4):
+    """Deterministic stages of the camera model (oracle/camera_ref.c).  rgb f32[B,3,H,W], params =
+    array of stillleben_amd._abi.CAMERA_DTYPE records; stage 0..4 (see camera_ref.c)."""
+    from stillleben_amd import _abi
+
+    L = lib()
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    B, _, H, W = rgb.shape
+    rec = np.ascontiguousarray(np.asarray(params, dtype=_abi.CAMERA_DTYPE).reshape(B))
+    out, tmp = np.zeros_like(rgb), np.zeros_like(rgb)
+    L.slref_camera_model.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    st = L.slref_camera_model(_p(rgb), _p(out), _p(tmp), B, H, W, _p(rec), int(stage))
+    if st != 0:
+        raise ValueError("oracle.camera_model: the random noise stage is not restated")
+    return out

@@ -128,6 +128,15 @@ class RenderScratch(C.Structure):
 
 
 _LIB = None
+# slhip_camera_params (include/slhip.h), 268 bytes
+CAMERA_DTYPE = np.dtype([
+    ("translation", np.float32, (6,)), ("scaling", np.float32, (3,)),
+    ("blur_kernel", np.float32, (25,)), ("post_kernel", np.float32, (25,)),
+    ("exposure_gain", np.float32), ("noise_a", np.float32), ("noise_b", np.float32), ("hue_shift", np.float32),
+    ("blur_enabled", np.uint32), ("noise_enabled", np.uint32), ("seed_lo", np.uint32), ("seed_hi", np.uint32),
+])
+assert CAMERA_DTYPE.itemsize == 268
+
 # SLHIP_LIB selects another build of the same library (developer A/B runs); there is no fallback
 _LIB_PATH = os.environ.get("SLHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libslhip.so")
 
@@ -172,6 +181,7 @@ def lib():
                                C.c_void_p, C.c_uint64, C.c_void_p]
     L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.POINTER(C.c_uint64)]
     L.slhip_overlap_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slhip_camera_model.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     _LIB = L
     return L
 
