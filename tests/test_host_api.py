@@ -92,27 +92,104 @@ def test_object_and_scene_rules(sl):
 
 
 def test_serialization_round_trip(sl):
-    # basic.cpp:309-373
+    # basic.cpp:309-373, step by step
     m = sl.Mesh(S.BUNNY, physics=False)
-    m.center_bbox()
-    m.scale_to_bbox_diagonal(0.5)
     scene = sl.Scene((640, 480))
     o = sl.Object(m)
+    distance = scene.min_dist_for_object_diameter(float(m.bbox.diagonal))
+    pose = torch.eye(4)
+    pose[2, 3] = distance
+    o.set_pose(pose)
     o.instance_index = 15
     scene.add_object(o)
-    pose = torch.eye(4)
-    pose[2, 3] = 0.5
-    o.set_pose(pose)
+    scene.set_camera_look_at([0.3, -0.2, 0.5], [0.0, 0.1, 0.0])
+    scene.light_directions = torch.tensor([[0.1, -0.4, -0.9], [0.5, 0.5, -0.2]])
+    scene.light_colors = torch.tensor([[300.0, 290.0, 280.0], [10.0, 20.0, 30.0]])
     text = scene.serialize()
-    cache = sl.MeshCache()
-    cache.add(m)
-    s2 = sl.Scene((320, 240))
-    s2.deserialize(text, cache)
-    assert s2.viewport == (640, 480)
-    o2 = s2.objects[0]
-    assert o2.mesh is m and o2.instance_index == 15
-    assert (o2.pose() - o.pose()).norm() < 1e-9
-    assert (o2.mesh.pretransform - m.pretransform).norm() < 1e-5
+    cache = sl.MeshCache()     # empty, as in the reference test: the mesh is loaded from its file name
+    s0 = sl.Scene((640, 480))
+    s0.deserialize(text, cache)
+    assert len(s0.objects) == 1
+    o0 = s0.objects[0]
+    assert float(o0.mesh._scale) == float(m._scale)
+    assert (o0.mesh.pretransform - m.pretransform).norm() < 1e-5
+    t = o0.pose()[:3, 3]
+    assert t[0] == 0 and t[1] == 0 and abs(float(t[2]) - distance) < 1e-6
+    assert o0.instance_index == 15
+    assert torch.equal(o0.pose(), o.pose())                        # 9 significant digits: exact
+    assert torch.allclose(s0.camera_pose(), scene.camera_pose(), atol=1e-6)
+    assert torch.equal(s0.light_directions, scene.light_directions) and torch.equal(s0.light_colors, scene.light_colors)
+    assert torch.equal(s0.projection_matrix(), scene.projection_matrix())
+    # cache functionality: a second scene shares the mesh object
+    s1 = sl.Scene((640, 480))
+    s1.deserialize(text, cache)
+    assert len(s1.objects) == 1 and s1.objects[0].mesh is o0.mesh
+
+
+def test_serialization_document_structure(sl):
+    """The document is the reference's: keys and order of scene.cpp:761-796 / object.cpp:384-406 /
+    mesh.cpp:1091-1097, values before sub-groups, [light] x 3, [object] + [object/mesh]."""
+    from stillleben_amd import serialization
+
+    m = sl.Mesh(S.CUBE, physics=False)
+    scene = sl.Scene((320, 240))
+    for k in range(2):
+        ob = sl.Object(m)
+        ob.static = k == 1
+        scene.add_object(ob)
+    doc = serialization.to_document(scene)
+    assert [k for k, _ in doc.values] == ["viewport", "projection", "cameraPosition", "cameraRotation", "ambientLight",
+                                          "numObjects", "backgroundPlanePose", "backgroundPlaneSize", "manualExposure"]
+    assert [n for n, _ in doc.groups] == ["light"] * 3 + ["object"] * 2
+    og = doc.groups_named("object")[1]
+    assert [k for k, _ in og.values] == ["pose", "instanceIndex", "specularColor", "shininess", "roughness", "metallic",
+                                         "casts_shadows", "stickerRange", "stickerRotation", "static", "density",
+                                         "linear_velocity_limit"]
+    assert og.value("static") == "true" and doc.value("numObjects") == "2" and doc.value("viewport") == "320 240"
+    assert [k for k, _ in og.group("mesh").values] == ["filename", "classIndex", "scale", "rigidPretransform"]
+    lines = scene.serialize().splitlines()
+    assert lines.index("[object]") < lines.index("[object/mesh]") and lines[0].startswith("viewport=")
+    # a Matrix4 is written row by row: the translation of a pose sits at positions 3, 7, 11
+    ob = scene.objects[0]
+    pose = torch.eye(4)
+    pose[0, 3], pose[1, 3], pose[2, 3] = 1.0, 2.0, 3.0
+    ob.set_pose(pose)
+    vals = serialization.to_document(scene).groups_named("object")[0].value("pose").split()
+    assert [vals[3], vals[7], vals[11]] == ["1", "2", "3"]
+
+
+def test_deserialize_reference_style_document(sl):
+    """A document as the reference writes it (6 significant digits, its key spelling) plus the legacy
+    `lightPosition` form (scene.cpp:817-821)."""
+    text = "\n".join([
+        "viewport=640 480",
+        "cameraPosition=0 0 0",
+        "cameraRotation=0 0 0 1",
+        "lightPosition=0 0 2",
+        "ambientLight=0.1 0.2 0.3",
+        "numObjects=1",
+        "manualExposure=1.5",
+        "[object]",
+        "pose=1 0 0 0.25 0 1 0 -0.5 0 0 1 1.75 0 0 0 1",
+        "instanceIndex=7",
+        "static=true",
+        "linearVelocityLimit=2.5",
+        "[object/mesh]",
+        "filename=" + S.CUBE,
+        "classIndex=3",
+        "scale=0.1",
+        "rigidPretransform=1 0 0 -0.5 0 1 0 0 0 0 1 0 0 0 0 1",
+    ]) + "\n"
+    scene = sl.Scene((64, 48))
+    scene.deserialize(text)
+    assert scene.viewport == (640, 480) and scene.manual_exposure == 1.5
+    ob = scene.objects[0]
+    assert ob.instance_index == 7 and ob.static and ob.mesh.class_index == 3
+    assert torch.allclose(ob.pose()[:3, 3], torch.tensor([0.25, -0.5, 1.75]))
+    assert abs(float(ob._linear_velocity_limit) - 2.5) < 1e-7
+    assert abs(float(ob.mesh.pretransform[0, 3]) - (-0.05)) < 1e-7       # scale * rigid translation
+    assert torch.allclose(scene.light_directions[0], torch.tensor([0.0, 0.0, -1.0]))
+    assert torch.allclose(scene.light_colors[0], torch.tensor([0.0, 0.8, 0.0]))
 
 
 def test_quaternion_helpers_and_alias_package(sl):
