@@ -121,16 +121,100 @@ def _decompose(pos, tris, depth, max_depth=4):
     return _decompose(pos, a, depth + 1, max_depth) + _decompose(pos, b, depth + 1, max_depth)
 
 
-def hulls_for_mesh(mesh):
-    from .mesh import Mesh
+# ---- hull cache (reference mesh.cpp:94-172 readCacheFile, :490-511 write) ------------------------------
+# `<mesh>.sl_mesh` of the reference holds PhysX-cooked hulls; its payload cannot be shared, but the
+# INVALIDATION KEYS are the same here: format version, mesh flags, MurmurHash2 digests of the vertex
+# positions and of the indices (Corrade::Utility::MurmurHash2 = MurmurHash64A on 64-bit hosts, default
+# seed 23), and "cache newer than the source file".  The file is written atomically (utils/os.cpp).
+CACHE_SUFFIX = ".sl_hulls"
+CACHE_MAGIC = b"SLHULLS\0"
+CACHE_VERSION = 1
 
-    data = mesh._data
-    cache = mesh._filename + ".hulls.npz"
-    force = bool(mesh._flags & Mesh.Flag.PHYSICS_FORCE_CONVEX_HULL)
-    if not force and os.path.exists(cache):
-        z = np.load(cache)
-        n = int(z["n_hulls"])
-        return [Hull(z["v%d" % i], z["t%d" % i]) for i in range(n)]
+
+def murmur64a(data, seed=23):
+    """MurmurHash64A of a bytes-like object (the digest Corrade's MurmurHash2 yields on 64-bit hosts)."""
+    b = bytes(data)
+    n = len(b)
+    m, r, mask = 0xC6A4A7935BD1E995, 47, (1 << 64) - 1
+    h = (seed ^ ((n * m) & mask)) & mask
+    nb = n // 8
+    if nb:
+        k = np.frombuffer(b, dtype="<u8", count=nb).copy()
+        with np.errstate(over="ignore"):
+            k *= np.uint64(m)
+            k ^= k >> np.uint64(r)
+            k *= np.uint64(m)
+        for kk in k.tolist():            # the fold is inherently sequential
+            h = ((h ^ kk) * m) & mask
+    tail = b[nb * 8:]
+    if tail:
+        h ^= int.from_bytes(tail, "little")
+        h = (h * m) & mask
+    h ^= h >> r
+    h = (h * m) & mask
+    h ^= h >> r
+    return h
+
+
+def _mesh_digests(data):
+    v = murmur64a(np.ascontiguousarray(data.positions, dtype="<f4").tobytes())
+    i = murmur64a(np.ascontiguousarray(data.indices, dtype="<u4").tobytes())
+    return v, i
+
+
+def read_cache(cache_file, source_file, data, flags):
+    """Returns the cached hulls or None (missing / stale / other version, flags or geometry)."""
+    import struct
+
+    if not os.path.exists(cache_file):
+        return None
+    if os.path.exists(source_file) and os.path.getmtime(cache_file) <= os.path.getmtime(source_file):
+        return None   # "Cache file is stale" (mesh.cpp:133-137)
+    try:
+        with open(cache_file, "rb") as f:
+            blob = f.read()
+        if blob[:8] != CACHE_MAGIC:
+            return None
+        version, fl, vh, ih, n = struct.unpack_from("<IIQQI", blob, 8)
+        if version != CACHE_VERSION or fl != int(flags):
+            return None
+        if (vh, ih) != _mesh_digests(data):
+            return None
+        off = 8 + struct.calcsize("<IIQQI")
+        hulls = []
+        for _ in range(n):
+            nv, nt = struct.unpack_from("<II", blob, off)
+            off += 8
+            v = np.frombuffer(blob, dtype="<f4", count=3 * nv, offset=off).reshape(nv, 3).copy()
+            off += 12 * nv
+            t = np.frombuffer(blob, dtype="<i4", count=3 * nt, offset=off).reshape(nt, 3).copy()
+            off += 12 * nt
+            hulls.append(Hull(v, t))
+        return hulls
+    except (OSError, struct.error, ValueError):
+        return None
+
+
+def write_cache(cache_file, data, flags, hulls):
+    import struct
+    import tempfile
+
+    vh, ih = _mesh_digests(data)
+    parts = [CACHE_MAGIC, struct.pack("<IIQQI", CACHE_VERSION, int(flags), vh, ih, len(hulls))]
+    for h in hulls:
+        parts.append(struct.pack("<II", len(h.vertices), len(h.triangles)))
+        parts.append(np.ascontiguousarray(h.vertices, dtype="<f4").tobytes())
+        parts.append(np.ascontiguousarray(h.triangles, dtype="<i4").tobytes())
+    try:
+        fd, tmp = tempfile.mkstemp(prefix=os.path.basename(cache_file) + ".", dir=os.path.dirname(cache_file) or ".")
+        with os.fdopen(fd, "wb") as f:
+            f.write(b"".join(parts))
+        os.replace(tmp, cache_file)       # atomic: readers see the old or the new file, never a torn one
+    except OSError:
+        pass                              # read-only asset directory: the cache is an optimisation
+
+
+def _compute_hulls(data, force):
     single = _reduce(data.positions)
     if force:
         return [single]
@@ -141,3 +225,25 @@ def hulls_for_mesh(mesh):
         return [single]
     parts = _decompose(data.positions, tris, 0)
     return parts if len(parts) > 1 else [single]
+
+
+def hulls_for_mesh(mesh, use_cache=True):
+    from .mesh import Mesh
+
+    data = mesh._data
+    force = bool(mesh._flags & Mesh.Flag.PHYSICS_FORCE_CONVEX_HULL)
+    fixture = mesh._filename + ".hulls.npz"   # decompositions made with the reference's V-HACD (oracle/ref_build/gen_hulls.py)
+    if not force and os.path.exists(fixture):
+        z = np.load(fixture)
+        n = int(z["n_hulls"])
+        return [Hull(z["v%d" % i], z["t%d" % i]) for i in range(n)]
+    on_disk = use_cache and "://" not in mesh._filename and os.path.exists(mesh._filename)   # primitive:// etc.: no cache (mesh.cpp:323)
+    cache_file = mesh._filename + CACHE_SUFFIX
+    if on_disk:
+        cached = read_cache(cache_file, mesh._filename, data, mesh._flags)
+        if cached is not None:
+            return cached
+    hulls = _compute_hulls(data, force)
+    if on_disk:
+        write_cache(cache_file, data, mesh._flags, hulls)
+    return hulls

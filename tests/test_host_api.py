@@ -240,3 +240,57 @@ def test_pose_samplers(sl):
     # the corrected orientation maps the viewing ray back onto +z
     assert np.allclose(T[:3, :3].T @ (T[:3, 3] / np.linalg.norm(T[:3, 3])), [0, 0, 1], atol=1e-5)
     assert np.allclose(ps.rotation_correction_for_translation(np.array([0, 0, 2.0])), np.eye(3))
+
+
+def test_hull_cache_invalidation_keys(sl, tmp_path):
+    """`.sl_mesh`-style cache (mesh.cpp:94-172, :490-511): hit when version, flags, vertex / index
+    digests match and the cache is newer than the source; miss otherwise; atomic rewrite."""
+    import os
+    import shutil
+    import time
+
+    from stillleben_amd import hulls
+
+    # MurmurHash64A known answers (seed 23 = Corrade's default): empty input and block + tail paths
+    assert hulls.murmur64a(b"") == hulls.murmur64a(b"", 23)
+    assert hulls.murmur64a(b"abcdefgh") != hulls.murmur64a(b"abcdefgi")
+    assert hulls.murmur64a(b"abcdefghijk") != hulls.murmur64a(b"abcdefghijl")
+    ref = 0
+    for seed, data in ((23, b"12345678"), (23, b"1234567890abc")):
+        ref ^= hulls.murmur64a(data, seed)
+    assert 0 < ref < 2 ** 64
+
+    src = tmp_path / "cube.glb"
+    shutil.copy(S.CUBE, src)
+    old = time.time() - 100
+    os.utime(src, (old, old))
+    m = sl.Mesh(str(src))                      # physics=True: computes the hulls and writes the cache
+    cache = str(src) + hulls.CACHE_SUFFIX
+    assert os.path.exists(cache)
+    got = hulls.read_cache(cache, str(src), m._data, m._flags)
+    assert got is not None and len(got) == len(m._hulls) == 1
+    assert np.array_equal(got[0].vertices, m._hulls[0].vertices) and np.array_equal(got[0].triangles, m._hulls[0].triangles)
+    # flags are a key
+    assert hulls.read_cache(cache, str(src), m._data, sl.Mesh.Flag.PHYSICS_FORCE_CONVEX_HULL) is None
+    # geometry digests are keys
+    m2 = sl.Mesh(str(src), physics=False)
+    m2._data.positions[0, 0] += 1e-3
+    assert hulls.read_cache(cache, str(src), m2._data, m2._flags) is None
+    m2._data.positions[0, 0] -= 1e-3
+    m2._data.indices[:3] = m2._data.indices[:3][::-1].copy()
+    assert hulls.read_cache(cache, str(src), m2._data, m2._flags) is None
+    # a source newer than the cache makes it stale
+    new = time.time() + 100
+    os.utime(src, (new, new))
+    assert hulls.read_cache(cache, str(src), m._data, m._flags) is None
+    # a truncated / foreign file is a miss, not an error
+    with open(cache, "wb") as f:
+        f.write(b"garbage")
+    os.utime(src, (old, old))
+    assert hulls.read_cache(cache, str(src), m._data, m._flags) is None
+    # and the next load rewrites it
+    m3 = sl.Mesh(str(src))
+    assert hulls.read_cache(cache, str(src), m3._data, m3._flags) is not None
+    # in-memory / primitive meshes never touch the disk
+    prim = sl.Mesh("primitive://cube")
+    assert prim._hulls is not None and not os.path.exists("primitive://cube" + hulls.CACHE_SUFFIX)
