@@ -249,7 +249,9 @@ typedef struct {
     int32_t stuck_frames;        /* 10 = 0.4 s * 25 FPS (scene.cpp:750)                       */
     uint32_t tabletop;           /* 1: run the redrop logic of simulateTableTopScene          */
     /* LDS sizing hints for the kernel (0 = worst case / hull vertices stay in global memory):
-       maxima over the scenes of the batch                                                   */
+       maxima over the scenes of the batch.  A scene that exceeds a non-zero hint (or has more
+       than 1024 hulls in one body) is left untouched by the launch -- the kernel never writes
+       outside the layout the hints sized.                                                     */
     uint32_t max_bodies_per_scene;
     uint32_t max_hull_verts_per_scene;   /* sum over a scene's bodies of their hull vertices  */
     uint32_t max_hulls_per_scene;

@@ -1,0 +1,137 @@
+"""Edge cases of the hot path on the GPU, each compared with the oracle: empty and ragged inputs,
+odd viewports, the documented caps (64 bodies, 512 candidate hull pairs, 160 solver contacts), scenes
+too large for the 8-per-CU LDS share, and the loud error paths of the C-ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import scenes as S
+from stillleben_amd import _abi
+from stillleben_amd import _settle_batch as SB
+from test_gpu_render import assert_geometry_equal, assert_rgb_close, both
+from test_gpu_settle import assert_bodies_equal, heap, run_both, scaled
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(sl):
+    from stillleben_amd._context import engine
+
+    return engine()
+
+
+# ---- render ---------------------------------------------------------------------------------------
+def test_empty_scene_and_ragged_batch(sl, oracle, eng):
+    """A scene without objects renders the clear values; a batch mixes it with populated scenes."""
+    empty = sl.Scene((160, 120))
+    full = S.clutter_scene(sl, 3, n_objects=4, size=(160, 120))
+    one = S.clutter_scene(sl, 4, n_objects=1, size=(160, 120))
+    bufs, ref = both(eng, oracle, [empty, full, one, sl.Scene((160, 120))])
+    assert_geometry_equal(bufs, ref)
+    assert_rgb_close(bufs, ref)
+    inst = bufs.instance.cpu().numpy()
+    assert (inst[0] == 0).all() and (inst[3] == 0).all() and (inst[1] != 0).any()
+    coord = bufs.coord.cpu().numpy()
+    assert (coord[0] == 3000.0).all()                      # render_pass.cpp:316 clear value
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (333, 97), (641, 479)])
+def test_odd_viewports(sl, oracle, eng, size):
+    scene = S.clutter_scene(sl, 9, n_objects=3, size=size)
+    bufs, ref = both(eng, oracle, [scene])
+    assert_geometry_equal(bufs, ref)
+    assert_rgb_close(bufs, ref)
+
+
+def test_render_rejects_mixed_viewports_and_missing_library_state(sl, eng):
+    with pytest.raises(ValueError):
+        eng.render([sl.Scene((64, 48)), sl.Scene((32, 24))])
+    L = _abi.lib()
+    # null arguments are refused with an error string, not a crash
+    assert L.slhip_settle(None, 1, None, None, None, None, None, 0, None) != 0
+    assert b"null" in L.slhip_last_error()
+    assert L.slhip_camera_model(None, None, None, 1, 4, 4, None, None) != 0
+
+
+# ---- settle ---------------------------------------------------------------------------------------
+def test_empty_and_single_body_scenes(sl, oracle):
+    cube = scaled(sl, S.CUBE, 0.2)
+    empty = sl.Scene((64, 48), seed=1)
+    single = heap(sl, 2, 1, cube)
+    gpu, ref = run_both(oracle, [empty, single, sl.Scene((64, 48), seed=3), heap(sl, 4, 2, cube)], frames=40)
+    assert_bodies_equal(gpu, ref)
+    assert len(gpu) == 3
+
+
+def test_maximum_body_count_and_contact_caps(sl, oracle):
+    """64 bodies (SLHIP_MAX_BODIES) dropped as one heap: the candidate hull-pair list and the solver
+    contact list run into their caps (512 / 160); the drop rules are part of the contract and the
+    GPU must apply them exactly like the oracle.  The LDS share of such a scene exceeds 20 KB, so
+    fewer than 8 scenes are resident per CU."""
+    cube = scaled(sl, S.CUBE, 0.12)
+    bunny = scaled(sl, S.BUNNY, 0.15)           # 121 hulls each
+    big = heap(sl, 11, 64, cube, bunny)
+    small = heap(sl, 12, 3, cube)
+    gpu, ref = run_both(oracle, [big, small], frames=12)
+    assert_bodies_equal(gpu, ref)
+
+
+def test_more_than_64_bodies_is_refused(sl):
+    from stillleben_amd import physics
+
+    cube = scaled(sl, S.CUBE, 0.1)
+    scene = heap(sl, 5, 65, cube)
+    se = physics.settle_engine()
+    with pytest.raises(RuntimeError) as e:          # the host refuses before anything is launched
+        SB.build_settle_batch([scene], se.pool, [(True, 0.04)])
+    assert "64" in str(e.value)
+    # and the C-ABI refuses a hand-made oversized scene as well
+    ok = heap(sl, 6, 2, cube)
+    srec, bodies = SB.build_settle_batch([ok], se.pool, [(True, 0.04)])
+    prm = SB.default_params(frames=1)
+    prm["max_bodies_per_scene"] = 65
+    L = _abi.lib()
+    d = se.eng.upload_records(bodies)
+    d_s = se.eng.upload_records(srec)
+    hulls_d, verts_d = se.hulls_dev()
+    scr = se.scratch(1, 0)
+    st = L.slhip_settle(C.c_void_p(d_s.data_ptr()), 1, C.c_void_p(d.data_ptr()), C.c_void_p(hulls_d.data_ptr()),
+                        C.c_void_p(verts_d.data_ptr()), C.c_void_p(np.ascontiguousarray(prm).ctypes.data),
+                        C.c_void_p(scr.data_ptr()), scr.numel(), None)
+    assert st != 0 and b"64" in L.slhip_last_error()
+
+
+def test_many_hull_scene_next_to_small_scenes(sl, oracle):
+    """Sizing hints are batch maxima: one scene of 12 bunnies (1452 hulls) next to tiny scenes."""
+    cube = scaled(sl, S.CUBE, 0.15)
+    bunny = scaled(sl, S.BUNNY, 0.2)
+    scene = sl.Scene((64, 48), seed=21)
+    for _ in range(12):
+        scene.add_object(sl.Object(bunny))
+    from stillleben_amd import physics
+
+    physics.prepare_tabletop(scene)
+    gpu, ref = run_both(oracle, [heap(sl, 22, 2, cube), scene, heap(sl, 23, 5, cube)], frames=15)
+    assert_bodies_equal(gpu, ref)
+
+
+def test_static_only_and_sleeping_scene(sl, oracle):
+    """All bodies static, and a scene left to sleep: nothing moves, flags and counters still agree."""
+    cube = scaled(sl, S.CUBE, 0.2)
+    scene = sl.Scene((64, 48), seed=31)
+    for k in range(3):
+        o = sl.Object(cube)
+        o.static = True
+        p = torch.eye(4)
+        p[0, 3] = 0.5 * k
+        o.set_pose(p)
+        scene.add_object(o)
+    gpu, ref = run_both(oracle, [scene], plane=False, frames=5)
+    assert_bodies_equal(gpu, ref)
+    rest = heap(sl, 32, 2, cube)
+    gpu, ref = run_both(oracle, [rest], frames=250)      # long enough for every body to fall asleep
+    assert_bodies_equal(gpu, ref)
+    assert (gpu["flags"] & 2).all() or np.abs(gpu["lin_vel"]).max() < 1e-3
