@@ -192,42 +192,52 @@ struct ClipVert {
     float bary[3];
 };
 
+// Sutherland-Hodgman against the near plane.  The output polygon is written to FIXED slots (a switch
+// over the six partially-inside cases) -- `out[n++] = ...` with a run-time n would push the polygon into
+// scratch memory, and that scratch traffic reaches HBM.  Vertex order and arithmetic are those of the
+// sequential form: for i = 0..2 { emit in[i] if inside; emit the edge (i, i+1) crossing if its ends
+// differ }, every crossing interpolated from the inside vertex towards the outside one.
+__device__ __forceinline__ ClipVert clip_cross(const ClipVert& a, const ClipVert& b, float da, float db)
+{
+    const float tt = da / (da - db);
+    ClipVert o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.clip[k] = fmaf(tt, b.clip[k] - a.clip[k], a.clip[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o.bary[k] = fmaf(tt, b.bary[k] - a.bary[k], a.bary[k]);
+    return o;
+}
+
 __device__ __forceinline__ int clip_near(const ClipVert* in, ClipVert* out)
 {
-    float d[3];
-    bool inside[3];
-    int n_in = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        d[i] = in[i].clip[2] + in[i].clip[3];
-        inside[i] = in[i].clip[2] >= -in[i].clip[3];
-        n_in += inside[i] ? 1 : 0;
-    }
-    if (n_in == 0) return 0;
-    if (n_in == 3) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) out[i] = in[i];
+    const float d0 = in[0].clip[2] + in[0].clip[3], d1 = in[1].clip[2] + in[1].clip[3], d2 = in[2].clip[2] + in[2].clip[3];
+    const bool i0 = in[0].clip[2] >= -in[0].clip[3], i1 = in[1].clip[2] >= -in[1].clip[3], i2 = in[2].clip[2] >= -in[2].clip[3];
+    const int m = (i0 ? 1 : 0) | (i1 ? 2 : 0) | (i2 ? 4 : 0);
+    if (m == 0) return 0;
+    if (m == 7) {
+        out[0] = in[0]; out[1] = in[1]; out[2] = in[2];
         return 3;
     }
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int j = (i + 1) % 3;
-        if (inside[i]) out[n++] = in[i];
-        if (inside[i] != inside[j]) {
-            const ClipVert& a = inside[i] ? in[i] : in[j];
-            const ClipVert& b = inside[i] ? in[j] : in[i];
-            const float da = inside[i] ? d[i] : d[j], db = inside[i] ? d[j] : d[i];
-            const float tt = da / (da - db);
-            ClipVert o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o.clip[k] = fmaf(tt, b.clip[k] - a.clip[k], a.clip[k]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) o.bary[k] = fmaf(tt, b.bary[k] - a.bary[k], a.bary[k]);
-            out[n++] = o;
-        }
+    switch (m) {
+    case 1:   // only v0 inside: v0, x01, x20
+        out[0] = in[0]; out[1] = clip_cross(in[0], in[1], d0, d1); out[2] = clip_cross(in[0], in[2], d0, d2);
+        return 3;
+    case 2:   // only v1: x01, v1, x12
+        out[0] = clip_cross(in[1], in[0], d1, d0); out[1] = in[1]; out[2] = clip_cross(in[1], in[2], d1, d2);
+        return 3;
+    case 4:   // only v2: x12, v2, x20
+        out[0] = clip_cross(in[2], in[1], d2, d1); out[1] = in[2]; out[2] = clip_cross(in[2], in[0], d2, d0);
+        return 3;
+    case 3:   // v0, v1 inside: v0, v1, x12, x20
+        out[0] = in[0]; out[1] = in[1]; out[2] = clip_cross(in[1], in[2], d1, d2); out[3] = clip_cross(in[0], in[2], d0, d2);
+        return 4;
+    case 5:   // v0, v2 inside: v0, x01, x12, v2
+        out[0] = in[0]; out[1] = clip_cross(in[0], in[1], d0, d1); out[2] = clip_cross(in[2], in[1], d2, d1); out[3] = in[2];
+        return 4;
+    default:  // 6: v1, v2 inside: x01, v1, v2, x20
+        out[0] = clip_cross(in[1], in[0], d1, d0); out[1] = in[1]; out[2] = in[2]; out[3] = clip_cross(in[2], in[0], d2, d0);
+        return 4;
     }
-    return n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -594,7 +604,9 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
     tgt.base_alpha = dr->base_color[3];
     tgt.alpha_cutoff = dr->alpha_cutoff;
 
-    for (int sub = 0; sub < n - 2; ++sub) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {   // n <= 4: at most two sub-triangles; unrolled so that poly[] keeps static indices
+        if (sub >= n - 2) break;
         Setup t;
         if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
         float bary[9];
@@ -658,7 +670,9 @@ __global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip
             ClipVert poly[4];
             const int n = clip_near(cv, poly);
             if (sub > n - 3) continue;
-            if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
+            const ClipVert& pb = sub == 0 ? poly[1] : poly[2];
+            const ClipVert& pc = sub == 0 ? poly[2] : poly[3];
+            if (!setup_tri(poly[0].clip, pb.clip, pc.clip, W, H, t)) continue;
             prim = dr->prim_base + tri;
             ok = true;
         }
@@ -1060,7 +1074,9 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
             const int px = (int)(pix % (unsigned)W), py = (int)(pix / (unsigned)W);
             float b[3] = {0.0f, 0.0f, 0.0f};
             bool found = false, front = false;
-            for (int sub = 0; sub < n - 2 && !found; ++sub) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {   // unrolled: static indices into poly[]
+                if (sub >= n - 2 || found) break;
                 Setup t;
                 if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
                 float l[3];

@@ -37,13 +37,15 @@ for i in range(B):
 import ctypes as C  # noqa: E402
 
 eng = engine()
-bufs = eng.render(scenes, _abi.OUT_GT6, ssao=True, shadows=True, buffers=None)   # warm-up
+MASK = int(os.environ.get("SLHIP_PROF_MASK", str(_abi.OUT_GT6)), 0)
+SSAO = os.environ.get("SLHIP_PROF_SSAO", "1") != "0"
+bufs = eng.render(scenes, MASK, ssao=SSAO, shadows=True, buffers=None)   # warm-up
 torch.cuda.synchronize()
 eng.L.slhip_timing_enable(1)
 ms = (C.c_float * 8)()
 eng.L.slhip_render_timings(C.byref(ms))
 for _ in range(REPS):
-    bufs = eng.render(scenes, _abi.OUT_GT6, ssao=True, shadows=True, buffers=bufs)
+    bufs = eng.render(scenes, MASK, ssao=SSAO, shadows=True, buffers=bufs)
 torch.cuda.synchronize()
 if eng.L.slhip_render_timings(C.byref(ms)) == 0:
     names = ["shadow_raster", "shadow_large", "vis_raster", "vis_large", "shade", "ssao", "ssao_apply", "tonemap"]
