@@ -445,31 +445,44 @@ struct Cand5 {
     bool ok[5];
 };
 
-__device__ __forceinline__ void emit(RawContacts& out, int& k, const Cand5& c, int i)
-{
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-        if (j == i) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (t == k) { out.pa[t] = c.p[j]; out.pb[t] = c.q[j]; out.sep[t] = c.s[j]; }
-        }
-    ++k;
-}
+// Selections are written component by component on VALUES: a conditional copy of a whole v3
+// (`cond ? a : b`, or a struct store under a branch) is lowered to a copy through a selected POINTER,
+// which pins Cand5 / RawContacts in scratch memory -- a global-memory round trip per move.
+__device__ __forceinline__ v3 vsel(bool c, v3 a, v3 b) { return V(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 
 __device__ __forceinline__ v3 pick_p(const Cand5& c, int i)
 {
     v3 r = c.p[0];
 #pragma unroll
-    for (int j = 1; j < 5; ++j) if (j == i) r = c.p[j];
+    for (int j = 1; j < 5; ++j) r = vsel(j == i, c.p[j], r);
+    return r;
+}
+__device__ __forceinline__ v3 pick_q(const Cand5& c, int i)
+{
+    v3 r = c.q[0];
+#pragma unroll
+    for (int j = 1; j < 5; ++j) r = vsel(j == i, c.q[j], r);
     return r;
 }
 __device__ __forceinline__ float pick_s(const Cand5& c, int i)
 {
     float r = c.s[0];
 #pragma unroll
-    for (int j = 1; j < 5; ++j) if (j == i) r = c.s[j];
+    for (int j = 1; j < 5; ++j) r = j == i ? c.s[j] : r;
     return r;
+}
+
+__device__ __forceinline__ void emit(RawContacts& out, int& k, const Cand5& c, int i)
+{
+    const v3 pp = pick_p(c, i), qq = pick_q(c, i);
+    const float ss = pick_s(c, i);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        out.pa[t] = vsel(t == k, pp, out.pa[t]);
+        out.pb[t] = vsel(t == k, qq, out.pb[t]);
+        out.sep[t] = t == k ? ss : out.sep[t];
+    }
+    ++k;
 }
 
 __device__ float reduce_candidates(const Cand5& c, v3 nrm, RawContacts& out)
@@ -1243,7 +1256,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         if (on) {
                             if (sl < rc.count && off + sl < kMaxActive) {
                                 const float e = 0.5f * (bodies[bi].restitution + prm.plane_restitution);
-                                const v3 pa = sl == 0 ? rc.pa[0] : sl == 1 ? rc.pa[1] : sl == 2 ? rc.pa[2] : rc.pa[3];
+                                const v3 pa = vsel(sl == 0, rc.pa[0], vsel(sl == 1, rc.pa[1], vsel(sl == 2, rc.pa[2], rc.pa[3])));
                                 const float sp = sl == 0 ? rc.sep[0] : sl == 1 ? rc.sep[1] : sl == 2 ? rc.sep[2] : rc.sep[3];
                                 fill_contact(&ac[off + sl], bi, -1, wb[bi], nullptr, pa, V(pa.x, pa.y, sc.plane_z), rc.n, sp,
                                              prm.rest_offset, e);
