@@ -442,7 +442,7 @@ __device__ __forceinline__ void make_shape(const WBody& wb, const HullRef& h, co
 struct Cand5 {
     v3 p[5], q[5];
     float s[5];
-    bool ok[5];
+    unsigned ok;          // validity mask, bit j = slot j
 };
 
 // Selections are written component by component on VALUES: a conditional copy of a whole v3
@@ -485,50 +485,66 @@ __device__ __forceinline__ void emit(RawContacts& out, int& k, const Cand5& c, i
     ++k;
 }
 
-__device__ float reduce_candidates(const Cand5& c, v3 nrm, RawContacts& out)
+// (always inlined BEFORE the optimiser runs: optimised on its own, its value selections over `c` would be
+// folded into loads through a selected address, which keeps Cand5 in scratch once inlined)
+__device__ __forceinline__ float reduce_candidates(const Cand5& c, v3 nrm, RawContacts& out)
 {
     int n = 0;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) n += c.ok[j] ? 1 : 0;
+    for (int j = 0; j < 5; ++j) n += (int)((c.ok >> j) & 1u);
     int k = 0;
     float mins = kInf;
     if (n <= 4) {
 #pragma unroll
         for (int j = 0; j < 5; ++j)
-            if (c.ok[j]) { emit(out, k, c, j); if (c.s[j] < mins) mins = c.s[j]; }
+            if ((c.ok >> j) & 1u) { emit(out, k, c, j); if (c.s[j] < mins) mins = c.s[j]; }
         out.count = k;
         return mins;
     }
-    // all five valid
+    // all five valid: the winners are carried as VALUES (index + point + separation) while the fixed
+    // slots are scanned -- no run-time indexed reads of `c`; same comparisons, same first-index ties
     int i0 = 0;
+    float s0 = c.s[0];
+    v3 p0 = c.p[0], q0 = c.q[0];
 #pragma unroll
-    for (int j = 1; j < 5; ++j) if (c.s[j] < pick_s(c, i0)) i0 = j;
-    const v3 p0 = pick_p(c, i0);
-    const float s0 = pick_s(c, i0);
+    for (int j = 1; j < 5; ++j) {
+        const bool b = c.s[j] < s0;
+        i0 = b ? j : i0; s0 = b ? c.s[j] : s0; p0 = vsel(b, c.p[j], p0); q0 = vsel(b, c.q[j], q0);
+    }
     int i1 = -1; float best = -3.0e38f;
+    float s1 = 0.0f;
+    v3 p1 = V(0, 0, 0), q1 = V(0, 0, 0);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        if (j == i0) continue;
         const v3 d = sub(c.p[j], p0);
         const float pen = kDepthWeight * (c.s[j] - s0);
         const float score = sqrtf(dot(d, d)) - pen;
-        if (score > best) { best = score; i1 = j; }
+        const bool b = j != i0 && score > best;
+        best = b ? score : best; i1 = b ? j : i1; s1 = b ? c.s[j] : s1; p1 = vsel(b, c.p[j], p1); q1 = vsel(b, c.q[j], q1);
     }
     int i2 = -1, i3 = -1; float mx = 0.0f, mn = 0.0f;
-    const v3 e = sub(pick_p(c, i1), p0);
+    float s2 = 0.0f, s3 = 0.0f;
+    v3 p2 = V(0, 0, 0), q2 = V(0, 0, 0), p3 = V(0, 0, 0), q3 = V(0, 0, 0);
+    const v3 e = sub(p1, p0);
     const float el = sqrtf(dot(e, e));
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        if (j == i0 || j == i1) continue;
+        const bool skip = j == i0 || j == i1;
         const float a = dot(cross(e, sub(c.p[j], p0)), nrm);
         const float pen = kDepthWeight * (c.s[j] - s0) * el;
-        if (a - pen > mx) { mx = a - pen; i2 = j; }
-        if (a + pen < mn) { mn = a + pen; i3 = j; }
+        const bool b2 = !skip && a - pen > mx, b3 = !skip && a + pen < mn;
+        mx = b2 ? a - pen : mx; i2 = b2 ? j : i2; s2 = b2 ? c.s[j] : s2; p2 = vsel(b2, c.p[j], p2); q2 = vsel(b2, c.q[j], q2);
+        mn = b3 ? a + pen : mn; i3 = b3 ? j : i3; s3 = b3 ? c.s[j] : s3; p3 = vsel(b3, c.p[j], p3); q3 = vsel(b3, c.q[j], q3);
     }
-    emit(out, k, c, i0); mins = fminf(mins, s0);
-    emit(out, k, c, i1); { const float t = pick_s(c, i1); if (t < mins) mins = t; }
-    if (i2 >= 0) { emit(out, k, c, i2); const float t = pick_s(c, i2); if (t < mins) mins = t; }
-    if (i3 >= 0) { emit(out, k, c, i3); const float t = pick_s(c, i3); if (t < mins) mins = t; }
+    out.pa[0] = p0; out.pb[0] = q0; out.sep[0] = s0; mins = fminf(mins, s0);
+    out.pa[1] = p1; out.pb[1] = q1; out.sep[1] = s1; if (s1 < mins) mins = s1;
+    k = 2;
+    const bool h2 = i2 >= 0, h3 = i3 >= 0;
+    // slot 2: candidate i2, or i3 when there is no i2; slot 3: candidate i3 when both exist
+    out.pa[2] = vsel(h2, p2, p3); out.pb[2] = vsel(h2, q2, q3); out.sep[2] = h2 ? s2 : s3;
+    out.pa[3] = p3; out.pb[3] = q3; out.sep[3] = s3;
+    if (h2) { ++k; if (s2 < mins) mins = s2; }
+    if (h3) { ++k; if (s3 < mins) mins = s3; }
     out.count = k;
     return mins;
 }
@@ -619,21 +635,21 @@ __device__ bool pair_tilt(const WBody& wa, const WBody& wb, const HullRef& ha, c
 }
 
 // stage 3: duplicate rejection in slot order + manifold reduction
-__device__ float pair_finish(const MainResult& m, Cand5& c, float radius, RawContacts& out)
+__device__ __forceinline__ float pair_finish(const MainResult& m, Cand5& c, float radius, RawContacts& out)
 {
-    c.p[0] = m.pa; c.q[0] = m.pb; c.s[0] = m.dist; c.ok[0] = true;
+    c.p[0] = m.pa; c.q[0] = m.pb; c.s[0] = m.dist; c.ok |= 1u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (!c.ok[k + 1]) continue;
+        if (!((c.ok >> (k + 1)) & 1u)) continue;
         bool dup = false;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             if (j > k) continue;
-            if (!c.ok[j]) continue;
+            if (!((c.ok >> j) & 1u)) continue;
             const v3 dd = sub(c.p[j], c.p[k + 1]);
             if (dot(dd, dd) < 2.5e-3f * radius * radius) dup = true;
         }
-        if (dup) c.ok[k + 1] = false;
+        if (dup) c.ok &= ~(1u << (k + 1));
     }
     out.n = m.n;
     return reduce_candidates(c, m.n, out);
@@ -1405,13 +1421,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     }
                     // gather the four candidates of a pair into its tilt-0 lane
                     Cand5 c;
+                    c.ok = 0u;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int from = (lane & ~3) + q;
                         c.p[q + 1] = V(__shfl(qa.x, from, 64), __shfl(qa.y, from, 64), __shfl(qa.z, from, 64));
                         c.q[q + 1] = V(__shfl(qb.x, from, 64), __shfl(qb.y, from, 64), __shfl(qb.z, from, 64));
                         c.s[q + 1] = __shfl(sp, from, 64);
-                        c.ok[q + 1] = __shfl(have ? 1 : 0, from, 64) != 0;
+                        c.ok |= (unsigned)(__shfl(have ? 1 : 0, from, 64) != 0) << (q + 1);
                     }
                     RawContacts rc;
                     rc.count = 0;
