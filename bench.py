@@ -116,8 +116,6 @@ class Pipeline:
     def launch_settle(self, item, slot=0):
         """Asynchronous: slhip_settle on one of the settle streams, then the 288 B/object read-back
         into pinned host memory; returns immediately."""
-        from stillleben_amd import _settle_batch as SB
-
         while len(self.s_settle) <= slot:
             self.s_settle.append(torch.cuda.Stream(device=self.eng.device))
         with torch.cuda.stream(self.s_settle[slot]):
@@ -131,7 +129,6 @@ class Pipeline:
             item["h_bodies"].copy_(d_bodies, non_blocking=True)
             item["ev_copy"] = torch.cuda.Event()
             item["ev_copy"].record()
-        del SB
 
     def finish(self, item, timed=True):
         """Host assembly (camera, light, draw records) + slhip_render of every chunk on the
@@ -176,17 +173,6 @@ class Pipeline:
         item["render_events"] = revs
         item["t_post"] = (time.perf_counter() - t0) * 1e3
         return outs
-
-    def collect(self, item):
-        """After a device synchronisation: per-phase timings of this item."""
-        ms = (C.c_float * 8)()
-        phases = np.zeros(8)
-        if self.eng.L.slhip_render_timings(C.byref(ms)) == 0:
-            phases += np.array(list(ms))
-        self.t_render.append(sum(a.elapsed_time(b) for a, b in item["render_events"]))
-        self.t_settle.append(item["ev0"].elapsed_time(item["ev1"]))
-        self.phase_ms.append(phases)
-        self.t_step_host.append(item["t_post"])
 
 
 def cpu_baseline(sl, meshes, scenes_per_thread, ssao, max_threads=32):

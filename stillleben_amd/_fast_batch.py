@@ -4,11 +4,8 @@ between the settle and the render of a batch: camera placement
 shadow matrices (render_pass.cpp:69-211) and the pose-dependent fields of the draw records.
 Everything pose-independent (materials, mesh ranges, chunks) is prepared once per batch by
 `prepare`.  tests/test_fast_batch.py checks it against the per-scene code paths."""
-import math
-
 import numpy as np
 
-from . import _abi
 from . import _math as M
 from ._batch import build_batch
 from .camera_placement import camera_rotation

@@ -1,5 +1,4 @@
-"""Negative-IoU loss (interface of the reference's stillleben/losses.py; pure torch)."""
-import torch
+"""Negative-IoU loss (interface of the reference's stillleben/losses.py; pure torch tensor ops)."""
 
 
 def neg_iou_loss(predict, target):

@@ -1,6 +1,5 @@
 """sl.RenderPass / sl.RenderPassResult (reference include/stillleben/render_pass.h:35-153,
 python/src/py_render_pass.cpp:81-279)."""
-import torch
 
 from . import _abi
 from ._context import engine, require_context
