@@ -40,6 +40,25 @@ extern "C" {
  * Render half
  * ------------------------------------------------------------------------------------------- */
 
+/* Image-based lighting ('next' row f1 of SURVEY.md 8f): the textures LightMap::load builds
+ * (reference src/light_map.cpp:360-606).  All cube maps are RGBA f32; faces in the OpenGL order
+ * +X -X +Y -Y +Z -Z; level l of a cube holds 6 faces of (size >> l)^2 texels and starts
+ * 4 * 6 * sum_{k<l} (size >> k)^2 floats into the buffer; rows of a face run along t.
+ * Sampling rules (OpenGL leaves them to the implementation; these are ours, shared by the oracle):
+ * bilinear within a level, texels beyond a face edge are taken from the face their direction points
+ * into (seamless), explicit-LOD fetches blend the two nearest levels linearly, `texture()` without an
+ * explicit LOD reads level 0.                                                                     */
+typedef struct {
+    float* d_env;            /* environment cube, env_levels levels (light_map.cpp:379-430)          */
+    float* d_irradiance;     /* diffuse irradiance cube, 1 level      (:455-515)                     */
+    float* d_prefilter;      /* GGX-prefiltered cube, pre_levels levels, roughness = l / (levels-1) (:517-573) */
+    float* d_brdf_lut;       /* f32 [lut_size][lut_size][2]: scale, bias of F0 (:575-603)             */
+    uint32_t env_size, env_levels;   /* reference: 512, 10 */
+    uint32_t irr_size;               /* 32  */
+    uint32_t pre_size, pre_levels;   /* 128, 5 */
+    uint32_t lut_size;               /* 512 */
+} slhip_light_map;
+
 /* Mesh pool: structure-of-arrays vertex storage shared by every scene of a batch.
  * Replaces the 68-byte interleaved GL vertex buffer of consolidateMesh
  * (reference src/mesh_tools/consolidate.cpp:53-61).  The 1-based `vertexIndex` attribute of
@@ -54,6 +73,8 @@ typedef struct {
     uint64_t n_vertices;
     uint64_t n_indices;
     uint64_t n_tex_bytes;
+    const slhip_light_map* d_light_maps;  /* DEVICE array; may be NULL when no scene uses one */
+    uint64_t n_light_maps;
 } slhip_mesh_pool;
 
 /* draw flags */
@@ -100,7 +121,11 @@ typedef struct {
     float manual_exposure;                   /* <0: auto exposure (tone_map_shader.frag:110) */
     uint32_t draw_begin, draw_end;           /* range in the draw array               */
     uint32_t n_prims;                        /* total triangles of the scene          */
-} slhip_scene;                               /* 464 bytes */
+    uint32_t light_map;                      /* 1 + index into pool->d_light_maps, 0 = none: IBL term
+                                                (render_shader.frag:375-394) + sky background
+                                                (render_pass.cpp:647-661)                          */
+    uint32_t _pad[3];
+} slhip_scene;                               /* 480 bytes */
 
 /* A unit of raster work: `count` consecutive triangles of one draw (<= SLHIP_CHUNK_TRIS).
  * Built on the host when the draw list is assembled so that every workgroup has a
@@ -309,6 +334,18 @@ int slhip_diff_pose_backward(const uint8_t* d_rgb, const float* d_coord, const i
                              const float* d_grad_img, const float* h_proj, const float* d_poses,
                              const int32_t* d_obj_inst, int n_obj, int H, int W, uint8_t* d_valid,
                              double* d_acc, float* d_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Image-based lighting precompute (replaces LightMap::load's GL passes, light_map.cpp:360-606, and
+ * src/shaders/cubemap_shader_{equirectangular,irradiance,prefilter}.frag, brdf_shader.frag)
+ * ------------------------------------------------------------------------------------------- */
+/* floats needed for the four buffers of a light map with the given sizes: out[0..3] = env,
+ * irradiance, prefilter, BRDF LUT                                                              */
+int slhip_light_map_floats(uint32_t env_size, uint32_t env_levels, uint32_t irr_size, uint32_t pre_size,
+                           uint32_t pre_levels, uint32_t lut_size, uint64_t out[4]);
+/* d_equirect: f32 [H][W][3] equirectangular radiance, row 0 = top (+z up, azimuth atan2(y, x) along
+ * the row); fills every buffer of *lm (a HOST struct holding DEVICE pointers).                   */
+int slhip_light_map_build(const float* d_equirect, int H, int W, const slhip_light_map* lm, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Camera model ('next' row f4 of SURVEY.md 8f): the step after the render in every data-generation

@@ -15,7 +15,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "libslref.so")
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     srcs.append(os.path.join(_HERE, "..", "include", "slhip.h"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
@@ -208,3 +208,32 @@ def camera_model(rgb, params, stage=4):
     if st != 0:
         raise ValueError("oracle.camera_model: the random noise stage is not restated")
     return out
+
+
+def light_map_build(equirect, sizes):
+    """IBL precompute (oracle/ibl_ref.c).  equirect f32[H,W,3]; sizes = dict(env_size, env_levels, irr_size,
+    pre_size, pre_levels, lut_size).  Returns dict of numpy buffers laid out like slhip_light_map's."""
+    from stillleben_amd import _abi
+
+    L = lib()
+    eq = np.ascontiguousarray(equirect, dtype=np.float32)
+    H, W, _ = eq.shape
+
+    def cube_floats(size, levels):
+        return sum(24 * (size >> l) ** 2 for l in range(levels))
+
+    bufs = {
+        "env": np.zeros(cube_floats(sizes["env_size"], sizes["env_levels"]), np.float32),
+        "irradiance": np.zeros(cube_floats(sizes["irr_size"], 1), np.float32),
+        "prefilter": np.zeros(cube_floats(sizes["pre_size"], sizes["pre_levels"]), np.float32),
+        "brdf_lut": np.zeros(2 * sizes["lut_size"] ** 2, np.float32),
+    }
+    rec = _abi.LightMapRec()
+    rec.d_env, rec.d_irradiance, rec.d_prefilter, rec.d_brdf_lut = (bufs[k].ctypes.data for k in ("env", "irradiance", "prefilter", "brdf_lut"))
+    for k, v in sizes.items():
+        setattr(rec, k, int(v))
+    L.slref_light_map_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    st = L.slref_light_map_build(_p(eq), H, W, C.byref(rec))
+    if st != 0:
+        raise RuntimeError("slref_light_map_build failed")
+    return bufs

@@ -43,6 +43,25 @@ class MeshPool(C.Structure):
         ("n_vertices", C.c_uint64),
         ("n_indices", C.c_uint64),
         ("n_tex_bytes", C.c_uint64),
+        ("d_light_maps", C.c_void_p),
+        ("n_light_maps", C.c_uint64),
+    ]
+
+
+class LightMapRec(C.Structure):
+    """slhip_light_map: device pointers + sizes of one image-based-lighting texture set."""
+
+    _fields_ = [
+        ("d_env", C.c_void_p),
+        ("d_irradiance", C.c_void_p),
+        ("d_prefilter", C.c_void_p),
+        ("d_brdf_lut", C.c_void_p),
+        ("env_size", C.c_uint32),
+        ("env_levels", C.c_uint32),
+        ("irr_size", C.c_uint32),
+        ("pre_size", C.c_uint32),
+        ("pre_levels", C.c_uint32),
+        ("lut_size", C.c_uint32),
     ]
 
 
@@ -88,10 +107,12 @@ SCENE_DTYPE = np.dtype(
         ("draw_begin", np.uint32),
         ("draw_end", np.uint32),
         ("n_prims", np.uint32),
+        ("light_map", np.uint32),     # 1 + index into the pool's light maps, 0 = none
+        ("_pad", np.uint32, (3,)),
     ],
     align=False,
 )
-assert SCENE_DTYPE.itemsize == 464, SCENE_DTYPE.itemsize
+assert SCENE_DTYPE.itemsize == 480, SCENE_DTYPE.itemsize
 
 CHUNK_DTYPE = np.dtype(
     [("scene", np.uint32), ("draw", np.uint32), ("first_tri", np.uint32), ("count", np.uint32)]
@@ -181,6 +202,8 @@ def lib():
                                C.c_void_p, C.c_uint64, C.c_void_p]
     L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.POINTER(C.c_uint64)]
     L.slhip_overlap_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slhip_light_map_floats.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint64 * 4)]
+    L.slhip_light_map_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.slhip_camera_model.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     _LIB = L
     return L

@@ -55,10 +55,17 @@ class Engine:
         self.pool = HostPool()
         self._pool_dev = None
         self._scratch = {}
+        self._light_maps = []        # registered LightMap objects; slot = index
+        self._light_maps_dev = None
 
     # ---- mesh pool -------------------------------------------------------------------------
     def register_mesh(self, mesh):
         return self.pool.register(mesh)
+
+    def register_light_map(self, lm):
+        self._light_maps.append(lm)
+        self._light_maps_dev = None
+        return len(self._light_maps) - 1
 
     def pool_abi(self):
         if self.pool.dirty or self._pool_dev is None:
@@ -69,6 +76,11 @@ class Engine:
         d = self._pool_dev
         p.d_pos, p.d_nrm, p.d_uv, p.d_col, p.d_idx, p.d_tex = (_ptr(t) for t in d)
         p.n_vertices, p.n_indices, p.n_tex_bytes = self.pool.n_vertices, self.pool.n_indices, self.pool.n_tex_bytes
+        if self._light_maps:
+            if self._light_maps_dev is None:
+                raw = b"".join(bytes(lm.rec) for lm in self._light_maps)
+                self._light_maps_dev = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(self.device)
+            p.d_light_maps, p.n_light_maps = _ptr(self._light_maps_dev), len(self._light_maps)
         return p
 
     # ---- scratch ---------------------------------------------------------------------------

@@ -24,7 +24,7 @@
 namespace {
 
 static_assert(sizeof(slhip_draw) == 272, "slhip_draw layout");
-static_assert(sizeof(slhip_scene) == 464, "slhip_scene layout");
+static_assert(sizeof(slhip_scene) == 480, "slhip_scene layout");
 static_assert(sizeof(slhip_chunk) == 16, "slhip_chunk layout");
 
 constexpr float kInvalid = 3000.0f;  // render_pass.cpp:316

@@ -37,8 +37,7 @@ class _OutOfScope:
         raise NotImplementedError("%s is outside the hot-path scope of stillleben_amd (SURVEY.md section 2)" % self._what)
 
 
-class LightMap(_OutOfScope):
-    _what = "LightMap / image-based lighting ('next' row f1)"
+from .light_map import LightMap  # noqa: E402,F401  (image-based lighting, 'next' row f1)
 
 
 class Viewer(_OutOfScope):

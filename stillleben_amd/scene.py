@@ -199,9 +199,11 @@ class Scene:
 
     @light_map.setter
     def light_map(self, v):
-        if v is not None:
-            raise NotImplementedError("image-based lighting is a 'next' row (SURVEY.md 8f f1)")
-        self._light_map = None
+        from .light_map import LightMap
+
+        if v is not None and not isinstance(v, LightMap):
+            v = LightMap(v)          # a path, as Scene::deserialize passes it (scene.cpp:841-842)
+        self._light_map = v
 
     @property
     def background_plane_pose(self):
