@@ -41,7 +41,7 @@ class RenderResult:
 
 
 def render(pool_arrays, srec, drec, W, H, flags, depth_peel=None, shadow_res=2048, want_hdr=False,
-           want_shadow=False):
+           want_shadow=False, light_maps=None):
     """Runs the CPU reference renderer on the binary scene description produced by
     stillleben_amd._batch.build_batch.  Returns numpy arrays shaped like the device buffers."""
     from stillleben_amd import _abi
@@ -51,6 +51,17 @@ def render(pool_arrays, srec, drec, W, H, flags, depth_peel=None, shadow_res=204
     pool = _abi.MeshPool()
     pool.d_pos, pool.d_nrm, pool.d_uv, pool.d_col, pool.d_idx, pool.d_tex = (_p(a) for a in (pos, nrm, uv, col, idx, tex))
     pool.n_vertices, pool.n_indices, pool.n_tex_bytes = len(pos), len(idx), tex.size
+    if light_maps:
+        # light_maps: list of (buffers dict as returned by light_map_build, sizes dict) -- host memory
+        recs = (_abi.LightMapRec * len(light_maps))()
+        keep = []
+        for r, (bufs, sizes) in zip(recs, light_maps):
+            b = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in bufs.items()}
+            keep.append(b)
+            r.d_env, r.d_irradiance, r.d_prefilter, r.d_brdf_lut = (b[k].ctypes.data for k in ("env", "irradiance", "prefilter", "brdf_lut"))
+            for k, v in sizes.items():
+                setattr(r, k, int(v))
+        pool.d_light_maps, pool.n_light_maps = C.cast(recs, C.c_void_p).value, len(light_maps)
     B = len(srec)
     r = RenderResult()
     r.rgb = np.zeros((B, H, W, 4), np.uint8)

@@ -51,6 +51,7 @@
 #include <string.h>
 
 #include "../include/slhip.h"
+#include "cubemap_ref.h"
 
 #define REF_PI 3.141592653589793f
 #define INVALID_VALUE 3000.0f /* render_pass.cpp:316 */
@@ -441,10 +442,40 @@ static void shade_fragment(const shade_ctx* cx, const slhip_draw* dr, const floa
             color[c] += inverse_shadow * (kD * base[c] / REF_PI + specular) * lc[c] * NdotL;
         }
     }
-    for (int c = 0; c < 3; ++c) {
-        color[c] += sc->ambient[c] * base[c];
-        color[c] += dr->emissive[c];
+    for (int c = 0; c < 3; ++c) color[c] += sc->ambient[c] * base[c];
+    if (sc->light_map != 0u && cx->pool->d_light_maps) {
+        /* image-based lighting (render_shader.frag:375-394); sampling rules: include/slhip.h, slhip_light_map */
+        const slhip_light_map* lm = cx->pool->d_light_maps + (sc->light_map - 1u);
+        const float d2 = 2.0f * dot3(normal, V);
+        cm3 refl = {d2 * normal[0] - V[0], d2 * normal[1] - V[1], d2 * normal[2] - V[2]};
+        float fab[2];
+        {
+            const int n = (int)lm->lut_size;
+            const float x = NoV * (float)n - 0.5f, y = roughness * (float)n - 0.5f;
+            const float fx = floorf(x), fy = floorf(y);
+            const float a = x - fx, b = y - fy;
+            int x0 = (int)fx, x1 = (int)fx + 1, y0 = (int)fy, y1 = (int)fy + 1;
+            if (x0 < 0) x0 = 0; if (x0 > n - 1) x0 = n - 1; if (x1 < 0) x1 = 0; if (x1 > n - 1) x1 = n - 1;
+            if (y0 < 0) y0 = 0; if (y0 > n - 1) y0 = n - 1; if (y1 < 0) y1 = 0; if (y1 > n - 1) y1 = n - 1;
+            const float* t = lm->d_brdf_lut;
+            for (int k = 0; k < 2; ++k)
+                fab[k] = cm_bil(a, b, t[2 * (y0 * n + x0) + k], t[2 * (y0 * n + x1) + k], t[2 * (y1 * n + x0) + k], t[2 * (y1 * n + x1) + k]);
+        }
+        const cm4 rad4 = cm_sample_lod(lm->d_prefilter, lm->pre_size, lm->pre_levels, refl, roughness * 4.0f);
+        cm3 nd = {normal[0], normal[1], normal[2]};
+        const cm4 irr4 = cm_sample_lod(lm->d_irradiance, lm->irr_size, 1u, nd, 0.0f);
+        const float rad[3] = {rad4.x, rad4.y, rad4.z}, irr[3] = {irr4.x, irr4.y, irr4.z};
+        const float Ems = 1.0f - (fab[0] + fab[1]);
+        for (int c = 0; c < 3; ++c) {
+            const float c_diff = base[c] * (1.0f - 0.04f) * (1.0f - metallic);
+            const float FssEss = kS[c] * fab[0] + fab[1];
+            const float F_avg = F0[c] + (1.0f - F0[c]) / 21.0f;
+            const float FmsEms = Ems * FssEss * F_avg / (1.0f - F_avg * Ems);
+            const float k_D = c_diff * (1.0f - FssEss - FmsEms);
+            color[c] += FssEss * rad[c] + (FmsEms + k_D) * irr[c];
+        }
     }
+    for (int c = 0; c < 3; ++c) color[c] += dr->emissive[c];
 
     /* normalOut (frag:404-405): camera-frame normal and n.v */
     float nc[3];
@@ -860,6 +891,24 @@ int slref_render(const slhip_mesh_pool* pool, const slhip_scene* scenes, const s
                         }
                 }
             }
+        }
+
+        /* sky background (render_pass.cpp:647-661): drawn at depth 1 with LEQUAL, i.e. wherever nothing was
+           rasterised; colour attachment 0 only, alpha 0 */
+        if (sc->light_map != 0u && pool->d_light_maps) {
+            const slhip_light_map* lm = pool->d_light_maps + (sc->light_map - 1u);
+            const float* m = sc->world_to_cam;
+            for (int py = 0; py < H; ++py)
+                for (int px = 0; px < W; ++px) {
+                    const size_t p = (size_t)py * W + px;
+                    if (depth[p] != 0xFFFFFFu) continue;   /* something was rasterised here */
+                    const float xn = (2.0f * ((float)px + 0.5f)) / (float)W - 1.0f, yn = (2.0f * ((float)py + 0.5f)) / (float)H - 1.0f;
+                    const float dcx = (xn - sc->proj[2]) / sc->proj[0], dcy = (yn - sc->proj[6]) / sc->proj[5];
+                    cm3 dw = {fmaf(m[8], 1.0f, fmaf(m[4], dcy, m[0] * dcx)), fmaf(m[9], 1.0f, fmaf(m[5], dcy, m[1] * dcx)),
+                              fmaf(m[10], 1.0f, fmaf(m[6], dcy, m[2] * dcx))};
+                    const cm4 e = cm_sample_lod(lm->d_env, lm->env_size, lm->env_levels, dw, 0.0f);
+                    hdr[4 * p + 0] = e.x; hdr[4 * p + 1] = e.y; hdr[4 * p + 2] = e.z; hdr[4 * p + 3] = 0.0f;
+                }
         }
 
         if (out->d_normals) memcpy(out->d_normals + 4 * base, nrmb, P * 4 * sizeof(float));

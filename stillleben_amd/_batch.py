@@ -108,6 +108,22 @@ def _effective_material(mat, obj):
     return metallic, roughness
 
 
+def effective_lights(scene):
+    """(directions [3,3], colours [3,3], ambient [3]) the renderer uses: with a light map bound, the
+    directional lights are the map's (Sun / Light1 / Light2, at most NUM_LIGHTS) and the ambient term is
+    off (render_pass.cpp:412-418, RenderShader::setLightMap render_shader.cpp:270-296)."""
+    lm = scene._light_map
+    if lm is None:
+        return (scene._light_directions.detach().cpu().numpy().astype(np.float32),
+                scene._light_colors.detach().cpu().numpy().astype(np.float32),
+                np.asarray(scene._ambient_light, dtype=np.float32))
+    ld = np.zeros((_abi.NUM_LIGHTS, 3), np.float32)
+    lc = np.zeros((_abi.NUM_LIGHTS, 3), np.float32)
+    for i, (d, c) in enumerate(list(zip(lm.light_directions, lm.light_colors))[:_abi.NUM_LIGHTS]):
+        ld[i], lc[i] = d, c
+    return ld, lc, np.zeros(3, np.float32)
+
+
 def scene_record(scene, rec, shadow_mats=None):
     rec["proj"] = scene._projection.reshape(-1)
     w2c = M.inverted_rigid(scene._camera_pose)
@@ -115,11 +131,11 @@ def scene_record(scene, rec, shadow_mats=None):
     # camPosition = worldToCam.invertedRigid().translation() (render_shader.cpp:246)
     rec["cam_position"][:3] = M.inverted_rigid(w2c)[:3, 3]
     rec["cam_position"][3] = 1.0
-    ld = scene._light_directions.detach().cpu().numpy().astype(np.float32)
-    lc = scene._light_colors.detach().cpu().numpy().astype(np.float32)
+    ld, lc, amb = effective_lights(scene)
     rec["light_dir"][:, :3] = ld
     rec["light_color"][:, :3] = lc
-    rec["ambient"][:3] = scene._ambient_light
+    rec["ambient"][:3] = amb
+    rec["light_map"] = 0 if scene._light_map is None else scene._light_map._slot + 1
     rec["manual_exposure"] = scene._manual_exposure
     if shadow_mats is not None:
         for i in range(_abi.NUM_LIGHTS):

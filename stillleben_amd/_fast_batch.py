@@ -51,6 +51,9 @@ def prepare(scenes, pool):
     t.proj = np.stack([s._projection for s in scenes]).astype(np.float32)
     t.proj_inv = np.linalg.inv(t.proj.astype(np.float64)).astype(np.float32)
     t.plane_size = np.stack([s._background_plane_size for s in scenes]).astype(np.float32)
+    if any(s._light_map is not None for s in scenes):
+        raise NotImplementedError("the vectorised batch path draws random light directions; scenes with a light map go "
+                                  "through _batch.build_batch")
     t.light_colors = np.stack([s._light_colors.numpy() for s in scenes]).astype(np.float32)
     t.max_objs = max(len(s._objects) for s in scenes)
     return t

@@ -77,8 +77,9 @@ def shadow_matrix(scene, corners, light_direction):  # render_pass.cpp:131-211
 
 
 def shadow_matrices(scene):
-    ld = scene._light_directions.detach().cpu().numpy().astype(np.float32)
-    lc = scene._light_colors.detach().cpu().numpy().astype(np.float32)
+    from ._batch import effective_lights
+
+    ld, lc, _ = effective_lights(scene)
     mats = [np.eye(4, dtype=np.float32) for _ in range(ld.shape[0])]
     corners = None
     for i in range(ld.shape[0]):

@@ -20,6 +20,7 @@
 // oracle/render_ref.c; this file is compiled with -ffp-contract=off so that only the explicit
 // fmaf() calls fuse.
 #include "slhip_common.h"
+#include "slhip_cubemap.h"
 
 namespace {
 
@@ -885,7 +886,7 @@ __device__ __forceinline__ float shadow_pcf16(const float* __restrict__ sm, int 
 __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ sc, const slhip_draw* __restrict__ dr,
                                                const float* base, const float* world, const float* nrm_in,
                                                bool front_facing, const float* __restrict__ shadow, int S,
-                                               float* color, float* normal_out)
+                                               const slhip_light_map* __restrict__ lm, float* color, float* normal_out)
 {
     float normal[3] = {nrm_in[0], nrm_in[1], nrm_in[2]};
     if (!front_facing) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
@@ -939,10 +940,42 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
         }
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        color[c] += sc->ambient[c] * base[c];
-        color[c] += dr->emissive[c];
+    for (int c = 0; c < 3; ++c) color[c] += sc->ambient[c] * base[c];
+    if (lm) {
+        // image-based lighting (render_shader.frag:375-394): split-sum specular + diffuse irradiance with the
+        // multiple-scattering correction of Fdez-Aguera; occlusion = 1 (no occlusion texture on this path)
+        const float d2 = 2.0f * dot3(normal, V);
+        const slcube::f3 refl = slcube::F3(d2 * normal[0] - V[0], d2 * normal[1] - V[1], d2 * normal[2] - V[2]);   // reflect(-V, N)
+        float fab[2];
+        {
+            const int n = (int)lm->lut_size;
+            const float x = NoV * (float)n - 0.5f, y = roughness * (float)n - 0.5f;
+            const float fx = floorf(x), fy = floorf(y);
+            const float a = x - fx, b = y - fy;
+            const int x0 = min(max((int)fx, 0), n - 1), x1 = min(max((int)fx + 1, 0), n - 1);
+            const int y0 = min(max((int)fy, 0), n - 1), y1 = min(max((int)fy + 1, 0), n - 1);
+            const float2* t = reinterpret_cast<const float2*>(lm->d_brdf_lut);
+            const float2 c00 = t[y0 * n + x0], c10 = t[y0 * n + x1], c01 = t[y1 * n + x0], c11 = t[y1 * n + x1];
+            const float tx = fmaf(a, c10.x - c00.x, c00.x), bx = fmaf(a, c11.x - c01.x, c01.x);
+            const float ty = fmaf(a, c10.y - c00.y, c00.y), by = fmaf(a, c11.y - c01.y, c01.y);
+            fab[0] = fmaf(b, bx - tx, tx); fab[1] = fmaf(b, by - ty, ty);
+        }
+        const float4 rad4 = slcube::sample_lod(lm->d_prefilter, lm->pre_size, lm->pre_levels, refl, roughness * 4.0f);
+        const float4 irr4 = slcube::sample_lod(lm->d_irradiance, lm->irr_size, 1u, slcube::F3(normal[0], normal[1], normal[2]), 0.0f);
+        const float rad[3] = {rad4.x, rad4.y, rad4.z}, irr[3] = {irr4.x, irr4.y, irr4.z};
+        const float Ems = 1.0f - (fab[0] + fab[1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float c_diff = base[c] * (1.0f - 0.04f) * (1.0f - metallic);
+            const float FssEss = kS[c] * fab[0] + fab[1];
+            const float F_avg = F0[c] + (1.0f - F0[c]) / 21.0f;
+            const float FmsEms = Ems * FssEss * F_avg / (1.0f - F_avg * Ems);
+            const float k_D = c_diff * (1.0f - FssEss - FmsEms);
+            color[c] += FssEss * rad[c] + (FmsEms + k_D) * irr[c];
+        }
     }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) color[c] += dr->emissive[c];
     float nc[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -1035,6 +1068,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
     if (threadIdx.x < 64 && threadIdx.x < n_scene_draws) s_prim_base[threadIdx.x] = draws[sc->draw_begin + threadIdx.x].prim_base;
     __syncthreads();
 
+    const slhip_light_map* lm = (sc->light_map != 0u && pool.d_light_maps) ? pool.d_light_maps + (sc->light_map - 1u) : nullptr;
     float color[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (active) {
         const unsigned long long key = vis[gp];
@@ -1118,12 +1152,25 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                 const float* sm = (prm.flags & SLHIP_RENDER_SHADOWS) && shadow
                                       ? shadow + (size_t)scene * SLHIP_NUM_LIGHTS * prm.S * prm.S
                                       : nullptr;
-                shade_fragment(sc, dr, base, world, nrm, front, sm, prm.S, color, nout);
+                shade_fragment(sc, dr, base, world, nrm, front, sm, prm.S, lm, color, nout);
                 cls = dr->class_index & 0xFFFFu;
                 inst = dr->instance_index & 0xFFFFu;
                 if (!(dr->flags & SLHIP_DRAW_NO_VERTEX_ID)) { vidx[0] = vi[0] + 1; vidx[1] = vi[1] + 1; vidx[2] = vi[2] + 1; }
                 bary[0] = b[0]; bary[1] = b[1]; bary[2] = b[2];
             }
+        }
+        if (key == kVisEmpty && lm) {
+            // sky background (render_pass.cpp:647-661, background_cube_shader.*): the environment along the
+            // pixel's view ray, alpha 0; the other targets keep their clear values
+            const int px = (int)(pix % (unsigned)W), py = (int)(pix / (unsigned)W);
+            const float xn = (2.0f * ((float)px + 0.5f)) / (float)W - 1.0f, yn = (2.0f * ((float)py + 0.5f)) / (float)H - 1.0f;
+            const float dcx = (xn - sc->proj[2]) / sc->proj[0], dcy = (yn - sc->proj[6]) / sc->proj[5];
+            // camera -> world rotation = transpose of the rotation block of world_to_cam
+            const float* m = sc->world_to_cam;
+            const slcube::f3 dw = slcube::F3(fmaf(m[8], 1.0f, fmaf(m[4], dcy, m[0] * dcx)), fmaf(m[9], 1.0f, fmaf(m[5], dcy, m[1] * dcx)),
+                                            fmaf(m[10], 1.0f, fmaf(m[6], dcy, m[2] * dcx)));
+            const float4 e = slcube::sample_lod(lm->d_env, lm->env_size, lm->env_levels, dw, 0.0f);
+            color[0] = e.x; color[1] = e.y; color[2] = e.z; color[3] = 0.0f;
         }
         if (out.d_coord) reinterpret_cast<float4*>(out.d_coord)[gp] = make_float4(coord[0], coord[1], coord[2], coord[3]);
         if (out.d_class) out.d_class[gp] = (uint16_t)cls;

@@ -146,3 +146,55 @@ def test_ibl_file_hdr_loader_and_lights(sl, tmp_path):
     bad.write_text("[Reflection]\nREFfile = sky_1.hdr\nREFmap = 2\n")
     with pytest.raises(RuntimeError):
         sl.LightMap(str(bad))
+
+
+def test_render_with_light_map_matches_oracle(sl, oracle):
+    """IBL shading term + sky background + the map's sun light, end to end: every geometric output bit
+    for bit, rgb to the 8-bit tolerance.  The oracle renders with the maps the GPU built (downloaded), so
+    this isolates the fragment stage from the precompute's transcendental differences."""
+    import scenes as S
+    from stillleben_amd import _abi, _engine
+    from stillleben_amd._batch import HostPool, build_batch
+    from stillleben_amd._context import engine
+    from test_gpu_render import assert_geometry_equal, assert_rgb_close
+
+    eq = sky(48, 96, seed=2)
+    sizes = dict(env_size=64, env_levels=7, irr_size=8, pre_size=32, pre_levels=5, lut_size=32)
+    lm = sl.LightMap(eq, sizes=sizes)
+    lm.light_directions = [np.array([0.3, -0.2, -0.93], np.float32)]       # as a [Sun] group would give
+    lm.light_colors = [np.array([3.0, 2.8, 2.5], np.float32)]
+    eng = engine()
+    scs = []
+    for seed, metal, rough in ((5, 0.9, 0.15), (6, 0.1, 0.7)):
+        sc = S.clutter_scene(sl, seed, n_objects=5, size=(200, 150), with_bunny=(seed == 6))
+        for o in sc.objects:
+            o.metallic, o.roughness = metal, rough
+        sc.background_plane_size = torch.tensor([0.0, 0.0])      # let the sky show
+        sc.light_map = lm
+        sc.ambient_light = torch.tensor([0.7, 0.7, 0.7])         # ignored while a light map is bound
+        scs.append(sc)
+    plain = S.clutter_scene(sl, 7, n_objects=3, size=(200, 150))     # a scene without a light map in the same batch
+    scs.append(plain)
+    mask = _abi.OUT_ALL
+    bufs = eng.render(scs, mask, ssao=True, shadows=True)
+    torch.cuda.synchronize()
+    pool = HostPool()
+    srec, drec, _ = build_batch(scs, pool, with_shadows=True)
+    assert list(srec["light_map"]) == [lm._slot + 1, lm._slot + 1, 0]
+    assert np.allclose(srec["light_dir"][0, 0, :3], lm.light_directions[0]) and (srec["ambient"][0] == 0).all()
+    host_maps = [({"env": lm.env.cpu().numpy(), "irradiance": lm.irradiance.cpu().numpy(), "prefilter": lm.prefilter.cpu().numpy(),
+                   "brdf_lut": lm.brdf_lut.cpu().numpy()}, sizes)] * (lm._slot + 1)
+    ref = oracle.render(pool.arrays(), srec, drec, 200, 150, mask | _abi.RENDER_SSAO | _abi.RENDER_SHADOWS,
+                        shadow_res=_engine.SHADOW_RES, light_maps=host_maps)
+    assert_geometry_equal(bufs, ref)
+    assert_rgb_close(bufs, ref)
+    rgb = bufs.rgb.cpu().numpy()
+    inst = bufs.instance.cpu().numpy()[..., 0]
+    empty = bufs.coord.cpu().numpy()[..., 0] == 3000.0                    # pixels without geometry (clear value)
+    sky_px = rgb[0][empty[0]]
+    assert len(sky_px) > 100 and (sky_px[:, 3] == 0).all() and sky_px[:, :3].max() > 0   # environment colour, alpha 0
+    assert (rgb[2][empty[2]] == 0).all()                                   # no light map: background stays cleared
+    # the IBL term matters: the same scene without the map is darker on the objects
+    scs[0].light_map = None
+    dark = eng.render([scs[0]], mask, ssao=True, shadows=True).rgb.cpu().numpy()[0]
+    assert rgb[0][inst[0] != 0][:, :3].astype(np.int32).sum() != dark[inst[0] != 0][:, :3].astype(np.int32).sum()
