@@ -68,6 +68,9 @@ typedef struct {
     const float* d_nrm;   /* float4[V]  nx ny nz 0                                */
     const float* d_uv;    /* float2[V]                                            */
     const float* d_col;   /* float4[V]  vertex colour (default 1,1,1,1)            */
+    const float* d_tan;   /* float4[V]  tangent xyz, bitangent sign (consolidate.cpp:275-279 writes w = 1;
+                             missing tangents are computed, compute_tangents.cpp); may be NULL when no
+                             draw has a normal texture                                          */
     const uint32_t* d_idx;/* u32[3T]    indices relative to the draw's vtx_base   */
     const uint8_t* d_tex; /* RGBA8 texel pool (all base-colour textures, mip 0)   */
     uint64_t n_vertices;
@@ -84,6 +87,13 @@ typedef struct {
 #define SLHIP_DRAW_ALPHA_TEST     8u  /* texture has an alpha channel: cut-off in the z pass     */
 #define SLHIP_DRAW_NO_VERTEX_ID  16u  /* mesh without the vertexIndex attribute (the background
                                          plane): vertex ids read 0 (render_pass.cpp:573-581)     */
+/* further material textures of RenderShader::setMaterial (render_shader.cpp:395-415), all RGBA8 in the
+ * texel pool, sampled bilinearly on mip 0 with repeat wrapping like the base colour texture            */
+#define SLHIP_DRAW_HAS_NORMAL_TEX    32u  /* tangent-space normal map (render_shader.frag:262-266)      */
+#define SLHIP_DRAW_HAS_MR_TEX        64u  /* roughness in G, metallic in B (frag:284-288)               */
+#define SLHIP_DRAW_HAS_OCCLUSION_TEX 128u /* R scales the image-based lighting term (frag:292-294,393)  */
+#define SLHIP_DRAW_HAS_EMISSIVE_TEX  256u /* sRGB, multiplies the emissive factor (frag:296-298)        */
+#define SLHIP_DRAW_HAS_STICKER       512u /* projected decal (frag:248-256, object.cpp:494-513)         */
 
 /* One drawable (sub-mesh of an object, or the background plane) of one scene.
  * Carries what RenderShader::setTransformations / setMaterial / setClassIndex /
@@ -106,7 +116,15 @@ typedef struct {
     uint32_t tex_offset;         /* byte offset of the RGBA8 base-colour texture      */
     uint32_t tex_w, tex_h;
     uint32_t clip_base;          /* first entry of this draw in the clip-position scratch */
-} slhip_draw;                    /* 272 bytes */
+    uint32_t normal_tex_offset, normal_tex_w, normal_tex_h;
+    uint32_t mr_tex_offset, mr_tex_w, mr_tex_h;
+    uint32_t occlusion_tex_offset, occlusion_tex_w, occlusion_tex_h;
+    uint32_t emissive_tex_offset, emissive_tex_w, emissive_tex_h;
+    uint32_t sticker_tex_offset, sticker_tex_w, sticker_tex_h;   /* rectangle texture, clamp to edge, row 0 = top of the image */
+    uint32_t _pad;
+    float sticker_projection[16];  /* Object::stickerViewProjection, row-major (object.cpp:494-513)       */
+    float sticker_range[4];        /* min.x, min.y, max(1e-6, size.x), max(1e-6, size.y) (render_shader.cpp:426-437) */
+} slhip_draw;                    /* 416 bytes */
 
 /* Per-scene camera + lights (reference Scene::setCameraIntrinsics src/scene.cpp:222-253,
  * RenderShader::setManualLighting render_shader.cpp:298-316).                               */

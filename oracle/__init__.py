@@ -47,10 +47,12 @@ def render(pool_arrays, srec, drec, W, H, flags, depth_peel=None, shadow_res=204
     from stillleben_amd import _abi
 
     L = lib()
-    pos, nrm, uv, col, idx, tex = [np.ascontiguousarray(a) for a in pool_arrays]
+    pos, nrm, uv, col, idx, tex = [np.ascontiguousarray(a) for a in pool_arrays[:6]]
+    tan = np.ascontiguousarray(pool_arrays[6]) if len(pool_arrays) > 6 else None
     pool = _abi.MeshPool()
     pool.d_pos, pool.d_nrm, pool.d_uv, pool.d_col, pool.d_idx, pool.d_tex = (_p(a) for a in (pos, nrm, uv, col, idx, tex))
     pool.n_vertices, pool.n_indices, pool.n_tex_bytes = len(pos), len(idx), tex.size
+    pool.d_tan = _p(tan)
     if light_maps:
         # light_maps: list of (buffers dict as returned by light_map_build, sizes dict) -- host memory
         recs = (_abi.LightMapRec * len(light_maps))()

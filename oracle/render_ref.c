@@ -317,6 +317,25 @@ static void tex_bilinear(const uint8_t* tex, int w, int h, float u, float v, flo
     }
 }
 
+/* rectangle texture (the sticker, frag:254): unnormalised texel coordinates, LINEAR, clamp to edge; the
+   image is stored top row first while GL texel row 0 is the bottom row of an imported image */
+static void tex_rect_bilinear(const uint8_t* tex, int w, int h, float xt, float yt, float out[4])
+{
+    const float x = xt - 0.5f, y = yt - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    int x0 = (int)fx, x1 = (int)fx + 1, y0 = (int)fy, y1 = (int)fy + 1;
+    if (x0 < 0) x0 = 0; if (x0 > w - 1) x0 = w - 1; if (x1 < 0) x1 = 0; if (x1 > w - 1) x1 = w - 1;
+    if (y0 < 0) y0 = 0; if (y0 > h - 1) y0 = h - 1; if (y1 < 0) y1 = 0; if (y1 > h - 1) y1 = h - 1;
+    y0 = (h - 1) - y0; y1 = (h - 1) - y1;
+    for (int c = 0; c < 4; ++c) {
+        const float a = (float)tex[4 * ((size_t)y0 * w + x0) + c] / 255.0f, b = (float)tex[4 * ((size_t)y0 * w + x1) + c] / 255.0f;
+        const float cc = (float)tex[4 * ((size_t)y1 * w + x0) + c] / 255.0f, d = (float)tex[4 * ((size_t)y1 * w + x1) + c] / 255.0f;
+        const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - cc, cc);
+        out[c] = fmaf(ay, bot - top, top);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* PBR shading (render_shader.frag:181-221, 248-399)                                           */
 /* ------------------------------------------------------------------------------------------ */
@@ -377,6 +396,7 @@ typedef struct {
 
 static void shade_fragment(const shade_ctx* cx, const slhip_draw* dr, const float base_in[4],
                            const float world[3], const float nrm_in[3], int front_facing,
+                           float roughness_in, float metallic_in, float occlusion, const float emissive[3],
                            float color[4], float normal_out[4])
 {
     const slhip_scene* sc = cx->sc;
@@ -389,8 +409,8 @@ static void shade_fragment(const shade_ctx* cx, const slhip_draw* dr, const floa
     normalize3(V);
     float NoV = clampf(dot3(normal, V), 1e-5f, 1.0f);
 
-    float roughness = fmaxf(dr->roughness, 0.045f);
-    float metallic = dr->metallic;
+    float roughness = fmaxf(roughness_in, 0.045f);
+    float metallic = metallic_in;
 
     color[0] = color[1] = color[2] = 0.0f;
     color[3] = base[3];
@@ -472,10 +492,10 @@ static void shade_fragment(const shade_ctx* cx, const slhip_draw* dr, const floa
             const float F_avg = F0[c] + (1.0f - F0[c]) / 21.0f;
             const float FmsEms = Ems * FssEss * F_avg / (1.0f - F_avg * Ems);
             const float k_D = c_diff * (1.0f - FssEss - FmsEms);
-            color[c] += FssEss * rad[c] + (FmsEms + k_D) * irr[c];
+            color[c] += (FssEss * rad[c] + (FmsEms + k_D) * irr[c]) * occlusion;
         }
     }
-    for (int c = 0; c < 3; ++c) color[c] += dr->emissive[c];
+    for (int c = 0; c < 3; ++c) color[c] += emissive[c];
 
     /* normalOut (frag:404-405): camera-frame normal and n.v */
     float nc[3];
@@ -846,9 +866,9 @@ int slref_render(const slhip_mesh_pool* pool, const slhip_scene* scenes, const s
                             if (depth_peel && (camz - 0.00001f <= depth_peel[4 * (base + p) + 3])) continue;
 
                             float basec[4] = {dr->base_color[0], dr->base_color[1], dr->base_color[2], dr->base_color[3]};
+                            const float u = interp(b, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]);
+                            const float v = interp(b, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]);
                             if (tex) {
-                                float u = interp(b, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]);
-                                float v = interp(b, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]);
                                 float tc[4];
                                 tex_bilinear(tex, (int)dr->tex_w, (int)dr->tex_h, u, v, tc);
                                 basec[0] *= powf(tc[0], 2.2f);
@@ -867,8 +887,68 @@ int slref_render(const slhip_mesh_pool* pool, const slhip_scene* scenes, const s
                                 objc[k] = interp(b, vo[0].objc[k], vo[1].objc[k], vo[2].objc[k]);
                                 cam[k] = interp(b, vo[0].cam[k], vo[1].cam[k], vo[2].cam[k]);
                             }
+                            if (dr->flags & SLHIP_DRAW_HAS_STICKER) { /* vert:89-94, frag:248-256 */
+                                float sx[3], sy[3];
+                                for (int k = 0; k < 3; ++k) {
+                                    const float* pp = pool->d_pos + 4 * (size_t)(dr->vtx_base + vi[k]);
+                                    const float pos[4] = {pp[0], pp[1], pp[2], 1.0f};
+                                    float obj4[4], sp[4];
+                                    mv4(dr->mesh_to_object, pos, obj4);
+                                    mv4(dr->sticker_projection, obj4, sp);
+                                    sx[k] = (sp[0] / sp[3] - dr->sticker_range[0]) / dr->sticker_range[2];
+                                    sy[k] = (sp[1] / sp[3] - dr->sticker_range[1]) / dr->sticker_range[3];
+                                }
+                                const float cxs = interp(b, sx[0], sx[1], sx[2]), cys = interp(b, sy[0], sy[1], sy[2]);
+                                if (cxs >= 0.0f && cys >= 0.0f && cxs < 1.0f && cys < 1.0f) {
+                                    float st[4];
+                                    tex_rect_bilinear(pool->d_tex + dr->sticker_tex_offset, (int)dr->sticker_tex_w, (int)dr->sticker_tex_h,
+                                                      cxs * (float)dr->sticker_tex_w, cys * (float)dr->sticker_tex_h, st);
+                                    const float sc4[4] = {powf(st[0], 2.2f), powf(st[1], 2.2f), powf(st[2], 2.2f), st[3]};
+                                    for (int c = 0; c < 4; ++c) basec[c] = basec[c] * (1.0f - st[3]) + sc4[c] * st[3];
+                                }
+                            }
+                            if (dr->flags & SLHIP_DRAW_HAS_NORMAL_TEX) { /* vert:77-80, frag:262-266 */
+                                float tw[3][3], bw[3][3];
+                                for (int k = 0; k < 3; ++k) {
+                                    const float* t4 = pool->d_tan + 4 * (size_t)(dr->vtx_base + vi[k]);
+                                    const float tv[3] = {t4[0], t4[1], t4[2]};
+                                    mv3p(dr->normal_to_world, tv, tw[k]);
+                                    normalize3(tw[k]);
+                                    bw[k][0] = vo[k].nrm[1] * tw[k][2] - vo[k].nrm[2] * tw[k][1];
+                                    bw[k][1] = vo[k].nrm[2] * tw[k][0] - vo[k].nrm[0] * tw[k][2];
+                                    bw[k][2] = vo[k].nrm[0] * tw[k][1] - vo[k].nrm[1] * tw[k][0];
+                                    normalize3(bw[k]);
+                                    for (int c = 0; c < 3; ++c) bw[k][c] *= t4[3];
+                                }
+                                float tc[4];
+                                tex_bilinear(pool->d_tex + dr->normal_tex_offset, (int)dr->normal_tex_w, (int)dr->normal_tex_h, u, v, tc);
+                                const float nx = tc[0] * 2.0f - 1.0f, ny = tc[1] * 2.0f - 1.0f, nz = tc[2] * 2.0f - 1.0f;
+                                float nn[3];
+                                for (int c = 0; c < 3; ++c)
+                                    nn[c] = nx * interp(b, tw[0][c], tw[1][c], tw[2][c]) + ny * interp(b, bw[0][c], bw[1][c], bw[2][c]) + nz * nrm[c];
+                                normalize3(nn);
+                                nrm[0] = nn[0]; nrm[1] = nn[1]; nrm[2] = nn[2];
+                            }
+                            float roughness = dr->roughness, metallic = dr->metallic, occlusion = 1.0f;
+                            float emissive[3] = {dr->emissive[0], dr->emissive[1], dr->emissive[2]};
+                            if (dr->flags & SLHIP_DRAW_HAS_MR_TEX) { /* frag:284-288 */
+                                float tc[4];
+                                tex_bilinear(pool->d_tex + dr->mr_tex_offset, (int)dr->mr_tex_w, (int)dr->mr_tex_h, u, v, tc);
+                                roughness *= tc[1];
+                                metallic *= tc[2];
+                            }
+                            if (dr->flags & SLHIP_DRAW_HAS_OCCLUSION_TEX) { /* frag:292-294 */
+                                float tc[4];
+                                tex_bilinear(pool->d_tex + dr->occlusion_tex_offset, (int)dr->occlusion_tex_w, (int)dr->occlusion_tex_h, u, v, tc);
+                                occlusion = tc[0];
+                            }
+                            if (dr->flags & SLHIP_DRAW_HAS_EMISSIVE_TEX) { /* frag:296-298 */
+                                float tc[4];
+                                tex_bilinear(pool->d_tex + dr->emissive_tex_offset, (int)dr->emissive_tex_w, (int)dr->emissive_tex_h, u, v, tc);
+                                for (int c = 0; c < 3; ++c) emissive[c] *= powf(tc[c], 2.2f);
+                            }
                             float color[4], nout[4];
-                            shade_fragment(&cx, dr, basec, world, nrm, front_facing, color, nout);
+                            shade_fragment(&cx, dr, basec, world, nrm, front_facing, roughness, metallic, occlusion, emissive, color, nout);
                             for (int c = 0; c < 4; ++c) hdr[4 * p + c] = color[c];
                             camc[4 * p + 0] = cam[0]; camc[4 * p + 1] = cam[1];
                             camc[4 * p + 2] = cam[2]; camc[4 * p + 3] = 1.0f;

@@ -17,6 +17,11 @@ DRAW_VERTEX_COLORS = 2
 DRAW_CASTS_SHADOW = 4
 DRAW_ALPHA_TEST = 8
 DRAW_NO_VERTEX_ID = 16
+DRAW_HAS_NORMAL_TEX = 32
+DRAW_HAS_MR_TEX = 64
+DRAW_HAS_OCCLUSION_TEX = 128
+DRAW_HAS_EMISSIVE_TEX = 256
+DRAW_HAS_STICKER = 512
 
 OUT_RGB = 0x01
 OUT_COORD = 0x02
@@ -38,6 +43,7 @@ class MeshPool(C.Structure):
         ("d_nrm", C.c_void_p),
         ("d_uv", C.c_void_p),
         ("d_col", C.c_void_p),
+        ("d_tan", C.c_void_p),
         ("d_idx", C.c_void_p),
         ("d_tex", C.c_void_p),
         ("n_vertices", C.c_uint64),
@@ -89,10 +95,18 @@ DRAW_DTYPE = np.dtype(
         ("tex_w", np.uint32),
         ("tex_h", np.uint32),
         ("clip_base", np.uint32),
+        ("normal_tex", np.uint32, (3,)),      # offset, w, h
+        ("mr_tex", np.uint32, (3,)),
+        ("occlusion_tex", np.uint32, (3,)),
+        ("emissive_tex", np.uint32, (3,)),
+        ("sticker_tex", np.uint32, (3,)),
+        ("_pad", np.uint32),
+        ("sticker_projection", np.float32, (16,)),
+        ("sticker_range", np.float32, (4,)),
     ],
     align=False,
 )
-assert DRAW_DTYPE.itemsize == 272, DRAW_DTYPE.itemsize
+assert DRAW_DTYPE.itemsize == 416, DRAW_DTYPE.itemsize
 
 SCENE_DTYPE = np.dtype(
     [

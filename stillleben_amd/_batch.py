@@ -23,6 +23,7 @@ class HostPool:
         self.nrm = [np.array([[0, 0, 1, 0]] * 4, np.float32)]
         self.uv = [np.array([[1, 0], [1, 1], [0, 0], [0, 1]], np.float32)]
         self.col = [np.ones((4, 4), np.float32)]
+        self.tan = [np.array([[1, 0, 0, 1]] * 4, np.float32)]
         self.idx = [np.array([0, 1, 2, 2, 1, 3], np.uint32)]
         self.tex = []
         self.n_vertices = 4
@@ -62,6 +63,8 @@ class HostPool:
         self.nrm.append(np.concatenate([d.normals, np.zeros((nv, 1), np.float32)], axis=1))
         self.uv.append(d.uvs.astype(np.float32))
         self.col.append(d.colors.astype(np.float32))
+        tan = getattr(d, "tangents", None)
+        self.tan.append(np.zeros((nv, 4), np.float32) if tan is None else np.ascontiguousarray(tan, dtype=np.float32))
         self.idx.append(d.indices.astype(np.uint32))
         self.n_vertices += nv
         self.n_indices += ni
@@ -85,7 +88,7 @@ class HostPool:
         self.col[0][v0:v0 + nv] = d.colors
 
     def _flatten(self):
-        for name in ("pos", "nrm", "uv", "col", "idx", "tex"):
+        for name in ("pos", "nrm", "uv", "col", "tan", "idx", "tex"):
             lst = getattr(self, name)
             if len(lst) > 1:
                 setattr(self, name, [np.concatenate(lst)])
@@ -93,7 +96,7 @@ class HostPool:
     def arrays(self):
         self._flatten()
         tex = self.tex[0] if self.tex else np.zeros(4, np.uint8)
-        return self.pos[0], self.nrm[0], self.uv[0], self.col[0], self.idx[0], tex
+        return self.pos[0], self.nrm[0], self.uv[0], self.col[0], self.idx[0], tex, self.tan[0]
 
 
 def _effective_material(mat, obj):
@@ -209,6 +212,23 @@ def build_batch(scenes, pool, predicate=None, with_shadows=True):
                         flags |= _abi.DRAW_ALPHA_TEST
                     d["tex_offset"] = slot.tex_offsets[mat.base_texture]
                     d["tex_w"], d["tex_h"] = slot.tex_sizes[mat.base_texture]
+                for attr, field, bit in (("normal_texture", "normal_tex", _abi.DRAW_HAS_NORMAL_TEX),
+                                         ("mr_texture", "mr_tex", _abi.DRAW_HAS_MR_TEX),
+                                         ("occlusion_texture", "occlusion_tex", _abi.DRAW_HAS_OCCLUSION_TEX),
+                                         ("emissive_texture", "emissive_tex", _abi.DRAW_HAS_EMISSIVE_TEX)):
+                    ti = getattr(mat, attr, None)
+                    if ti is not None:
+                        flags |= bit
+                        d[field] = (slot.tex_offsets[ti],) + tuple(slot.tex_sizes[ti])
+                st = obj._sticker_texture
+                if st is not None and obj._sticker_range is not None:
+                    # render_pass.cpp:601-606: projection + range per object, the rectangle texture if one is set
+                    off, w, h = pool.add_texture(st._rgba)
+                    flags |= _abi.DRAW_HAS_STICKER
+                    d["sticker_tex"] = (off, w, h)
+                    d["sticker_projection"] = obj.sticker_view_projection().reshape(-1)
+                    r = np.asarray(obj._sticker_range, dtype=np.float32)   # min.x, min.y, max.x, max.y
+                    d["sticker_range"] = (r[0], r[1], max(f32(1e-6), r[2] - r[0]), max(f32(1e-6), r[3] - r[1]))
                 d["flags"] = flags
                 d["vtx_base"] = slot.vtx_base
                 d["idx_base"] = slot.idx_base + sm.first_index

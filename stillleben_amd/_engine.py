@@ -74,7 +74,8 @@ class Engine:
             self.pool.dirty = False
         p = _abi.MeshPool()
         d = self._pool_dev
-        p.d_pos, p.d_nrm, p.d_uv, p.d_col, p.d_idx, p.d_tex = (_ptr(t) for t in d)
+        p.d_pos, p.d_nrm, p.d_uv, p.d_col, p.d_idx, p.d_tex = (_ptr(t) for t in d[:6])
+        p.d_tan = _ptr(d[6])
         p.n_vertices, p.n_indices, p.n_tex_bytes = self.pool.n_vertices, self.pool.n_indices, self.pool.n_tex_bytes
         if self._light_maps:
             if self._light_maps_dev is None:

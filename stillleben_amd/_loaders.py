@@ -31,13 +31,19 @@ class Material:
     (reference src/shaders/render_shader.cpp:326-417)."""
 
     def __init__(self, base_color=(1.0, 1.0, 1.0, 1.0), metallic=None, roughness=None,
-                 emissive=(0.0, 0.0, 0.0), base_texture=None):
+                 emissive=(0.0, 0.0, 0.0), base_texture=None, normal_texture=None, mr_texture=None,
+                 occlusion_texture=None, emissive_texture=None):
         self.base_color = np.asarray(base_color, dtype=np.float32)
         # None == attribute absent in the file => shader defaults 0.04 / 0.5
         self.metallic = metallic
         self.roughness = roughness
         self.emissive = np.asarray(emissive, dtype=np.float32)
         self.base_texture = base_texture  # index into ConsolidatedMesh.textures or None
+        # further inputs of RenderShader::setMaterial (render_shader.cpp:395-415), same indexing
+        self.normal_texture = normal_texture
+        self.mr_texture = mr_texture              # roughness in G, metallic in B
+        self.occlusion_texture = occlusion_texture
+        self.emissive_texture = emissive_texture
 
 
 class ConsolidatedMesh:
@@ -46,6 +52,7 @@ class ConsolidatedMesh:
         self.normals = np.zeros((0, 3), np.float32)
         self.uvs = np.zeros((0, 2), np.float32)
         self.colors = np.zeros((0, 4), np.float32)
+        self.tangents = None   # f32 [V,4] (xyz, bitangent sign) or None = zeros
         self.has_vertex_colors = False
         self.indices = np.zeros((0,), np.uint32)
         self.submeshes = []
@@ -63,6 +70,33 @@ def _smooth_normals(pos, idx):
     ln = np.linalg.norm(n, axis=1, keepdims=True)
     ln[ln == 0] = 1.0
     return (n / ln).astype(np.float32)
+
+
+def compute_tangents(pos, nrm, uv, idx):
+    """mesh_tools::computeTangents (src/mesh_tools/compute_tangents.cpp:26-137): per-triangle tangent /
+    bitangent from the UV parametrisation, averaged per vertex, bitangent sign in w.  float32 like the
+    reference; a degenerate UV triangle poisons its vertices with inf / nan there as well."""
+    nv = len(pos)
+    tan = np.zeros((nv, 3), np.float32)
+    bit = np.zeros((nv, 3), np.float32)
+    deg = np.zeros(nv, np.float32)
+    f = idx.reshape(-1, 3).astype(np.int64)
+    with np.errstate(all="ignore"):
+        d1, d2 = pos[f[:, 1]] - pos[f[:, 0]], pos[f[:, 2]] - pos[f[:, 0]]
+        u1, u2 = uv[f[:, 1]] - uv[f[:, 0]], uv[f[:, 2]] - uv[f[:, 0]]
+        r = (np.float32(1.0) / (u1[:, 0] * u2[:, 1] - u1[:, 1] * u2[:, 0])).astype(np.float32)
+        t = ((d1 * u2[:, 1:2] - d2 * u1[:, 1:2]) * r[:, None]).astype(np.float32)
+        b = ((d2 * u1[:, 0:1] - d1 * u2[:, 0:1]) * r[:, None]).astype(np.float32)
+        for k in range(3):   # sequential accumulation order = face order, as in the reference loop
+            np.add.at(tan, f[:, k], t)
+            np.add.at(bit, f[:, k], b)
+            np.add.at(deg, f[:, k], 1.0)
+        tan = tan / deg[:, None]
+        bit = bit / deg[:, None]
+        tan = tan / np.sqrt((tan * tan).sum(axis=1, keepdims=True))
+        bit = bit / np.sqrt((bit * bit).sum(axis=1, keepdims=True))
+        sign = np.sign((np.cross(nrm, tan) * bit).sum(axis=1)).astype(np.float32)
+    return np.concatenate([tan.astype(np.float32), sign[:, None]], axis=1).astype(np.float32)
 
 
 def _load_image(data):
@@ -194,7 +228,13 @@ def load_gltf(path):
             metallic = pbr.get("metallicFactor", 1.0)
             roughness = pbr.get("roughnessFactor", 1.0)
             has_mr_tex = "metallicRoughnessTexture" in pbr
+
+            def opt_tex(container, key):
+                return texture_index(container[key]["index"])[0] if key in container else None
+
             m = Material(
+                normal_texture=opt_tex(md, "normalTexture"), mr_texture=opt_tex(pbr, "metallicRoughnessTexture"),
+                occlusion_texture=opt_tex(md, "occlusionTexture"), emissive_texture=opt_tex(md, "emissiveTexture"),
                 base_color=pbr.get("baseColorFactor", (1.0, 1.0, 1.0, 1.0)),
                 metallic=None if (metallic == 1.0 and not has_mr_tex) else metallic,
                 roughness=None if (roughness == 1.0 and not has_mr_tex) else roughness,
@@ -210,7 +250,7 @@ def load_gltf(path):
         mat_cache[mid] = len(out.materials) - 1
         return mat_cache[mid]
 
-    pos_l, nrm_l, uv_l, col_l, idx_l = [], [], [], [], []
+    pos_l, nrm_l, uv_l, col_l, idx_l, tan_l = [], [], [], [], [], []
     v_off = 0
     i_off = 0
 
@@ -237,10 +277,19 @@ def load_gltf(path):
             out.has_vertex_colors = True
         else:
             c = np.ones((n, 4), np.float32)
+        # tangents: the file's, else computed from the UVs (consolidate.cpp:90-94); a mesh without UVs gets zeros
+        if "TANGENT" in attrs:
+            tan = accessor(attrs["TANGENT"]).astype(np.float32)
+        elif "TEXCOORD_0" in attrs:
+            tan = compute_tangents(pos, nrm, uv, idx)
+        else:
+            tan = np.zeros((n, 4), np.float32)
         T = transform.astype(np.float32)
         # transformPoint / transformVector of the baked node transform (consolidate.cpp:252-294)
         pos_t = (pos @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
         nrm_t = (nrm @ T[:3, :3].T).astype(np.float32)
+        # quirk kept: consolidate.cpp:275-279 writes Vector4{transformVector(tangent.xyz), 1.0f} -- the bitangent sign is lost
+        tan_l.append(np.concatenate([(tan[:, :3] @ T[:3, :3].T).astype(np.float32), np.ones((n, 1), np.float32)], axis=1))
         pos_l.append(pos_t)
         nrm_l.append(nrm_t)
         uv_l.append(uv)
@@ -271,6 +320,7 @@ def load_gltf(path):
     out.normals = np.concatenate(nrm_l)
     out.uvs = np.concatenate(uv_l)
     out.colors = np.concatenate(col_l)
+    out.tangents = np.concatenate(tan_l)
     out.indices = np.concatenate(idx_l)
     out._tex_alpha = [a for (_, a) in sorted(image_cache.values())]
     return out

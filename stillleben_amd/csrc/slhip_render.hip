@@ -24,7 +24,7 @@
 
 namespace {
 
-static_assert(sizeof(slhip_draw) == 272, "slhip_draw layout");
+static_assert(sizeof(slhip_draw) == 416, "slhip_draw layout");
 static_assert(sizeof(slhip_scene) == 480, "slhip_scene layout");
 static_assert(sizeof(slhip_chunk) == 16, "slhip_chunk layout");
 
@@ -374,6 +374,30 @@ __device__ __forceinline__ void tex_bilinear(const uint8_t* __restrict__ tex, in
     const float ax = x - fx, ay = y - fy;
     const int x0 = wrapi((int)fx, w), y0 = wrapi((int)fy, h);
     const int x1 = wrapi((int)fx + 1, w), y1 = wrapi((int)fy + 1, h);
+    const uchar4 t00 = reinterpret_cast<const uchar4*>(tex)[(size_t)y0 * w + x0];
+    const uchar4 t10 = reinterpret_cast<const uchar4*>(tex)[(size_t)y0 * w + x1];
+    const uchar4 t01 = reinterpret_cast<const uchar4*>(tex)[(size_t)y1 * w + x0];
+    const uchar4 t11 = reinterpret_cast<const uchar4*>(tex)[(size_t)y1 * w + x1];
+    const unsigned char c00[4] = {t00.x, t00.y, t00.z, t00.w}, c10[4] = {t10.x, t10.y, t10.z, t10.w};
+    const unsigned char c01[4] = {t01.x, t01.y, t01.z, t01.w}, c11[4] = {t11.x, t11.y, t11.z, t11.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float a = (float)c00[c] / 255.0f, b = (float)c10[c] / 255.0f;
+        const float cc = (float)c01[c] / 255.0f, d = (float)c11[c] / 255.0f;
+        const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - cc, cc);
+        out[c] = fmaf(ay, bot - top, top);
+    }
+}
+
+// rectangle texture (the sticker, render_shader.frag:254): unnormalised texel coordinates, LINEAR, clamp to
+// edge.  The image is stored top row first while GL texel row 0 is the BOTTOM row of an imported image.
+__device__ __forceinline__ void tex_rect_bilinear(const uint8_t* __restrict__ tex, int w, int h, float xt, float yt, float* out)
+{
+    const float x = xt - 0.5f, y = yt - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    const int x0 = min(max((int)fx, 0), w - 1), x1 = min(max((int)fx + 1, 0), w - 1);
+    const int y0 = (h - 1) - min(max((int)fy, 0), h - 1), y1 = (h - 1) - min(max((int)fy + 1, 0), h - 1);
     const uchar4 t00 = reinterpret_cast<const uchar4*>(tex)[(size_t)y0 * w + x0];
     const uchar4 t10 = reinterpret_cast<const uchar4*>(tex)[(size_t)y0 * w + x1];
     const uchar4 t01 = reinterpret_cast<const uchar4*>(tex)[(size_t)y1 * w + x0];
@@ -886,7 +910,8 @@ __device__ __forceinline__ float shadow_pcf16(const float* __restrict__ sm, int 
 __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ sc, const slhip_draw* __restrict__ dr,
                                                const float* base, const float* world, const float* nrm_in,
                                                bool front_facing, const float* __restrict__ shadow, int S,
-                                               const slhip_light_map* __restrict__ lm, float* color, float* normal_out)
+                                               const slhip_light_map* __restrict__ lm, float roughness_in, float metallic_in,
+                                               float occlusion, const float* emissive, float* color, float* normal_out)
 {
     float normal[3] = {nrm_in[0], nrm_in[1], nrm_in[2]};
     if (!front_facing) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
@@ -894,8 +919,8 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
                   sc->cam_position[2] - world[2]};
     normalize3(V);
     const float NoV = clampf(dot3(normal, V), 1e-5f, 1.0f);
-    const float roughness = fmaxf(dr->roughness, 0.045f);
-    const float metallic = dr->metallic;
+    const float roughness = fmaxf(roughness_in, 0.045f);
+    const float metallic = metallic_in;
 
     color[0] = color[1] = color[2] = 0.0f;
     color[3] = base[3];
@@ -971,11 +996,11 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
             const float F_avg = F0[c] + (1.0f - F0[c]) / 21.0f;
             const float FmsEms = Ems * FssEss * F_avg / (1.0f - F_avg * Ems);
             const float k_D = c_diff * (1.0f - FssEss - FmsEms);
-            color[c] += FssEss * rad[c] + (FmsEms + k_D) * irr[c];
+            color[c] += (FssEss * rad[c] + (FmsEms + k_D) * irr[c]) * occlusion;
         }
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) color[c] += dr->emissive[c];
+    for (int c = 0; c < 3; ++c) color[c] += emissive[c];
     float nc[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -1129,9 +1154,9 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
             if (found) {
                 const float camz = interp(b, vo[0].objc[3], vo[1].objc[3], vo[2].objc[3]);
                 float base[4] = {dr->base_color[0], dr->base_color[1], dr->base_color[2], dr->base_color[3]};
+                const float u = interp(b, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]);
+                const float v = interp(b, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]);
                 if (dr->flags & SLHIP_DRAW_HAS_BASE_TEX) {
-                    const float u = interp(b, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]);
-                    const float v = interp(b, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]);
                     float tc[4];
                     tex_bilinear(pool.d_tex + dr->tex_offset, (int)dr->tex_w, (int)dr->tex_h, u, v, tc);
                     base[0] *= powf(tc[0], 2.2f);
@@ -1149,10 +1174,79 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                 }
                 coord[3] = camz;
                 camc[3] = 1.0f;
+                if (dr->flags & SLHIP_DRAW_HAS_STICKER) {
+                    // projected decal (render_shader.vert:89-94, frag:248-256): per-vertex projection of the object
+                    // coordinates into the sticker frame, interpolated like every other varying
+                    float sx[3], sy[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float4 p4 = reinterpret_cast<const float4*>(pool.d_pos)[dr->vtx_base + vi[k]];
+                        const float pos[4] = {p4.x, p4.y, p4.z, 1.0f};
+                        float obj4[4], sp[4];
+                        mv4(dr->mesh_to_object, pos, obj4);
+                        mv4(dr->sticker_projection, obj4, sp);
+                        sx[k] = (sp[0] / sp[3] - dr->sticker_range[0]) / dr->sticker_range[2];
+                        sy[k] = (sp[1] / sp[3] - dr->sticker_range[1]) / dr->sticker_range[3];
+                    }
+                    const float cx = interp(b, sx[0], sx[1], sx[2]), cy = interp(b, sy[0], sy[1], sy[2]);
+                    if (cx >= 0.0f && cy >= 0.0f && cx < 1.0f && cy < 1.0f) {
+                        float st[4];
+                        tex_rect_bilinear(pool.d_tex + dr->sticker_tex_offset, (int)dr->sticker_tex_w, (int)dr->sticker_tex_h,
+                                          cx * (float)dr->sticker_tex_w, cy * (float)dr->sticker_tex_h, st);
+                        const float sc4[4] = {powf(st[0], 2.2f), powf(st[1], 2.2f), powf(st[2], 2.2f), st[3]};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) base[c] = base[c] * (1.0f - st[3]) + sc4[c] * st[3];   // mix(base, sticker, sticker.a)
+                    }
+                }
+                if (dr->flags & SLHIP_DRAW_HAS_NORMAL_TEX) {
+                    // tangent-space normal map (vert:77-80, frag:262-266)
+                    float tw[3][3], bw[3][3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float4 t4 = reinterpret_cast<const float4*>(pool.d_tan)[dr->vtx_base + vi[k]];
+                        const float tv[3] = {t4.x, t4.y, t4.z};
+                        mv3p(dr->normal_to_world, tv, tw[k]);
+                        normalize3(tw[k]);
+                        bw[k][0] = vo[k].nrm[1] * tw[k][2] - vo[k].nrm[2] * tw[k][1];
+                        bw[k][1] = vo[k].nrm[2] * tw[k][0] - vo[k].nrm[0] * tw[k][2];
+                        bw[k][2] = vo[k].nrm[0] * tw[k][1] - vo[k].nrm[1] * tw[k][0];
+                        normalize3(bw[k]);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) bw[k][c] *= t4.w;
+                    }
+                    float tc[4];
+                    tex_bilinear(pool.d_tex + dr->normal_tex_offset, (int)dr->normal_tex_w, (int)dr->normal_tex_h, u, v, tc);
+                    const float nx = tc[0] * 2.0f - 1.0f, ny = tc[1] * 2.0f - 1.0f, nz = tc[2] * 2.0f - 1.0f;
+                    float nn[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        nn[c] = nx * interp(b, tw[0][c], tw[1][c], tw[2][c]) + ny * interp(b, bw[0][c], bw[1][c], bw[2][c]) + nz * nrm[c];
+                    normalize3(nn);
+                    nrm[0] = nn[0]; nrm[1] = nn[1]; nrm[2] = nn[2];
+                }
+                float roughness = dr->roughness, metallic = dr->metallic, occlusion = 1.0f;
+                float emissive[3] = {dr->emissive[0], dr->emissive[1], dr->emissive[2]};
+                if (dr->flags & SLHIP_DRAW_HAS_MR_TEX) {
+                    float tc[4];
+                    tex_bilinear(pool.d_tex + dr->mr_tex_offset, (int)dr->mr_tex_w, (int)dr->mr_tex_h, u, v, tc);
+                    roughness *= tc[1];
+                    metallic *= tc[2];
+                }
+                if (dr->flags & SLHIP_DRAW_HAS_OCCLUSION_TEX) {
+                    float tc[4];
+                    tex_bilinear(pool.d_tex + dr->occlusion_tex_offset, (int)dr->occlusion_tex_w, (int)dr->occlusion_tex_h, u, v, tc);
+                    occlusion = tc[0];
+                }
+                if (dr->flags & SLHIP_DRAW_HAS_EMISSIVE_TEX) {
+                    float tc[4];
+                    tex_bilinear(pool.d_tex + dr->emissive_tex_offset, (int)dr->emissive_tex_w, (int)dr->emissive_tex_h, u, v, tc);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) emissive[c] *= powf(tc[c], 2.2f);
+                }
                 const float* sm = (prm.flags & SLHIP_RENDER_SHADOWS) && shadow
                                       ? shadow + (size_t)scene * SLHIP_NUM_LIGHTS * prm.S * prm.S
                                       : nullptr;
-                shade_fragment(sc, dr, base, world, nrm, front, sm, prm.S, lm, color, nout);
+                shade_fragment(sc, dr, base, world, nrm, front, sm, prm.S, lm, roughness, metallic, occlusion, emissive, color, nout);
                 cls = dr->class_index & 0xFFFFu;
                 inst = dr->instance_index & 0xFFFFu;
                 if (!(dr->flags & SLHIP_DRAW_NO_VERTEX_ID)) { vidx[0] = vi[0] + 1; vidx[1] = vi[1] + 1; vidx[2] = vi[2] + 1; }

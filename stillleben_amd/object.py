@@ -35,7 +35,7 @@ class Object:
         self._restitution = f32(0.1)
         self._mass_props = None
         self._scene = None
-        # sticker decals are out of scope; setters are accepted
+        # sticker decal (object.h:250-262): range in the sticker frame, rotation of that frame, rectangle texture
         self._sticker_range = None
         self._sticker_rotation = None
         self._sticker_texture = None
@@ -133,13 +133,50 @@ class Object:
     def angular_velocity(self, v):
         self._angular_velocity = as_vec(v, 3)
 
-    # ---- sticker (accepted, not rendered) -------------------------------------------------------
-    sticker_range = property(lambda self: self._sticker_range,
-                             lambda self, v: setattr(self, "_sticker_range", v))
-    sticker_rotation = property(lambda self: self._sticker_rotation,
-                                lambda self, v: setattr(self, "_sticker_rotation", v))
-    sticker_texture = property(lambda self: self._sticker_texture,
-                               lambda self, v: setattr(self, "_sticker_texture", v))
+    # ---- sticker decal (object.cpp:480-513; rendered by render_shader.vert:89-94 / frag:248-256) --------
+    @property
+    def sticker_range(self):
+        return self._sticker_range
+
+    @sticker_range.setter
+    def sticker_range(self, v):
+        """Range2D in the sticker projection frame: (min.x, min.y, max.x, max.y) or a Range2D-like object."""
+        if v is None:
+            self._sticker_range = None
+            return
+        if hasattr(v, "min") and hasattr(v, "max"):
+            v = list(np.asarray(v.min, dtype=np.float32).reshape(-1)[:2]) + list(np.asarray(v.max, dtype=np.float32).reshape(-1)[:2])
+        self._sticker_range = as_vec(v, 4)
+
+    @property
+    def sticker_rotation(self):
+        return self._sticker_rotation
+
+    @sticker_rotation.setter
+    def sticker_rotation(self, q):
+        self._sticker_rotation = None if q is None else as_vec(q, 4)   # quaternion x y z w
+
+    @property
+    def sticker_texture(self):
+        return self._sticker_texture
+
+    @sticker_texture.setter
+    def sticker_texture(self, tex):
+        self._sticker_texture = tex
+
+    def sticker_view_projection(self):
+        """Object::stickerViewProjection (object.cpp:494-513): proj * translate(0,0,1) * rotation."""
+        from . import _math as M
+
+        diagonal = self._mesh.bbox.np_diagonal()
+        # Magnum's constructor takes COLUMNS: the reference's 4 vectors are the columns of proj
+        proj = np.array([[f32(2.0) / diagonal, 0, 0, 0], [0, f32(2.0) / diagonal, 0, 0], [0, 0, 1, 0], [0, 0, 1, 1]], np.float32).T
+        trans = np.eye(4, dtype=np.float32)
+        trans[2, 3] = 1.0
+        rot = np.eye(4, dtype=np.float32)
+        q = self._sticker_rotation if self._sticker_rotation is not None else np.array([0, 0, 0, 1], np.float32)
+        rot[:3, :3] = M.quat_to_matrix(q)
+        return (proj @ trans @ rot).astype(np.float32)
 
     # ---- mass properties (object.cpp:215-257; PxRigidBodyExt::updateMassAndInertia) --------------
     def _props(self):

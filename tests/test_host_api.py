@@ -205,8 +205,8 @@ def test_quaternion_helpers_and_alias_package(sl):
 
 
 def test_out_of_scope_shims_fail_loudly(sl):
-    with pytest.raises(NotImplementedError):
-        sl.LightMap("x.ibl")
+    with pytest.raises(RuntimeError):
+        sl.LightMap("x.ibl")          # image-based lighting exists (row f1): a missing file is reported like the reference does
     with pytest.raises(NotImplementedError):
         sl.Viewer()
     scene = sl.Scene((64, 48))
