@@ -82,7 +82,8 @@ typedef struct {
 
 /* draw flags */
 #define SLHIP_DRAW_HAS_BASE_TEX   1u  /* base colour texture bound (render_shader.cpp:430-433)   */
-#define SLHIP_DRAW_VERTEX_COLORS  2u  /* multiply base colour by vertex colour                   */
+#define SLHIP_DRAW_VERTEX_COLORS  2u  /* mesh carries vertex colours; informational: the reference's
+                                         fragment shader never reads the varying (render_shader.vert:86) */
 #define SLHIP_DRAW_CASTS_SHADOW   4u  /* Object::castsShadows (render_pass.cpp:437)              */
 #define SLHIP_DRAW_ALPHA_TEST     8u  /* texture has an alpha channel: cut-off in the z pass     */
 #define SLHIP_DRAW_NO_VERTEX_ID  16u  /* mesh without the vertexIndex attribute (the background
