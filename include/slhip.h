@@ -89,12 +89,25 @@ typedef struct {
 #define SLHIP_DRAW_NO_VERTEX_ID  16u  /* mesh without the vertexIndex attribute (the background
                                          plane): vertex ids read 0 (render_pass.cpp:573-581)     */
 /* further material textures of RenderShader::setMaterial (render_shader.cpp:395-415), all RGBA8 in the
- * texel pool, sampled bilinearly on mip 0 with repeat wrapping like the base colour texture            */
+ * texel pool with their mip chains, sampled through the sampler of the asset file (see below)          */
 #define SLHIP_DRAW_HAS_NORMAL_TEX    32u  /* tangent-space normal map (render_shader.frag:262-266)      */
 #define SLHIP_DRAW_HAS_MR_TEX        64u  /* roughness in G, metallic in B (frag:284-288)               */
 #define SLHIP_DRAW_HAS_OCCLUSION_TEX 128u /* R scales the image-based lighting term (frag:292-294,393)  */
 #define SLHIP_DRAW_HAS_EMISSIVE_TEX  256u /* sRGB, multiplies the emissive factor (frag:296-298)        */
 #define SLHIP_DRAW_HAS_STICKER       512u /* projected decal (frag:248-256, object.cpp:494-513)         */
+
+/* Texture sampler state (one byte per texture of a draw).  Every 2D texture is stored with its full mip
+ * chain: level l has max(1, w >> l) x max(1, h >> l) texels and follows level l-1 directly; a level is the
+ * 2x2 box filter of the previous one, rounded to nearest (glGenerateMipmap leaves the filter to the
+ * implementation).  Level of detail per OpenGL 4.5 section 8.14: rho = max(|d(u,v)/dx|, |d(u,v)/dy|) in
+ * texels with forward differences of the perspective-correct coordinates to the pixel's +x / +y
+ * neighbours, lambda = log2(rho); lambda <= 0 uses the magnification filter on level 0.               */
+#define SLHIP_SAMPLER_WRAP_S(m)   ((m) & 3u)          /* 0 repeat, 1 clamp to edge, 2 mirrored repeat */
+#define SLHIP_SAMPLER_WRAP_T(m)   (((m) >> 2) & 3u)
+#define SLHIP_SAMPLER_MAG_LINEAR  0x10u               /* else nearest */
+#define SLHIP_SAMPLER_MIN_LINEAR  0x20u               /* else nearest */
+#define SLHIP_SAMPLER_MIP(m)      (((m) >> 6) & 3u)   /* 0 base level only, 1 nearest level, 2 linear between levels */
+#define SLHIP_SAMPLER_DEFAULT     (SLHIP_SAMPLER_MAG_LINEAR | SLHIP_SAMPLER_MIN_LINEAR | (2u << 6))   /* repeat, trilinear */
 
 /* One drawable (sub-mesh of an object, or the background plane) of one scene.
  * Carries what RenderShader::setTransformations / setMaterial / setClassIndex /
@@ -122,10 +135,12 @@ typedef struct {
     uint32_t occlusion_tex_offset, occlusion_tex_w, occlusion_tex_h;
     uint32_t emissive_tex_offset, emissive_tex_w, emissive_tex_h;
     uint32_t sticker_tex_offset, sticker_tex_w, sticker_tex_h;   /* rectangle texture, clamp to edge, row 0 = top of the image */
-    uint32_t _pad;
+    uint8_t  tex_sampler[8];     /* SLHIP_SAMPLER_* of the base, normal, metallic-roughness, occlusion, emissive
+                                    texture (mesh.cpp:656-663: the file's filters and wrapping, mipmaps generated) */
+    uint32_t _pad[3];
     float sticker_projection[16];  /* Object::stickerViewProjection, row-major (object.cpp:494-513)       */
     float sticker_range[4];        /* min.x, min.y, max(1e-6, size.x), max(1e-6, size.y) (render_shader.cpp:426-437) */
-} slhip_draw;                    /* 416 bytes */
+} slhip_draw;                    /* 432 bytes */
 
 /* Per-scene camera + lights (reference Scene::setCameraIntrinsics src/scene.cpp:222-253,
  * RenderShader::setManualLighting render_shader.cpp:298-316).                               */

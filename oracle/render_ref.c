@@ -250,6 +250,25 @@ static inline int coverage(const tri_setup* t, int px, int py, float lambda[3])
     return 1;
 }
 
+/* perspective-correct barycentrics (w.r.t. the original triangle) of pixel (px,py) on the plane of the
+   set-up sub-triangle, also outside its edges: the texture footprint */
+static inline void bary_at(const tri_setup* t, int px, int py, float b[3])
+{
+    int64_t cx = 256 * (int64_t)px + 128, cy = 256 * (int64_t)py + 128;
+    float l[3];
+    float fa = (float)t->area2;
+    for (int i = 0; i < 3; ++i) {
+        int a = (i + 1) % 3, c = (i + 2) % 3;
+        int64_t e = (t->X[c] - t->X[a]) * (cy - t->Y[a]) - (t->Y[c] - t->Y[a]) * (cx - t->X[a]);
+        if (t->flipped) e = -e;
+        l[i] = (float)e / fa;
+    }
+    float pw0 = l[0] * t->invw[0], pw1 = l[1] * t->invw[1], pw2 = l[2] * t->invw[2];
+    float sw = (pw0 + pw1) + pw2;
+    float bs[3] = {pw0 / sw, pw1 / sw, pw2 / sw};
+    for (int k = 0; k < 3; ++k) b[k] = fmaf(bs[2], t->bary[2][k], fmaf(bs[1], t->bary[1][k], bs[0] * t->bary[0][k]));
+}
+
 static inline float interp(const float b[3], float a0, float a1, float a2)
 {
     return fmaf(b[2], a2 - a0, fmaf(b[1], a1 - a0, a0));
@@ -298,23 +317,117 @@ static inline int wrapi(int i, int n)
     return m < 0 ? m + n : m;
 }
 
-static void tex_bilinear(const uint8_t* tex, int w, int h, float u, float v, float out[4])
+/* ---- 2D textures with mip chains and the asset's sampler state (include/slhip.h, SLHIP_SAMPLER_*) ---- */
+static inline int wrap_coord(int i, int n, unsigned mode)
 {
+    if (mode == 1u) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    if (mode == 2u) {
+        const int m = wrapi(i, 2 * n);
+        return m < n ? m : 2 * n - 1 - m;
+    }
+    return wrapi(i, n);
+}
+
+static inline void texel_rgba(const uint8_t* lvl, int w, int x, int y, float out[4])
+{
+    const uint8_t* t = lvl + 4 * ((size_t)y * w + x);
+    for (int c = 0; c < 4; ++c) out[c] = (float)t[c] / 255.0f;
+}
+
+static void tex_level(const uint8_t* lvl, int w, int h, unsigned sampler, int linear, float u, float v, float out[4])
+{
+    const unsigned ws = SLHIP_SAMPLER_WRAP_S(sampler), wt = SLHIP_SAMPLER_WRAP_T(sampler);
+    if (!linear) {
+        texel_rgba(lvl, w, wrap_coord((int)floorf(u * (float)w), w, ws), wrap_coord((int)floorf(v * (float)h), h, wt), out);
+        return;
+    }
     float x = fmaf(u, (float)w, -0.5f), y = fmaf(v, (float)h, -0.5f);
     float fx = floorf(x), fy = floorf(y);
     float ax = x - fx, ay = y - fy;
-    int x0 = wrapi((int)fx, w), y0 = wrapi((int)fy, h);
-    int x1 = wrapi((int)fx + 1, w), y1 = wrapi((int)fy + 1, h);
-    const uint8_t* t00 = tex + 4 * ((size_t)y0 * w + x0);
-    const uint8_t* t10 = tex + 4 * ((size_t)y0 * w + x1);
-    const uint8_t* t01 = tex + 4 * ((size_t)y1 * w + x0);
-    const uint8_t* t11 = tex + 4 * ((size_t)y1 * w + x1);
+    int x0 = wrap_coord((int)fx, w, ws), y0 = wrap_coord((int)fy, h, wt);
+    int x1 = wrap_coord((int)fx + 1, w, ws), y1 = wrap_coord((int)fy + 1, h, wt);
+    float c00[4], c10[4], c01[4], c11[4];
+    texel_rgba(lvl, w, x0, y0, c00); texel_rgba(lvl, w, x1, y0, c10);
+    texel_rgba(lvl, w, x0, y1, c01); texel_rgba(lvl, w, x1, y1, c11);
     for (int c = 0; c < 4; ++c) {
-        float a = (float)t00[c] / 255.0f, b = (float)t10[c] / 255.0f;
-        float cc = (float)t01[c] / 255.0f, d = (float)t11[c] / 255.0f;
-        float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - cc, cc);
+        float top = fmaf(ax, c10[c] - c00[c], c00[c]), bot = fmaf(ax, c11[c] - c01[c], c01[c]);
         out[c] = fmaf(ay, bot - top, top);
     }
+}
+
+static const uint8_t* tex_level_ptr(const uint8_t* tex, int w0, int h0, int l, int* w, int* h)
+{
+    size_t off = 0;
+    *w = w0; *h = h0;
+    for (int k = 0; k < l; ++k) {
+        off += 4 * (size_t)(*w) * (*h);
+        *w = *w >> 1 > 1 ? *w >> 1 : 1;
+        *h = *h >> 1 > 1 ? *h >> 1 : 1;
+    }
+    return tex + off;
+}
+
+/* log2 of a positive normal float: exponent + degree-6 polynomial in fmaf form (max error 1.4e-6), the same
+   operations as the HIP path (bit-identical level of detail; libm's log2f differs from the device's) */
+static inline float det_log2(float x)
+{
+    uint32_t bits;
+    memcpy(&bits, &x, 4);
+    const int e = (int)(bits >> 23) - 127;
+    uint32_t mb = (bits & 0x7fffffu) | 0x3f800000u;
+    float m;
+    memcpy(&m, &mb, 4);
+    const float t = m - 1.0f;
+    float q = 0.02049034833908081f;
+    q = fmaf(q, t, -0.09606625884771347f);
+    q = fmaf(q, t, 0.2155885398387909f);
+    q = fmaf(q, t, -0.33924779295921326f);
+    q = fmaf(q, t, 0.4777059257030487f);
+    q = fmaf(q, t, -0.721162736415863f);
+    q = fmaf(q, t, 1.4426932334899902f);
+    return fmaf(q, t, (float)e);
+}
+
+/* texture2D(): level of detail from the forward differences to the +x / +y pixel neighbours (GL 4.5, 8.14) */
+static void tex_sample(const uint8_t* tex, int w, int h, unsigned sampler, float u, float v, float dudx, float dvdx,
+                       float dudy, float dvdy, float out[4])
+{
+    const unsigned mip = SLHIP_SAMPLER_MIP(sampler);
+    const float ax = dudx * (float)w, bx = dvdx * (float)h, ay = dudy * (float)w, by = dvdy * (float)h;
+    const float rx = sqrtf(fmaf(bx, bx, ax * ax)), ry = sqrtf(fmaf(by, by, ay * ay));
+    const float rho = fmaxf(rx, ry);
+    const int magnify = !(rho > 1.0f);
+    if (magnify || mip == 0u) {
+        tex_level(tex, w, h, sampler, (sampler & (magnify ? SLHIP_SAMPLER_MAG_LINEAR : SLHIP_SAMPLER_MIN_LINEAR)) != 0u, u, v, out);
+        return;
+    }
+    int top = 0;
+    for (int m = w > h ? w : h; m > 1; m >>= 1) ++top;
+    const float lambda = fminf(det_log2(rho), (float)top);
+    const int lin = (sampler & SLHIP_SAMPLER_MIN_LINEAR) != 0u;
+    int lw, lh;
+    if (mip == 1u) {
+        int l = (int)ceilf(lambda + 0.5f) - 1;
+        if (l > top) l = top;
+        if (l < 0) l = 0;
+        const uint8_t* p = tex_level_ptr(tex, w, h, l, &lw, &lh);
+        tex_level(p, lw, lh, sampler, lin, u, v, out);
+        return;
+    }
+    int l0 = (int)floorf(lambda);
+    if (l0 > top) l0 = top;
+    const int l1 = l0 + 1 < top ? l0 + 1 : top;
+    const float f = lambda - (float)l0;
+    float a[4], b[4];
+    const uint8_t* p0 = tex_level_ptr(tex, w, h, l0, &lw, &lh);
+    tex_level(p0, lw, lh, sampler, lin, u, v, a);
+    if (l1 == l0 || f == 0.0f) {
+        for (int c = 0; c < 4; ++c) out[c] = a[c];
+        return;
+    }
+    const uint8_t* p1 = tex_level_ptr(tex, w, h, l1, &lw, &lh);
+    tex_level(p1, lw, lh, sampler, lin, u, v, b);
+    for (int c = 0; c < 4; ++c) out[c] = fmaf(f, b[c] - a[c], a[c]);
 }
 
 /* rectangle texture (the sticker, frag:254): unnormalised texel coordinates, LINEAR, clamp to edge; the
@@ -868,9 +981,14 @@ int slref_render(const slhip_mesh_pool* pool, const slhip_scene* scenes, const s
                             float basec[4] = {dr->base_color[0], dr->base_color[1], dr->base_color[2], dr->base_color[3]};
                             const float u = interp(b, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]);
                             const float v = interp(b, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]);
+                            float bxn[3], byn[3];
+                            bary_at(&ts, px + 1, py, bxn);
+                            bary_at(&ts, px, py + 1, byn);
+                            const float dudx = interp(bxn, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]) - u, dvdx = interp(bxn, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]) - v;
+                            const float dudy = interp(byn, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]) - u, dvdy = interp(byn, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]) - v;
                             if (tex) {
                                 float tc[4];
-                                tex_bilinear(tex, (int)dr->tex_w, (int)dr->tex_h, u, v, tc);
+                                tex_sample(tex, (int)dr->tex_w, (int)dr->tex_h, dr->tex_sampler[0], u, v, dudx, dvdx, dudy, dvdy, tc);
                                 basec[0] *= powf(tc[0], 2.2f);
                                 basec[1] *= powf(tc[1], 2.2f);
                                 basec[2] *= powf(tc[2], 2.2f);
@@ -921,7 +1039,7 @@ int slref_render(const slhip_mesh_pool* pool, const slhip_scene* scenes, const s
                                     for (int c = 0; c < 3; ++c) bw[k][c] *= t4[3];
                                 }
                                 float tc[4];
-                                tex_bilinear(pool->d_tex + dr->normal_tex_offset, (int)dr->normal_tex_w, (int)dr->normal_tex_h, u, v, tc);
+                                tex_sample(pool->d_tex + dr->normal_tex_offset, (int)dr->normal_tex_w, (int)dr->normal_tex_h, dr->tex_sampler[1], u, v, dudx, dvdx, dudy, dvdy, tc);
                                 const float nx = tc[0] * 2.0f - 1.0f, ny = tc[1] * 2.0f - 1.0f, nz = tc[2] * 2.0f - 1.0f;
                                 float nn[3];
                                 for (int c = 0; c < 3; ++c)
@@ -933,18 +1051,18 @@ int slref_render(const slhip_mesh_pool* pool, const slhip_scene* scenes, const s
                             float emissive[3] = {dr->emissive[0], dr->emissive[1], dr->emissive[2]};
                             if (dr->flags & SLHIP_DRAW_HAS_MR_TEX) { /* frag:284-288 */
                                 float tc[4];
-                                tex_bilinear(pool->d_tex + dr->mr_tex_offset, (int)dr->mr_tex_w, (int)dr->mr_tex_h, u, v, tc);
+                                tex_sample(pool->d_tex + dr->mr_tex_offset, (int)dr->mr_tex_w, (int)dr->mr_tex_h, dr->tex_sampler[2], u, v, dudx, dvdx, dudy, dvdy, tc);
                                 roughness *= tc[1];
                                 metallic *= tc[2];
                             }
                             if (dr->flags & SLHIP_DRAW_HAS_OCCLUSION_TEX) { /* frag:292-294 */
                                 float tc[4];
-                                tex_bilinear(pool->d_tex + dr->occlusion_tex_offset, (int)dr->occlusion_tex_w, (int)dr->occlusion_tex_h, u, v, tc);
+                                tex_sample(pool->d_tex + dr->occlusion_tex_offset, (int)dr->occlusion_tex_w, (int)dr->occlusion_tex_h, dr->tex_sampler[3], u, v, dudx, dvdx, dudy, dvdy, tc);
                                 occlusion = tc[0];
                             }
                             if (dr->flags & SLHIP_DRAW_HAS_EMISSIVE_TEX) { /* frag:296-298 */
                                 float tc[4];
-                                tex_bilinear(pool->d_tex + dr->emissive_tex_offset, (int)dr->emissive_tex_w, (int)dr->emissive_tex_h, u, v, tc);
+                                tex_sample(pool->d_tex + dr->emissive_tex_offset, (int)dr->emissive_tex_w, (int)dr->emissive_tex_h, dr->tex_sampler[4], u, v, dudx, dvdx, dudy, dvdy, tc);
                                 for (int c = 0; c < 3; ++c) emissive[c] *= powf(tc[c], 2.2f);
                             }
                             float color[4], nout[4];

@@ -22,6 +22,8 @@ DRAW_HAS_MR_TEX = 64
 DRAW_HAS_OCCLUSION_TEX = 128
 DRAW_HAS_EMISSIVE_TEX = 256
 DRAW_HAS_STICKER = 512
+# SLHIP_SAMPLER_*: wrap S | wrap T << 2 (0 repeat, 1 clamp, 2 mirror) | mag linear 0x10 | min linear 0x20 | mip mode << 6
+SAMPLER_DEFAULT = 0x10 | 0x20 | (2 << 6)
 
 OUT_RGB = 0x01
 OUT_COORD = 0x02
@@ -100,13 +102,14 @@ DRAW_DTYPE = np.dtype(
         ("occlusion_tex", np.uint32, (3,)),
         ("emissive_tex", np.uint32, (3,)),
         ("sticker_tex", np.uint32, (3,)),
-        ("_pad", np.uint32),
+        ("tex_sampler", np.uint8, (8,)),     # base, normal, metallic-roughness, occlusion, emissive
+        ("_pad", np.uint32, (3,)),
         ("sticker_projection", np.float32, (16,)),
         ("sticker_range", np.float32, (4,)),
     ],
     align=False,
 )
-assert DRAW_DTYPE.itemsize == 416, DRAW_DTYPE.itemsize
+assert DRAW_DTYPE.itemsize == 432, DRAW_DTYPE.itemsize
 
 SCENE_DTYPE = np.dtype(
     [

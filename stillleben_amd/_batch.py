@@ -10,8 +10,21 @@ from . import _math as M
 from ._math import f32
 
 
+def mip_down(img):
+    """Next mip level of an RGBA8 image [H,W,4]."""
+    h, w = img.shape[0], img.shape[1]
+    nh, nw = max(1, h >> 1), max(1, w >> 1)
+    ys0 = np.minimum(2 * np.arange(nh), h - 1)
+    ys1 = np.minimum(2 * np.arange(nh) + 1, h - 1)
+    xs0 = np.minimum(2 * np.arange(nw), w - 1)
+    xs1 = np.minimum(2 * np.arange(nw) + 1, w - 1)
+    s = (img[ys0][:, xs0].astype(np.uint16) + img[ys0][:, xs1] + img[ys1][:, xs0] + img[ys1][:, xs1] + 2) >> 2
+    return s.astype(np.uint8)
+
+
 class PoolSlot:
-    __slots__ = ("vtx_base", "idx_base", "tex_offsets", "tex_sizes", "tex_alpha", "version", "n_vertices", "n_indices")
+    __slots__ = ("vtx_base", "idx_base", "tex_offsets", "tex_sizes", "tex_alpha", "tex_samplers", "version", "n_vertices",
+                 "n_indices")
 
 
 class HostPool:
@@ -32,14 +45,20 @@ class HostPool:
         self.dirty = True
         self._textures = {}  # id(array) -> (offset, w, h)
 
-    def add_texture(self, rgba):
-        key = id(rgba)
+    def add_texture(self, rgba, mips=True):
+        """Appends an RGBA8 image (row 0 = top) and, for 2D textures, its mip chain (include/slhip.h:
+        level l+1 = 2x2 box filter of level l, rounded to nearest; max(1, size >> 1) per axis)."""
+        key = (id(rgba), bool(mips))
         if key in self._textures:
             return self._textures[key]
         off = self.n_tex_bytes
         a = np.ascontiguousarray(rgba, dtype=np.uint8)
-        self.tex.append(a.reshape(-1))
-        self.n_tex_bytes += a.size
+        levels = [a]
+        while mips and max(levels[-1].shape[0], levels[-1].shape[1]) > 1:
+            levels.append(mip_down(levels[-1]))
+        for lv in levels:
+            self.tex.append(lv.reshape(-1))
+            self.n_tex_bytes += lv.size
         self._textures[key] = (off, a.shape[1], a.shape[0])
         self.dirty = True
         return self._textures[key]
@@ -74,6 +93,8 @@ class HostPool:
             slot.tex_offsets.append(off)
             slot.tex_sizes.append((w, h))
         slot.tex_alpha = list(getattr(d, "_tex_alpha", [False] * len(d.textures)))
+        # sampler state of each texture as the asset file gives it (mesh.cpp:656-663); default: repeat, trilinear
+        slot.tex_samplers = list(getattr(d, "tex_samplers", None) or [_abi.SAMPLER_DEFAULT] * len(d.textures))
         slot.version = mesh._version
         mesh._slot = slot
         mesh._slot_pool = self
@@ -176,6 +197,7 @@ def build_batch(scenes, pool, predicate=None, with_shadows=True):
                 off, w, h = pool.add_texture(tex._rgba)
                 d["base_color"] = (1.0, 1.0, 1.0, 1.0)
                 d["tex_offset"], d["tex_w"], d["tex_h"] = off, w, h
+                d["tex_sampler"][0] = _abi.SAMPLER_DEFAULT
                 flags |= _abi.DRAW_HAS_BASE_TEX
             else:
                 d["base_color"] = (0.0, 0.8, 0.0, 1.0)
@@ -212,18 +234,20 @@ def build_batch(scenes, pool, predicate=None, with_shadows=True):
                         flags |= _abi.DRAW_ALPHA_TEST
                     d["tex_offset"] = slot.tex_offsets[mat.base_texture]
                     d["tex_w"], d["tex_h"] = slot.tex_sizes[mat.base_texture]
-                for attr, field, bit in (("normal_texture", "normal_tex", _abi.DRAW_HAS_NORMAL_TEX),
-                                         ("mr_texture", "mr_tex", _abi.DRAW_HAS_MR_TEX),
-                                         ("occlusion_texture", "occlusion_tex", _abi.DRAW_HAS_OCCLUSION_TEX),
-                                         ("emissive_texture", "emissive_tex", _abi.DRAW_HAS_EMISSIVE_TEX)):
+                    d["tex_sampler"][0] = slot.tex_samplers[mat.base_texture]
+                for k, (attr, field, bit) in enumerate((("normal_texture", "normal_tex", _abi.DRAW_HAS_NORMAL_TEX),
+                                                        ("mr_texture", "mr_tex", _abi.DRAW_HAS_MR_TEX),
+                                                        ("occlusion_texture", "occlusion_tex", _abi.DRAW_HAS_OCCLUSION_TEX),
+                                                        ("emissive_texture", "emissive_tex", _abi.DRAW_HAS_EMISSIVE_TEX))):
                     ti = getattr(mat, attr, None)
                     if ti is not None:
                         flags |= bit
                         d[field] = (slot.tex_offsets[ti],) + tuple(slot.tex_sizes[ti])
+                        d["tex_sampler"][k + 1] = slot.tex_samplers[ti]
                 st = obj._sticker_texture
                 if st is not None and obj._sticker_range is not None:
                     # render_pass.cpp:601-606: projection + range per object, the rectangle texture if one is set
-                    off, w, h = pool.add_texture(st._rgba)
+                    off, w, h = pool.add_texture(st._rgba, mips=False)    # rectangle texture: one level
                     flags |= _abi.DRAW_HAS_STICKER
                     d["sticker_tex"] = (off, w, h)
                     d["sticker_projection"] = obj.sticker_view_projection().reshape(-1)

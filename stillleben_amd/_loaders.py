@@ -58,6 +58,7 @@ class ConsolidatedMesh:
         self.submeshes = []
         self.materials = []
         self.textures = []  # list of HxWx4 uint8 arrays, row 0 = top of the image
+        self.tex_samplers = []  # one SLHIP_SAMPLER_* byte per texture (empty = defaults)
 
 
 def _smooth_normals(pos, idx):
@@ -97,6 +98,27 @@ def compute_tangents(pos, nrm, uv, idx):
         bit = bit / np.sqrt((bit * bit).sum(axis=1, keepdims=True))
         sign = np.sign((np.cross(nrm, tan) * bit).sum(axis=1)).astype(np.float32)
     return np.concatenate([tan.astype(np.float32), sign[:, None]], axis=1).astype(np.float32)
+
+
+def _gltf_sampler(doc, sampler_id):
+    """glTF sampler -> SLHIP_SAMPLER_* byte.  Unspecified filters: linear / linear-mipmap-linear (what Magnum's
+    importer hands to mesh.cpp:656-663); wrap defaults to repeat (10497)."""
+    from . import _abi
+
+    if sampler_id is None:
+        return _abi.SAMPLER_DEFAULT
+    sp = doc["samplers"][sampler_id]
+    wrap = {10497: 0, 33071: 1, 33648: 2}
+    m = wrap.get(sp.get("wrapS", 10497), 0) | (wrap.get(sp.get("wrapT", 10497), 0) << 2)
+    if sp.get("magFilter", 9729) == 9729:
+        m |= 0x10
+    # minFilter: 9728 NEAREST, 9729 LINEAR, 9984 NEAREST_MIPMAP_NEAREST, 9985 LINEAR_MIPMAP_NEAREST,
+    #            9986 NEAREST_MIPMAP_LINEAR, 9987 LINEAR_MIPMAP_LINEAR
+    mn = sp.get("minFilter", 9987)
+    if mn in (9729, 9985, 9987):
+        m |= 0x20
+    m |= {9728: 0, 9729: 0, 9984: 1, 9985: 1, 9986: 2, 9987: 2}.get(mn, 2) << 6
+    return m
 
 
 def _load_image(data):
@@ -205,6 +227,7 @@ def load_gltf(path):
                 data = b[bv.get("byteOffset", 0):bv.get("byteOffset", 0) + bv["byteLength"]]
             arr, has_alpha = _load_image(data)
             out.textures.append(arr)
+            out.tex_samplers.append(_gltf_sampler(doc, doc["textures"][tex_id].get("sampler")))
             image_cache[src] = (len(out.textures) - 1, has_alpha)
         return image_cache[src]
 

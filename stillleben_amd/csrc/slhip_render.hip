@@ -24,7 +24,7 @@
 
 namespace {
 
-static_assert(sizeof(slhip_draw) == 416, "slhip_draw layout");
+static_assert(sizeof(slhip_draw) == 432, "slhip_draw layout");
 static_assert(sizeof(slhip_scene) == 480, "slhip_scene layout");
 static_assert(sizeof(slhip_chunk) == 16, "slhip_chunk layout");
 
@@ -366,27 +366,136 @@ __device__ __forceinline__ int wrapi(int i, int n)
     return m < 0 ? m + n : m;
 }
 
-__device__ __forceinline__ void tex_bilinear(const uint8_t* __restrict__ tex, int w, int h, float u, float v,
-                                             float* out)
+// ---- 2D textures with mip chains and the asset's sampler state (include/slhip.h, SLHIP_SAMPLER_*) ----
+__device__ __forceinline__ int wrap_coord(int i, int n, unsigned mode)
 {
+    if (mode == 1u) return min(max(i, 0), n - 1);             // clamp to edge
+    if (mode == 2u) {                                         // mirrored repeat
+        const int m = wrapi(i, 2 * n);
+        return m < n ? m : 2 * n - 1 - m;
+    }
+    return wrapi(i, n);                                       // repeat
+}
+
+__device__ __forceinline__ void texel_rgba(const uint8_t* __restrict__ lvl, int w, int x, int y, float* out)
+{
+    const uchar4 t = reinterpret_cast<const uchar4*>(lvl)[(size_t)y * w + x];
+    out[0] = (float)t.x / 255.0f; out[1] = (float)t.y / 255.0f; out[2] = (float)t.z / 255.0f; out[3] = (float)t.w / 255.0f;
+}
+
+// one level, nearest or bilinear
+__device__ __forceinline__ void tex_level(const uint8_t* __restrict__ lvl, int w, int h, unsigned sampler, bool linear, float u,
+                                          float v, float* out)
+{
+    const unsigned ws = SLHIP_SAMPLER_WRAP_S(sampler), wt = SLHIP_SAMPLER_WRAP_T(sampler);
+    if (!linear) {
+        texel_rgba(lvl, w, wrap_coord((int)floorf(u * (float)w), w, ws), wrap_coord((int)floorf(v * (float)h), h, wt), out);
+        return;
+    }
     const float x = fmaf(u, (float)w, -0.5f), y = fmaf(v, (float)h, -0.5f);
     const float fx = floorf(x), fy = floorf(y);
     const float ax = x - fx, ay = y - fy;
-    const int x0 = wrapi((int)fx, w), y0 = wrapi((int)fy, h);
-    const int x1 = wrapi((int)fx + 1, w), y1 = wrapi((int)fy + 1, h);
-    const uchar4 t00 = reinterpret_cast<const uchar4*>(tex)[(size_t)y0 * w + x0];
-    const uchar4 t10 = reinterpret_cast<const uchar4*>(tex)[(size_t)y0 * w + x1];
-    const uchar4 t01 = reinterpret_cast<const uchar4*>(tex)[(size_t)y1 * w + x0];
-    const uchar4 t11 = reinterpret_cast<const uchar4*>(tex)[(size_t)y1 * w + x1];
-    const unsigned char c00[4] = {t00.x, t00.y, t00.z, t00.w}, c10[4] = {t10.x, t10.y, t10.z, t10.w};
-    const unsigned char c01[4] = {t01.x, t01.y, t01.z, t01.w}, c11[4] = {t11.x, t11.y, t11.z, t11.w};
+    const int x0 = wrap_coord((int)fx, w, ws), y0 = wrap_coord((int)fy, h, wt);
+    const int x1 = wrap_coord((int)fx + 1, w, ws), y1 = wrap_coord((int)fy + 1, h, wt);
+    float c00[4], c10[4], c01[4], c11[4];
+    texel_rgba(lvl, w, x0, y0, c00); texel_rgba(lvl, w, x1, y0, c10);
+    texel_rgba(lvl, w, x0, y1, c01); texel_rgba(lvl, w, x1, y1, c11);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float a = (float)c00[c] / 255.0f, b = (float)c10[c] / 255.0f;
-        const float cc = (float)c01[c] / 255.0f, d = (float)c11[c] / 255.0f;
-        const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - cc, cc);
+        const float top = fmaf(ax, c10[c] - c00[c], c00[c]), bot = fmaf(ax, c11[c] - c01[c], c01[c]);
         out[c] = fmaf(ay, bot - top, top);
     }
+}
+
+// level l of a texture whose level 0 is w0 x h0 at `tex`: pointer and size
+__device__ __forceinline__ const uint8_t* tex_level_ptr(const uint8_t* __restrict__ tex, int w0, int h0, int l, int& w, int& h)
+{
+    size_t off = 0;
+    w = w0; h = h0;
+    for (int k = 0; k < l; ++k) {
+        off += 4 * (size_t)w * h;
+        w = max(1, w >> 1); h = max(1, h >> 1);
+    }
+    return tex + off;
+}
+
+// log2 of a positive normal float from exponent + a degree-6 polynomial in fmaf form (max error 1.4e-6): the
+// SAME operations run in the oracle, so the level of detail -- and everything sampled with it, normal maps
+// included -- is bit-identical on both sides (libm's and the device's log2f differ in the last bits)
+__device__ __forceinline__ float det_log2(float x)
+{
+    const unsigned bits = __float_as_uint(x);
+    const int e = (int)(bits >> 23) - 127;
+    const float t = __uint_as_float((bits & 0x7fffffu) | 0x3f800000u) - 1.0f;
+    float q = 0.02049034833908081f;
+    q = fmaf(q, t, -0.09606625884771347f);
+    q = fmaf(q, t, 0.2155885398387909f);
+    q = fmaf(q, t, -0.33924779295921326f);
+    q = fmaf(q, t, 0.4777059257030487f);
+    q = fmaf(q, t, -0.721162736415863f);
+    q = fmaf(q, t, 1.4426932334899902f);
+    return fmaf(q, t, (float)e);
+}
+
+// texture2D() of the fragment shader: (du, dv) to the +x and +y pixel neighbours select the level
+__device__ __forceinline__ void tex_sample(const uint8_t* __restrict__ tex, int w, int h, unsigned sampler, float u, float v,
+                                           float dudx, float dvdx, float dudy, float dvdy, float* out)
+{
+    const unsigned mip = SLHIP_SAMPLER_MIP(sampler);
+    const float ax = dudx * (float)w, bx = dvdx * (float)h, ay = dudy * (float)w, by = dvdy * (float)h;
+    const float rx = sqrtf(fmaf(bx, bx, ax * ax)), ry = sqrtf(fmaf(by, by, ay * ay));
+    const float rho = fmaxf(rx, ry);
+    const bool magnify = !(rho > 1.0f);            // lambda <= 0 (or a degenerate footprint)
+    if (magnify || mip == 0u) {
+        tex_level(tex, w, h, sampler, (sampler & (magnify ? SLHIP_SAMPLER_MAG_LINEAR : SLHIP_SAMPLER_MIN_LINEAR)) != 0u, u, v, out);
+        return;
+    }
+    int top = 0;
+    for (int m = max(w, h); m > 1; m >>= 1) ++top;  // last level = floor(log2(max(w, h)))
+    const float lambda = fminf(det_log2(rho), (float)top);
+    const bool lin = (sampler & SLHIP_SAMPLER_MIN_LINEAR) != 0u;
+    int lw, lh;
+    if (mip == 1u) {                                // nearest level: round half up (section 8.14.3)
+        const int l = min((int)ceilf(lambda + 0.5f) - 1, top);
+        const uint8_t* p = tex_level_ptr(tex, w, h, max(l, 0), lw, lh);
+        tex_level(p, lw, lh, sampler, lin, u, v, out);
+        return;
+    }
+    const int l0 = min((int)floorf(lambda), top), l1 = min(l0 + 1, top);
+    const float f = lambda - (float)l0;
+    float a[4], b[4];
+    const uint8_t* p0 = tex_level_ptr(tex, w, h, l0, lw, lh);
+    tex_level(p0, lw, lh, sampler, lin, u, v, a);
+    if (l1 == l0 || f == 0.0f) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = a[c];
+        return;
+    }
+    const uint8_t* p1 = tex_level_ptr(tex, w, h, l1, lw, lh);
+    tex_level(p1, lw, lh, sampler, lin, u, v, b);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = fmaf(f, b[c] - a[c], a[c]);
+}
+
+// perspective-correct barycentrics (w.r.t. the ORIGINAL triangle) of pixel (px, py) on the plane of the
+// set-up sub-triangle -- also outside its edges (used for the texture footprint)
+__device__ __forceinline__ void bary_at(const Setup& t, const float* b0, const float* b1, const float* b2, int px, int py, float* b)
+{
+    const long long cx = 256ll * px + 128, cy = 256ll * py + 128;
+    float l[3];
+    const float fa = (float)t.area2;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int a = (i + 1) % 3, c = (i + 2) % 3;
+        long long e = (long long)(t.X[c] - t.X[a]) * (cy - t.Y[a]) - (long long)(t.Y[c] - t.Y[a]) * (cx - t.X[a]);
+        if (t.flipped) e = -e;
+        l[i] = (float)e / fa;
+    }
+    const float pw0 = l[0] * t.invw[0], pw1 = l[1] * t.invw[1], pw2 = l[2] * t.invw[2];
+    const float sw = (pw0 + pw1) + pw2;
+    const float bs[3] = {pw0 / sw, pw1 / sw, pw2 / sw};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[k] = fmaf(bs[2], b2[k], fmaf(bs[1], b1[k], bs[0] * b0[k]));
 }
 
 // rectangle texture (the sticker, render_shader.frag:254): unnormalised texel coordinates, LINEAR, clamp to
@@ -428,6 +537,7 @@ struct MainTarget {
     const float* uv;     // [3][2]
     const uint8_t* tex;
     int tex_w, tex_h;
+    unsigned tex_sampler;
     float base_alpha, alpha_cutoff;
 
     __device__ __forceinline__ void emit(const Setup& t, int px, int py, const float* l) const
@@ -455,8 +565,12 @@ struct MainTarget {
             if (tex) {
                 const float u = interp(b, uv[0], uv[2], uv[4]);
                 const float v = interp(b, uv[1], uv[3], uv[5]);
+                float bx[3], by[3];
+                bary_at(t, bary, bary + 3, bary + 6, px + 1, py, bx);
+                bary_at(t, bary, bary + 3, bary + 6, px, py + 1, by);
                 float tc[4];
-                tex_bilinear(tex, tex_w, tex_h, u, v, tc);
+                tex_sample(tex, tex_w, tex_h, tex_sampler, u, v, interp(bx, uv[0], uv[2], uv[4]) - u, interp(bx, uv[1], uv[3], uv[5]) - v,
+                           interp(by, uv[0], uv[2], uv[4]) - u, interp(by, uv[1], uv[3], uv[5]) - v, tc);
                 if (base_alpha * tc[3] < alpha_cutoff) return;
             }
         }
@@ -623,6 +737,7 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
         }
         tgt.tex = pool.d_tex + dr->tex_offset;
         tgt.tex_w = (int)dr->tex_w; tgt.tex_h = (int)dr->tex_h;
+        tgt.tex_sampler = dr->tex_sampler[0];
     }
     tgt.camz = camz;
     tgt.uv = uvs;
@@ -1131,7 +1246,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
             ClipVert poly[4];
             const int n = clip_near(cv, poly);
             const int px = (int)(pix % (unsigned)W), py = (int)(pix / (unsigned)W);
-            float b[3] = {0.0f, 0.0f, 0.0f};
+            float b[3] = {0.0f, 0.0f, 0.0f}, bx[3] = {0.0f, 0.0f, 0.0f}, by[3] = {0.0f, 0.0f, 0.0f};
             bool found = false, front = false;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {   // unrolled: static indices into poly[]
@@ -1150,15 +1265,20 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                                 fmaf(bs[1], poly[sub + 1].bary[k], bs[0] * poly[0].bary[k]));
                 front = t.flipped;
                 found = true;
+                // texture footprint: the same plane one pixel to the right / below
+                bary_at(t, poly[0].bary, poly[sub + 1].bary, poly[sub + 2].bary, px + 1, py, bx);
+                bary_at(t, poly[0].bary, poly[sub + 1].bary, poly[sub + 2].bary, px, py + 1, by);
             }
             if (found) {
                 const float camz = interp(b, vo[0].objc[3], vo[1].objc[3], vo[2].objc[3]);
                 float base[4] = {dr->base_color[0], dr->base_color[1], dr->base_color[2], dr->base_color[3]};
                 const float u = interp(b, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]);
                 const float v = interp(b, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]);
+                const float dudx = interp(bx, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]) - u, dvdx = interp(bx, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]) - v;
+                const float dudy = interp(by, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]) - u, dvdy = interp(by, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]) - v;
                 if (dr->flags & SLHIP_DRAW_HAS_BASE_TEX) {
                     float tc[4];
-                    tex_bilinear(pool.d_tex + dr->tex_offset, (int)dr->tex_w, (int)dr->tex_h, u, v, tc);
+                    tex_sample(pool.d_tex + dr->tex_offset, (int)dr->tex_w, (int)dr->tex_h, dr->tex_sampler[0], u, v, dudx, dvdx, dudy, dvdy, tc);
                     base[0] *= powf(tc[0], 2.2f);
                     base[1] *= powf(tc[1], 2.2f);
                     base[2] *= powf(tc[2], 2.2f);
@@ -1215,7 +1335,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                         for (int c = 0; c < 3; ++c) bw[k][c] *= t4.w;
                     }
                     float tc[4];
-                    tex_bilinear(pool.d_tex + dr->normal_tex_offset, (int)dr->normal_tex_w, (int)dr->normal_tex_h, u, v, tc);
+                    tex_sample(pool.d_tex + dr->normal_tex_offset, (int)dr->normal_tex_w, (int)dr->normal_tex_h, dr->tex_sampler[1], u, v, dudx, dvdx, dudy, dvdy, tc);
                     const float nx = tc[0] * 2.0f - 1.0f, ny = tc[1] * 2.0f - 1.0f, nz = tc[2] * 2.0f - 1.0f;
                     float nn[3];
 #pragma unroll
@@ -1228,18 +1348,18 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                 float emissive[3] = {dr->emissive[0], dr->emissive[1], dr->emissive[2]};
                 if (dr->flags & SLHIP_DRAW_HAS_MR_TEX) {
                     float tc[4];
-                    tex_bilinear(pool.d_tex + dr->mr_tex_offset, (int)dr->mr_tex_w, (int)dr->mr_tex_h, u, v, tc);
+                    tex_sample(pool.d_tex + dr->mr_tex_offset, (int)dr->mr_tex_w, (int)dr->mr_tex_h, dr->tex_sampler[2], u, v, dudx, dvdx, dudy, dvdy, tc);
                     roughness *= tc[1];
                     metallic *= tc[2];
                 }
                 if (dr->flags & SLHIP_DRAW_HAS_OCCLUSION_TEX) {
                     float tc[4];
-                    tex_bilinear(pool.d_tex + dr->occlusion_tex_offset, (int)dr->occlusion_tex_w, (int)dr->occlusion_tex_h, u, v, tc);
+                    tex_sample(pool.d_tex + dr->occlusion_tex_offset, (int)dr->occlusion_tex_w, (int)dr->occlusion_tex_h, dr->tex_sampler[3], u, v, dudx, dvdx, dudy, dvdy, tc);
                     occlusion = tc[0];
                 }
                 if (dr->flags & SLHIP_DRAW_HAS_EMISSIVE_TEX) {
                     float tc[4];
-                    tex_bilinear(pool.d_tex + dr->emissive_tex_offset, (int)dr->emissive_tex_w, (int)dr->emissive_tex_h, u, v, tc);
+                    tex_sample(pool.d_tex + dr->emissive_tex_offset, (int)dr->emissive_tex_w, (int)dr->emissive_tex_h, dr->tex_sampler[4], u, v, dudx, dvdx, dudy, dvdy, tc);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) emissive[c] *= powf(tc[c], 2.2f);
                 }

@@ -180,3 +180,100 @@ def test_sticker_decal_and_ibl_occlusion(sl, oracle):
     red = (inst == 1) & (rgb[..., 0] > rgb[..., 2] + 40)
     assert red.sum() > 50                                        # the decal is visible on object 1 ...
     assert ((inst == 2) & (rgb[..., 0] > rgb[..., 2] + 80)).sum() < red.sum() // 4     # ... and only there
+
+
+def quad_mesh(tex, sampler, uv_scale=1.0, uv_shift=0.0):
+    """A 0.4 m square in the xy plane with UVs [shift, shift + scale]^2 and one base-colour texture."""
+    m = _loaders.ConsolidatedMesh()
+    m.positions = np.array([[-0.2, -0.2, 0], [0.2, -0.2, 0], [0.2, 0.2, 0], [-0.2, 0.2, 0]], np.float32)
+    m.normals = np.array([[0, 0, 1]] * 4, np.float32)
+    m.uvs = (np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32) * uv_scale + uv_shift).astype(np.float32)
+    m.colors = np.ones((4, 4), np.float32)
+    m.indices = np.array([0, 1, 2, 0, 2, 3], np.uint32)
+    m.textures = [tex]
+    m.tex_samplers = [sampler]
+    m._tex_alpha = [False]
+    m.materials = [_loaders.Material(base_color=(1, 1, 1, 1), metallic=0.0, roughness=0.9, base_texture=0)]
+    m.submeshes = [_loaders.SubMesh(0, 6, 0)]
+    return m
+
+
+def checker(n=256, cell=1):
+    y, x = np.mgrid[0:n, 0:n]
+    c = (((x // cell) + (y // cell)) & 1).astype(np.uint8) * 255
+    t = np.stack([c, c, c, np.full_like(c, 255)], axis=-1)
+    t[: n // 2, :, 2] = 255           # blue tint on the top half so that orientation errors show
+    return t.astype(np.uint8)
+
+
+@pytest.mark.parametrize("sampler,uv_scale", [
+    (_abi.SAMPLER_DEFAULT, 1.0),                       # repeat, trilinear
+    (0x10 | 0x20 | (1 << 6), 1.0),                     # linear, nearest mip level
+    (0x10 | 0x20, 3.0),                                # no mipmaps, repeat x3
+    (1 | (1 << 2) | 0x10 | 0x20 | (2 << 6), 2.0),      # clamp to edge, UVs beyond [0,1]
+    (2 | (2 << 2) | (2 << 6), 2.5),                    # mirrored repeat, nearest texel + linear between levels
+    (0, 1.0),                                          # nearest, base level
+])
+def test_sampler_modes_and_mipmaps_match_oracle(sl, oracle, sampler, uv_scale):
+    import scenes as S
+
+    mesh = sl.Mesh.from_data(quad_mesh(checker(128, 2), sampler, uv_scale, -0.25 if uv_scale > 1 else 0.0))
+    scene = sl.Scene((200, 150), seed=1)
+    rng = np.random.default_rng(3)
+    for k, (z, tilt) in enumerate(((0.6, 0.2), (1.6, 1.1), (3.0, 1.35))):   # near (magnified) .. far and grazing (minified)
+        o = sl.Object(mesh)
+        pose = np.eye(4, dtype=np.float32)
+        c, s_ = np.cos(tilt), np.sin(tilt)
+        pose[:3, :3] = np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]], np.float32)
+        pose[:3, 3] = [0.35 * (k - 1), 0.0, z]
+        o.set_pose(torch.from_numpy(pose))
+        scene.add_object(o)
+    scene.light_directions = torch.tensor([[0.0, 0.2, 1.0]])
+    scene.manual_exposure = 1.0
+    del rng, S
+    render_both(sl, oracle, [scene])
+
+
+def test_minified_checkerboard_is_filtered_not_aliased(sl):
+    """1-texel checkerboard seen from far away: with mipmaps the quad is uniform mid-grey, with the base level
+    only it is aliased noise -- the property mip-mapping exists for."""
+    from stillleben_amd._context import engine
+
+    out = {}
+    for name, sampler in (("mip", _abi.SAMPLER_DEFAULT), ("nomip", 0x10 | 0x20)):
+        mesh = sl.Mesh.from_data(quad_mesh(checker(256, 1), sampler))
+        scene = sl.Scene((160, 120), seed=1)
+        o = sl.Object(mesh)
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, 3] = [0.0, 0.0, 2.5]
+        o.set_pose(torch.from_numpy(pose))
+        scene.add_object(o)
+        scene.ambient_light = torch.tensor([1.0, 1.0, 1.0])
+        scene.light_colors = torch.zeros(3, 3)
+        scene.manual_exposure = 0.5
+        b = engine().render([scene], _abi.OUT_ALL, ssao=False, shadows=False)
+        rgb = b.rgb.cpu().numpy()[0].astype(np.float32)
+        inst = b.instance.cpu().numpy()[0, :, :, 0]
+        inner = np.zeros_like(inst, bool)
+        ys, xs = np.nonzero(inst == 1)
+        inner[ys.min() + 2: ys.max() - 1, xs.min() + 2: xs.max() - 1] = True
+        out[name] = rgb[inner & (inst == 1)][:, 0]
+    assert out["mip"].std() < 2.0 and out["nomip"].std() > 10.0 * max(out["mip"].std(), 0.5)
+
+
+def test_mip_chain_and_gltf_sampler_parsing():
+    from stillleben_amd._batch import HostPool, mip_down
+
+    img = np.arange(5 * 6 * 4, dtype=np.uint8).reshape(5, 6, 4)
+    nxt = mip_down(img)
+    assert nxt.shape == (2, 3, 4)
+    assert nxt[0, 0, 0] == (int(img[0, 0, 0]) + img[0, 1, 0] + img[1, 0, 0] + img[1, 1, 0] + 2) // 4
+    one = mip_down(np.full((1, 4, 4), 200, np.uint8))
+    assert one.shape == (1, 2, 4) and (one == 200).all()
+    pool = HostPool()
+    off, w, h = pool.add_texture(np.zeros((8, 4, 4), np.uint8))
+    assert (off, w, h) == (0, 4, 8) and pool.n_tex_bytes == 4 * (32 + 8 + 2 + 1)     # 4x8, 2x4, 1x2, 1x1
+    assert pool.add_texture(np.zeros((3, 3, 4), np.uint8), mips=False)[0] == pool.n_tex_bytes - 36
+    doc = {"samplers": [{"magFilter": 9728, "minFilter": 9985, "wrapS": 33071, "wrapT": 33648}, {}]}
+    assert _loaders._gltf_sampler(doc, 0) == (1 | (2 << 2) | 0x20 | (1 << 6))
+    assert _loaders._gltf_sampler(doc, 1) == _abi.SAMPLER_DEFAULT and _loaders._gltf_sampler(doc, None) == _abi.SAMPLER_DEFAULT
