@@ -158,7 +158,9 @@ typedef struct {
     uint32_t light_map;                      /* 1 + index into pool->d_light_maps, 0 = none: IBL term
                                                 (render_shader.frag:375-394) + sky background
                                                 (render_pass.cpp:647-661)                          */
-    uint32_t _pad[3];
+    uint32_t bg_tex[3];                      /* background image (Scene::setBackgroundImage, render_pass.cpp:637-646):
+                                                byte offset in the texel pool, width, height; width 0 = none.
+                                                A rectangle texture: one level, row 0 = top of the image     */
 } slhip_scene;                               /* 480 bytes */
 
 /* A unit of raster work: `count` consecutive triangles of one draw (<= SLHIP_CHUNK_TRIS).

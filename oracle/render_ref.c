@@ -886,6 +886,7 @@ int slref_render(const slhip_mesh_pool* pool, const slhip_scene* scenes, const s
     uint32_t* depth = (uint32_t*)malloc(P * sizeof(uint32_t));
     float* hdr = (float*)malloc(P * 4 * sizeof(float));
     float* hdr2 = (float*)malloc(P * 4 * sizeof(float));
+    float* hdr_lum = (float*)malloc(P * 4 * sizeof(float)); /* the image the auto-exposure average is taken from */
     float* aobuf = (float*)malloc(P * sizeof(float));
     float* camc = (float*)malloc(P * 4 * sizeof(float));
     float* nrmb = (float*)malloc(P * 4 * sizeof(float));
@@ -1091,6 +1092,27 @@ int slref_render(const slhip_mesh_pool* pool, const slhip_scene* scenes, const s
             }
         }
 
+        /* the exposure average (1x1 mip level) is generated BEFORE any background is drawn
+           (render_pass.cpp:632-635 precede :637-661): it sees the objects over the cleared target only */
+        memcpy(hdr_lum, hdr, P * 4 * sizeof(float));
+
+        /* background image (render_pass.cpp:637-646, background_shader.vert/frag): the rectangle texture
+           stretched over the viewport, integer texel coordinates on a LINEAR rectangle sampler, alpha 0.
+           DEVIATION: the reference draws the quad at NDC z = 0 with the depth test on, which also paints over
+           every object farther than 0.198 m; here the image fills the pixels where nothing was rasterised. */
+        if (sc->bg_tex[1] != 0u && sc->bg_tex[2] != 0u) {
+            const int tw = (int)sc->bg_tex[1], th = (int)sc->bg_tex[2];
+            for (int py = 0; py < H; ++py)
+                for (int px = 0; px < W; ++px) {
+                    const size_t p = (size_t)py * W + px;
+                    if (depth[p] != 0xFFFFFFu) continue;
+                    const float tcx = ((float)px + 0.5f) / (float)W, tcy = 1.0f - ((float)py + 0.5f) / (float)H;
+                    const int tx = (int)(tcx * (float)tw), ty = (int)(tcy * (float)th);
+                    float c[4];
+                    tex_rect_bilinear(pool->d_tex + sc->bg_tex[0], tw, th, (float)tx, (float)ty, c);
+                    hdr[4 * p + 0] = c[0]; hdr[4 * p + 1] = c[1]; hdr[4 * p + 2] = c[2]; hdr[4 * p + 3] = 0.0f;
+                }
+        } else
         /* sky background (render_pass.cpp:647-661): drawn at depth 1 with LEQUAL, i.e. wherever nothing was
            rasterised; colour attachment 0 only, alpha 0 */
         if (sc->light_map != 0u && pool->d_light_maps) {
@@ -1120,7 +1142,7 @@ int slref_render(const slhip_mesh_pool* pool, const slhip_scene* scenes, const s
             tm_in = hdr2;
         }
         if (hdr_out) memcpy(hdr_out + 4 * base, tm_in, P * 4 * sizeof(float));
-        if (out->d_rgb) tone_map(tm_in, hdr, W, H, sc->manual_exposure, out->d_rgb + 4 * base);
+        if (out->d_rgb) tone_map(tm_in, hdr_lum, W, H, sc->manual_exposure, out->d_rgb + 4 * base);
     }
     free(depth); free(hdr); free(hdr2); free(aobuf); free(camc); free(nrmb); free(shadow);
     return 0;

@@ -125,7 +125,7 @@ SCENE_DTYPE = np.dtype(
         ("draw_end", np.uint32),
         ("n_prims", np.uint32),
         ("light_map", np.uint32),     # 1 + index into the pool's light maps, 0 = none
-        ("_pad", np.uint32, (3,)),
+        ("bg_tex", np.uint32, (3,)),  # background image: offset, w, h (w = 0: none)
     ],
     align=False,
 )

@@ -178,6 +178,8 @@ def build_batch(scenes, pool, predicate=None, with_shadows=True):
         objs = [o for o in scene._objects if predicate is None or predicate(o)]
         mats = _shadow.shadow_matrices(scene) if with_shadows else None
         scene_record(scene, srec[si], mats)
+        if scene._background_image is not None:
+            srec[si]["bg_tex"] = pool.add_texture(scene._background_image._rgba, mips=False)
         srec[si]["draw_begin"] = len(draws)
         prim = 0
         # background plane first (render_pass.cpp:545-582)

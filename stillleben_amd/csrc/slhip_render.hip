@@ -1210,6 +1210,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
 
     const slhip_light_map* lm = (sc->light_map != 0u && pool.d_light_maps) ? pool.d_light_maps + (sc->light_map - 1u) : nullptr;
     float color[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float lum_color[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // what the exposure average sees: objects over the cleared target
     if (active) {
         const unsigned long long key = vis[gp];
         float coord[4] = {kInvalid, kInvalid, kInvalid, kInvalid};
@@ -1373,7 +1374,18 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                 bary[0] = b[0]; bary[1] = b[1]; bary[2] = b[2];
             }
         }
-        if (key == kVisEmpty && lm) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lum_color[c] = color[c];   // the 1x1 mip is generated before any background is drawn
+        if (key == kVisEmpty && sc->bg_tex[1] != 0u && sc->bg_tex[2] != 0u) {
+            // background image (render_pass.cpp:637-646): stretched over the viewport, integer texel coordinates on a
+            // LINEAR rectangle sampler, alpha 0; fills the pixels where nothing was rasterised (see oracle/render_ref.c)
+            const int px = (int)(pix % (unsigned)W), py = (int)(pix / (unsigned)W);
+            const int tw = (int)sc->bg_tex[1], th = (int)sc->bg_tex[2];
+            const float tcx = ((float)px + 0.5f) / (float)W, tcy = 1.0f - ((float)py + 0.5f) / (float)H;
+            float c[4];
+            tex_rect_bilinear(pool.d_tex + sc->bg_tex[0], tw, th, (float)(int)(tcx * (float)tw), (float)(int)(tcy * (float)th), c);
+            color[0] = c[0]; color[1] = c[1]; color[2] = c[2]; color[3] = 0.0f;
+        } else if (key == kVisEmpty && lm) {
             // sky background (render_pass.cpp:647-661, background_cube_shader.*): the environment along the
             // pixel's view ray, alpha 0; the other targets keep their clear values
             const int px = (int)(pix % (unsigned)W), py = (int)(pix / (unsigned)W);
@@ -1404,7 +1416,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
         // deterministic block sum (fixed tree) -> one partial per block
         __shared__ float red[4][256];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = color[c];
+        for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = lum_color[c];
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1) {
             if (threadIdx.x < s) {

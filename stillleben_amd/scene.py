@@ -189,9 +189,9 @@ class Scene:
 
     @background_image.setter
     def background_image(self, v):
-        if v is not None:
-            raise NotImplementedError("background_image is outside the hot-path scope (SURVEY.md section 2 row 9)")
-        self._background_image = None
+        """A Texture (rectangle texture of the reference, py_scene.cpp:131-140) stretched over the viewport
+        behind the objects, or None."""
+        self._background_image = v
 
     @property
     def light_map(self):

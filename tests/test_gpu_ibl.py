@@ -198,3 +198,43 @@ def test_render_with_light_map_matches_oracle(sl, oracle):
     scs[0].light_map = None
     dark = eng.render([scs[0]], mask, ssao=True, shadows=True).rgb.cpu().numpy()[0]
     assert rgb[0][inst[0] != 0][:, :3].astype(np.int32).sum() != dark[inst[0] != 0][:, :3].astype(np.int32).sum()
+
+
+def test_background_image_and_exposure_average(sl, oracle):
+    """Scene.background_image fills the pixels without geometry (alpha 0) and -- like the sky -- does not
+    enter the auto-exposure average, which the reference takes before any background is drawn
+    (render_pass.cpp:632-646)."""
+    import scenes as S
+    from stillleben_amd import _abi, _engine
+    from stillleben_amd._batch import HostPool, build_batch
+    from stillleben_amd._context import engine
+    from test_gpu_render import assert_geometry_equal, assert_rgb_close
+
+    rng = np.random.default_rng(0)
+    img = (rng.random((30, 40, 4)) * 255).astype(np.uint8)
+    img[:15, :, 0] = 255                                       # red-ish top half
+    sc = S.clutter_scene(sl, 8, n_objects=4, size=(160, 120))
+    sc.background_plane_size = torch.tensor([0.0, 0.0])
+    sc.background_image = sl.Texture(torch.from_numpy(img))
+    auto = S.clutter_scene(sl, 8, n_objects=4, size=(160, 120))    # same scene, no background: same exposure expected
+    auto.background_plane_size = torch.tensor([0.0, 0.0])
+    eng = engine()
+    scs = [sc, auto]
+    bufs = eng.render(scs, _abi.OUT_ALL, ssao=True, shadows=True)
+    torch.cuda.synchronize()
+    pool = HostPool()
+    srec, drec, _ = build_batch(scs, pool, with_shadows=True)
+    assert srec["bg_tex"][0][1] == 40 and srec["bg_tex"][0][2] == 30 and srec["bg_tex"][1][1] == 0
+    ref = oracle.render(pool.arrays(), srec, drec, 160, 120, _abi.OUT_ALL | _abi.RENDER_SSAO | _abi.RENDER_SHADOWS,
+                        shadow_res=_engine.SHADOW_RES)
+    assert_geometry_equal(bufs, ref)
+    assert_rgb_close(bufs, ref)
+    rgb = bufs.rgb.cpu().numpy()
+    empty = bufs.coord.cpu().numpy()[..., 0] == 3000.0
+    assert (rgb[0][empty[0]][:, 3] == 0).all() and rgb[0][empty[0]][:, :3].max() > 0 and (rgb[1][empty[1]] == 0).all()
+    sc.manual_exposure = 1.0
+    fixed = eng.render([sc], _abi.OUT_ALL, ssao=True, shadows=True).rgb.cpu().numpy()[0]
+    top, bottom = fixed[:40][empty[0][:40]], fixed[-40:][empty[0][-40:]]
+    assert top[:, 0].mean() > bottom[:, 0].mean() + 20         # upright: the red half of the image is at the top
+    covered = ~empty[0]
+    assert np.array_equal(rgb[0][covered][:, :3], rgb[1][covered][:, :3])   # objects: identical exposure with / without background
