@@ -409,6 +409,17 @@ typedef struct {
 int slhip_camera_model(const float* d_in, float* d_out, float* d_tmp, uint32_t n_images, int H, int W,
                        const slhip_camera_params* d_params, void* stream);
 
+/* bp_to_vertices_and_colors (diff.py:215-352, row D6), dense form: for every pixel that belongs to one
+ * of the n_obj objects, the negated gradient of the objective w.r.t. the three vertices of its triangle
+ * (-bary_k * dL/dX, X = object coordinates of the pixel) and w.r.t. their colours (-bary_k * dL/dI).
+ * d_bary f32[H,W,4] (the barycentric target); outputs f32[H,W,3,3], zero where no object matches; the
+ * caller selects the rows of one object's pixels (row-major, as the reference's boolean indexing does)
+ * and pairs them with the vertex-index target.  d_valid u8[H,W] is scratch.                       */
+int slhip_diff_vertex_backward(const uint8_t* d_rgb, const float* d_coord, const int16_t* d_inst,
+                               const float* d_bary, const float* d_grad_img, const float* h_proj,
+                               const float* d_poses, const int32_t* d_obj_inst, int n_obj, int H, int W,
+                               uint8_t* d_valid, float* d_grad_vertices, float* d_grad_colors, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Library
  * ------------------------------------------------------------------------------------------- */

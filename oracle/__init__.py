@@ -250,3 +250,25 @@ def light_map_build(equirect, sizes):
     if st != 0:
         raise RuntimeError("slref_light_map_build failed")
     return bufs
+
+
+def vertex_backward(rgb, coord, inst, bary, grad_img, P, poses, obj_inst):
+    """D6 dense form (oracle/diff_ref.c slref_vertex_backward): returns (grad_vertices, grad_colors) f32[H,W,3,3]."""
+    L = lib()
+    H, W = inst.shape
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    coord = np.ascontiguousarray(coord, dtype=np.float32)
+    inst = np.ascontiguousarray(inst, dtype=np.int16)
+    bary = np.ascontiguousarray(bary, dtype=np.float32)
+    if bary.shape[-1] == 3:
+        bary = np.ascontiguousarray(np.concatenate([bary, np.zeros(bary.shape[:-1] + (1,), np.float32)], axis=-1))
+    grad_img = np.ascontiguousarray(grad_img, dtype=np.float32)
+    P = np.ascontiguousarray(P, dtype=np.float32)
+    poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
+    obj_inst = np.ascontiguousarray(obj_inst, dtype=np.int32)
+    gv = np.zeros((H, W, 3, 3), np.float32)
+    gc = np.zeros((H, W, 3, 3), np.float32)
+    L.slref_vertex_backward.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.slref_vertex_backward(_p(rgb), _p(coord), _p(inst), _p(bary), _p(grad_img), _p(P), _p(poses), _p(obj_inst), len(poses), H, W,
+                            _p(gv), _p(gc))
+    return gv, gc

@@ -158,3 +158,56 @@ void slref_pose_backward(const uint8_t* rgb, const float* coord, const int16_t* 
     }
     free(valid); free(mask); free(dmask); free(c3); free(dc); free(gx); free(gy); free(depth);
 }
+
+
+/* D6: bp_to_vertices_and_colors (diff.py:215-352), dense form (see slhip_diff_vertex_backward in include/slhip.h):
+   per pixel of an object -bary_k * dL/dX and -bary_k * dL/dI, float32 like the reference's torch code.
+   gv, gc: f32[H,W,3,3]. */
+void slref_vertex_backward(const uint8_t* rgb, const float* coord, const int16_t* inst, const float* bary,
+                           const float* grad_img, const float* P, const float* poses, const int32_t* obj_inst,
+                           int n_obj, int H, int W, float* gv, float* gc)
+{
+    const size_t N = (size_t)H * W;
+    uint8_t* valid = (uint8_t*)malloc(N);
+    float* depth = (float*)calloc(N, sizeof(float));
+    float* gx = (float*)malloc(3 * N * sizeof(float));
+    float* gy = (float*)malloc(3 * N * sizeof(float));
+    for (size_t p = 0; p < N; ++p) depth[p] = coord[4 * p + 3];
+    slref_sobel_valid(inst, depth, H, W, valid);
+    slref_image_gradients(rgb, valid, H, W, gx, gy);
+    for (size_t p = 0; p < N; ++p) {
+        float* ov = gv + 9 * p;
+        float* oc = gc + 9 * p;
+        for (int k = 0; k < 9; ++k) { ov[k] = 0.0f; oc[k] = 0.0f; }
+        int o = -1;
+        for (int k = 0; k < n_obj; ++k)
+            if ((int16_t)obj_inst[k] == inst[p]) { o = k; break; }
+        if (o < 0) continue;
+        const float* T = poses + 16 * o;
+        float M[3][4];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c)
+                M[r][c] = ((P[4 * r] * T[c] + P[4 * r + 1] * T[4 + c]) + P[4 * r + 2] * T[8 + c]) + P[4 * r + 3] * T[12 + c];
+        const float X[4] = {coord[4 * p], coord[4 * p + 1], coord[4 * p + 2], 1.0f};
+        float PX[3];
+        for (int r = 0; r < 3; ++r) PX[r] = ((M[r][0] * X[0] + M[r][1] * X[1]) + M[r][2] * X[2]) + M[r][3] * X[3];
+        const float den = PX[2] * PX[2];
+        float gl[3], g3[3];
+        for (int c = 0; c < 3; ++c) gl[c] = grad_img[(size_t)c * N + p];
+        for (int j = 0; j < 3; ++j) {
+            const float gxw = (PX[2] * M[0][j] - PX[0] * M[2][j]) / den;
+            const float gyw = (PX[2] * M[1][j] - PX[1] * M[2][j]) / den;
+            float a = 0.0f;
+            for (int c = 0; c < 3; ++c) a += gl[c] * (gx[(size_t)c * N + p] * gxw + gy[(size_t)c * N + p] * gyw);
+            g3[j] = a;
+        }
+        for (int k = 0; k < 3; ++k) {
+            const float bk = bary[4 * p + k];
+            for (int j = 0; j < 3; ++j) {
+                ov[3 * k + j] = -(bk * g3[j]);
+                oc[3 * k + j] = -(bk * gl[j]);
+            }
+        }
+    }
+    free(valid); free(depth); free(gx); free(gy);
+}

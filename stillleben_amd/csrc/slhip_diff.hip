@@ -199,6 +199,70 @@ __global__ void k_acc_to_float(const double* __restrict__ acc, float* __restrict
     if (i < n) out[i] = (float)acc[i];
 }
 
+
+// D6 (diff.py:215-352): per pixel of an object, -bary_k * dL/dX and -bary_k * dL/dI.  float32 like the
+// reference's torch code: x = (P X)_0 / (P X)_2 with P = proj * pose, so dx/dX_j = (P2 P[0,j] - P0 P[2,j]) / P2^2.
+__global__ __launch_bounds__(256) void k_vertex_backward(const uint8_t* __restrict__ rgb, const float* __restrict__ coord,
+                                                         const int16_t* __restrict__ inst, const uint8_t* __restrict__ valid,
+                                                         const float* __restrict__ bary, const float* __restrict__ grad_img, Mat4 P,
+                                                         const float* __restrict__ poses, const int* __restrict__ obj_inst, int n_obj,
+                                                         int H, int W, float* __restrict__ gv, float* __restrict__ gc)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const size_t N = (size_t)H * W;
+    float outv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, outc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int16_t id = inst[p];
+    int o = -1;
+    for (int k = 0; k < n_obj; ++k)
+        if ((int16_t)obj_inst[k] == id) { o = k; break; }
+    if (o >= 0) {
+        const int h = p / W, w = p % W;
+        float gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0};
+        if (valid[p]) pixel_gradients(rgb, h, w, H, W, gx, gy);   // zero padding at the image border, zero where !valid (D3)
+        // M = proj * pose, rows 0..2 (the reference's [3x4] <= [4x4] @ [4x4], fp32 dot products in k order)
+        const float* T = poses + 16 * o;
+        float M[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                M[r][c] = ((P.m[4 * r] * T[c] + P.m[4 * r + 1] * T[4 + c]) + P.m[4 * r + 2] * T[8 + c]) + P.m[4 * r + 3] * T[12 + c];
+        const float X[4] = {coord[4 * (size_t)p], coord[4 * (size_t)p + 1], coord[4 * (size_t)p + 2], 1.0f};
+        float PX[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) PX[r] = ((M[r][0] * X[0] + M[r][1] * X[1]) + M[r][2] * X[2]) + M[r][3] * X[3];
+        const float den = PX[2] * PX[2];
+        float gl[3], g3[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gl[c] = grad_img[c * N + p];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float gxw = (PX[2] * M[0][j] - PX[0] * M[2][j]) / den;
+            const float gyw = (PX[2] * M[1][j] - PX[1] * M[2][j]) / den;
+            // grad_img_wrt_3D[c][j] = gx[c] * gxw + gy[c] * gyw;  grad_loss_wrt_3D[j] = sum_c gl[c] * that
+            float a = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a += gl[c] * (gx[c] * gxw + gy[c] * gyw);
+            g3[j] = a;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float bk = bary[4 * (size_t)p + k];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                outv[3 * k + j] = -(bk * g3[j]);
+                outc[3 * k + j] = -(bk * gl[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        gv[9 * (size_t)p + k] = outv[k];
+        gc[9 * (size_t)p + k] = outc[k];
+    }
+}
+
 }  // namespace
 
 extern "C" int slhip_diff_sobel_valid(const int16_t* d_inst, const float* d_depth, int depth_stride, int H, int W,
@@ -247,6 +311,31 @@ extern "C" int slhip_diff_pose_backward(const uint8_t* d_rgb, const float* d_coo
     SLHIP_CHECK(hipMemsetAsync(d_acc, 0, sizeof(double) * 6 * n_obj, stream));
     k_pose_backward<<<blocks, 256, 0, stream>>>(d_rgb, d_coord, d_inst, d_valid, d_grad_img, P, d_poses, d_obj_inst, n_obj, H, W, d_acc);
     k_acc_to_float<<<(6 * n_obj + 63) / 64, 64, 0, stream>>>(d_acc, d_out, 6 * n_obj);
+    SLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int slhip_diff_vertex_backward(const uint8_t* d_rgb, const float* d_coord, const int16_t* d_inst,
+                                          const float* d_bary, const float* d_grad_img, const float* h_proj,
+                                          const float* d_poses, const int32_t* d_obj_inst, int n_obj, int H, int W,
+                                          uint8_t* d_valid, float* d_grad_vertices, float* d_grad_colors, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_rgb || !d_coord || !d_inst || !d_bary || !d_grad_img || !h_proj || !d_poses || !d_obj_inst || !d_valid ||
+        !d_grad_vertices || !d_grad_colors) {
+        slhip::set_error("slhip_diff_vertex_backward: null argument");
+        return -1;
+    }
+    if (H <= 0 || W <= 0 || n_obj < 0) {
+        slhip::set_error("slhip_diff_vertex_backward: bad sizes");
+        return -1;
+    }
+    Mat4 P;
+    for (int i = 0; i < 16; ++i) P.m[i] = h_proj[i];
+    const int blocks = (H * W + 255) / 256;
+    k_sobel_valid<<<blocks, 256, 0, stream>>>(d_inst, d_coord + 3, 4, H, W, d_valid);
+    k_vertex_backward<<<blocks, 256, 0, stream>>>(d_rgb, d_coord, d_inst, d_valid, d_bary, d_grad_img, P, d_poses, d_obj_inst,
+                                                  n_obj, H, W, d_grad_vertices, d_grad_colors);
     SLHIP_LAUNCH_CHECK();
     return 0;
 }

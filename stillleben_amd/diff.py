@@ -17,7 +17,7 @@ from .profiling import Timer
 
 __all__ = [
     'compute_image_space_gradients', 'backpropagate_gradient_to_poses', 'apply_pose_delta',
-    'generate_sobel_valid_mask', 'dilate_object_mask',
+    'generate_sobel_valid_mask', 'dilate_object_mask', 'bp_to_vertices_and_colors', 'soft_forward',
 ]
 
 DIFF_AVAILABLE = True
@@ -120,6 +120,98 @@ def backpropagate_gradient_to_poses(scene, render_result, grad_objective_wrt_rnd
                                             _p(ids), n, H, W, _p(valid), _p(acc), _p(res), _stream(eng))
     _abi.check(st, "slhip_diff_pose_backward")
     return res.cpu()
+
+
+def bp_to_vertices_and_colors(scene, render_result, grad_objective_wrt_rnd_img, visualize_grad=False):
+    r"""diff.py:215-352 (row D6): backpropagates an image-space gradient to the vertices (and vertex colours)
+    of the meshes.  Returns three lists with one entry per rendered object: vertex indices int32[3P] (the
+    1-based ids of the vertex-index target, pixel by pixel in row-major order), -d objective / d vertex
+    f32[3P,3] and -d objective / d colour f32[3P,3] (barycentric-weighted, ready for Mesh.update_*)."""
+    eng = engine()
+    objs = scene.objects
+    rgb = render_result.rgb().to(eng.device).contiguous()
+    H, W = rgb.shape[:2]
+    out_dev = render_result.rgb().device
+    g = grad_objective_wrt_rnd_img.to(eng.device, torch.float32).contiguous()
+    if tuple(g.shape) != (3, H, W):
+        raise ValueError("grad_objective_wrt_rnd_img must be 3xHxW")
+    vertex_index_2_bp, grad_vertices_2_bp, grad_colors_2_bp = [], [], []
+    if not objs:
+        return vertex_index_2_bp, grad_vertices_2_bp, grad_colors_2_bp
+    coord = render_result.coordDepth().to(eng.device).contiguous()
+    inst = render_result.instance_index().squeeze(-1).to(eng.device).contiguous()
+    bary = render_result.barycentric_coeffs().to(eng.device, torch.float32)
+    if bary.shape[-1] == 3:
+        bary = torch.cat([bary, torch.zeros_like(bary[..., :1])], dim=-1)
+    bary = bary.contiguous()
+    vidx = render_result.vertex_indices().to(eng.device)[..., :3].reshape(-1, 3)
+    poses = torch.stack([o.pose() for o in objs]).to(eng.device, torch.float32).contiguous()
+    ids = torch.tensor([o.instance_index for o in objs], dtype=torch.int32, device=eng.device)
+    P = np.ascontiguousarray(scene.projection_matrix().numpy(), dtype=np.float32)
+    valid = torch.empty((H, W), dtype=torch.uint8, device=eng.device)
+    gv = torch.empty((H * W, 3, 3), dtype=torch.float32, device=eng.device)
+    gc = torch.empty((H * W, 3, 3), dtype=torch.float32, device=eng.device)
+    with torch.cuda.device(eng.device):
+        st = eng.L.slhip_diff_vertex_backward(_p(rgb), _p(coord), _p(inst), _p(bary), _p(g), C.c_void_p(P.ctypes.data), _p(poses),
+                                              _p(ids), len(objs), H, W, _p(valid), _p(gv), _p(gc), _stream(eng))
+    _abi.check(st, "slhip_diff_vertex_backward")
+    flat_inst = inst.reshape(-1)
+    for obj in objs:
+        m = flat_inst == obj.instance_index          # the reference's boolean indexing: pixels in row-major order
+        if not bool(m.any()):
+            print('instance_index image for the current object is empty')
+            print('object not rendered as a part of the scene')
+            continue
+        vertex_index_2_bp.append(vidx[m].reshape(-1).to(out_dev))
+        grad_vertices_2_bp.append(gv[m].reshape(-1, 3).to(out_dev))
+        grad_colors_2_bp.append(gc[m].reshape(-1, 3).to(out_dev))
+    return vertex_index_2_bp, grad_vertices_2_bp, grad_colors_2_bp
+
+
+def soft_forward(scene, render_result, obs_rgb, loss_fn):
+    """diff.py:130-213: blends the depth-peeled renders (weights 0.7, 0.3, 0.1, 0.1, 0.05), blurs with the 11x11
+    Gaussian, evaluates `loss_fn` against the observation and backpropagates the image gradient of every peel layer
+    to vertices and colours.  `render_result` is the list of results in peeling order.  (The reference additionally
+    demands an `is_extracted` attribute that nothing in its tree sets, diff.py:153 -- not required here.)"""
+    import types
+
+    if not isinstance(render_result, (list, tuple)):
+        raise ValueError("render_result should be a list or tuple")
+    if obs_rgb.dim() != 3:
+        raise ValueError("Observed RGB should have 3 dimension CxHxW")
+    if obs_rgb.shape[0] != 3:
+        raise ValueError("Observed RGB should of format CxHxW with C=3")
+    if obs_rgb.dtype != torch.float32:
+        raise ValueError("Observed RGB should be of type torch.float32")
+    if obs_rgb.max().item() > 1:
+        raise ValueError("Observed RGB should have range [0,1]")
+    if not isinstance(loss_fn, types.FunctionType):
+        raise ValueError("loss_fn should be a callable function")
+    for rr in render_result:
+        if rr.rgb().shape != render_result[0].rgb().shape:
+            raise ValueError("render_results should correspond to the same scene")
+    device = render_result[0].rgb().device
+    rgbs = torch.stack([rr.rgb()[:, :, :3].permute(2, 0, 1).float() / 255.0 for rr in render_result]).detach()
+    rgbs.requires_grad = True
+    weights = torch.tensor([0.7, 0.3, 0.1, 0.1, 0.05], device=device)
+    soft_rgb = (rgbs * weights[: rgbs.shape[0], None, None, None]).sum(dim=0)
+    ks, sig = 11, 1.0                                                  # diff.py:61-71
+    ax = torch.arange(ks, dtype=torch.float32, device=device) - (ks - 1) / 2.0
+    k1 = torch.exp(-0.5 * (ax / sig) ** 2)
+    kernel = (k1[:, None] * k1[None, :])
+    kernel = (kernel / kernel.sum()).view(1, 1, ks, ks)
+    soft_gauss = torch.nn.functional.conv2d(soft_rgb.unsqueeze(1), kernel, padding=ks // 2).squeeze(1)
+    loss, loss_img = loss_fn(soft_gauss.unsqueeze(0), obs_rgb.to(device).unsqueeze(0))
+    loss.backward()
+    grads = rgbs.grad.clone()
+    vertex_index_2_bp, grad_vertices_2_bp, grad_colors_2_bp = [], [], []
+    for ir, rr in enumerate(render_result):
+        vi, gv, gc = bp_to_vertices_and_colors(scene, rr, grads[ir])
+        vertex_index_2_bp += vi
+        grad_vertices_2_bp += gv
+        grad_colors_2_bp += gc
+    return (soft_rgb.detach().clone(), [r.clone().detach() for r in rgbs], loss_img, loss.item(), vertex_index_2_bp,
+            grad_vertices_2_bp, grad_colors_2_bp)
 
 
 def apply_pose_delta(pose, delta, orthonormalize=True):

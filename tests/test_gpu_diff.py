@@ -170,3 +170,72 @@ def test_c5_many_objects_linearity(sl):
     g0[:, near] = 0.0
     d0 = sl.diff.backpropagate_gradient_to_poses(scene, res, g0)
     assert float(d0[0].abs().max()) == 0.0 and float(d0[1:].abs().max()) > 0.0
+
+
+class _ResultVB(_Result):
+    def __init__(self, rgb, coord, inst, bary, vidx):
+        super().__init__(rgb, coord, inst)
+        self._bary, self._vidx = torch.from_numpy(bary), torch.from_numpy(vidx)
+
+    def barycentric_coeffs(self):
+        return self._bary
+
+    def vertex_indices(self):
+        return self._vidx
+
+
+@pytest.mark.parametrize("name", ["small", "occl"])
+def test_d6_bp_to_vertices_and_colors(sl, oracle, name):
+    """Row D6 through the public API: identical to the oracle (same float32 operation order) and within float
+    tolerance of the reference's own outputs (tests/golden/diff_vertex_golden.npz)."""
+    V = np.load(os.path.join(os.path.dirname(GOLDEN), "diff_vertex_golden.npz"))
+    objs = [_Obj(p, i) for p, i in zip(V[name + "_poses"], V[name + "_obj_inst"])]
+    scene = _Scene(V[name + "_P"], objs)
+    res = _ResultVB(V[name + "_rgb"], V[name + "_coord"], V[name + "_inst"], V[name + "_bary"], V[name + "_vidx"])
+    vi, gv, gc = sl.diff.bp_to_vertices_and_colors(scene, res, torch.from_numpy(V[name + "_grad_img"]))
+    assert len(vi) == len(objs)
+    vi_c, gv_c, gc_c = (torch.cat(x).numpy() for x in (vi, gv, gc))
+    assert np.array_equal(vi_c, V[name + "_out_vidx"])
+    ogv, ogc = oracle.vertex_backward(V[name + "_rgb"], V[name + "_coord"], V[name + "_inst"], V[name + "_bary"], V[name + "_grad_img"],
+                                      V[name + "_P"], V[name + "_poses"], V[name + "_obj_inst"])
+    ref_gv = np.concatenate([ogv[V[name + "_inst"] == o].reshape(-1, 3) for o in V[name + "_obj_inst"]])
+    ref_gc = np.concatenate([ogc[V[name + "_inst"] == o].reshape(-1, 3) for o in V[name + "_obj_inst"]])
+    assert np.array_equal(gv_c.view(np.uint32), ref_gv.view(np.uint32)) and np.array_equal(gc_c.view(np.uint32), ref_gc.view(np.uint32))
+    scale = max(1.0, float(np.abs(V[name + "_out_gv"]).max()))
+    assert np.abs(gv_c - V[name + "_out_gv"]).max() <= 2e-5 * scale and np.abs(gc_c - V[name + "_out_gc"]).max() <= 1e-6
+
+
+def test_d6_on_a_rendered_scene_and_soft_forward(sl):
+    """The vertex path end to end on real render targets: ids / barycentrics come from the renderer, the result
+    feeds Mesh.update_positions, and soft_forward blends two depth-peel layers."""
+    scene = S.clutter_scene(sl, 3, n_objects=3, size=(160, 120))
+    scene.manual_exposure = 1.0
+    rp = sl.RenderPass()
+    res = rp.render(scene)
+    g = torch.from_numpy(pattern_grad(120, 160))
+    vi, gv, gc = sl.diff.bp_to_vertices_and_colors(scene, res, g)
+    inst = res.instance_index().squeeze(-1)
+    seen = [o for o in scene.objects if bool((inst == o.instance_index).any())]
+    assert len(vi) == len(seen) >= 2
+    for o, v, a, c in zip(seen, vi, gv, gc):
+        n = int((inst == o.instance_index).sum())
+        assert v.shape == (3 * n,) and a.shape == (3 * n, 3) and c.shape == (3 * n, 3)
+        assert int(v.min()) >= 1 and int(v.max()) <= o.mesh.points.shape[0]
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+    # linear in the image gradient
+    vi2, gv2, _ = sl.diff.bp_to_vertices_and_colors(scene, res, 2.0 * g)
+    assert torch.equal(vi2[0], vi[0]) and torch.allclose(gv2[0], 2.0 * gv[0], rtol=1e-5, atol=1e-7)
+    # the gradients are in the units Mesh.update_positions expects
+    m = seen[0].mesh
+    before = m.points.clone()
+    m.update_positions(vi[0][:3], before[(vi[0][:3] - 1).long()] + 1e-4 * gv[0][:3])
+    assert not torch.equal(m.points, before)
+    peel = rp.render(scene, depth_peel=res)
+
+    def loss_fn(pred, obs):
+        d = (pred - obs) ** 2
+        return d.mean(), d
+
+    obs = torch.rand(3, 120, 160)
+    soft, layers, loss_img, loss, svi, sgv, sgc = sl.diff.soft_forward(scene, [res, peel], obs, loss_fn)
+    assert soft.shape == (3, 120, 160) and len(layers) == 2 and loss > 0 and len(svi) == len(sgv) == len(sgc) >= len(seen)

@@ -78,3 +78,26 @@ def test_apply_pose_delta(oracle, G):
     assert np.allclose(raw, G["apd_out_raw"], atol=1e-6)
     R = out[:, :3, :3]
     assert np.allclose(R @ np.transpose(R, (0, 2, 1)), np.eye(3), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["small", "occl"])
+def test_d6_vertex_backward_matches_reference(oracle, name):
+    """Row D6: oracle/diff_ref.c slref_vertex_backward against the outputs of the REFERENCE's
+    bp_to_vertices_and_colors (oracle/ref_build/gen_diff_vertex_golden.py)."""
+    G = np.load(os.path.join(os.path.dirname(GOLDEN), "diff_vertex_golden.npz"))
+    inst = G[name + "_inst"]
+    gv, gc = oracle.vertex_backward(G[name + "_rgb"], G[name + "_coord"], inst, G[name + "_bary"], G[name + "_grad_img"],
+                                    G[name + "_P"], G[name + "_poses"], G[name + "_obj_inst"])
+    vi_ref, gv_ref, gc_ref = G[name + "_out_vidx"], G[name + "_out_gv"], G[name + "_out_gc"]
+    off = 0
+    for o, n in zip(G[name + "_obj_inst"], G[name + "_n"]):
+        m = inst == o
+        assert 3 * int(m.sum()) == int(n)
+        assert np.array_equal(G[name + "_vidx"][m].reshape(-1), vi_ref[off:off + n])
+        a, b = gv[m].reshape(-1, 3), gv_ref[off:off + n]
+        scale = max(1.0, float(np.abs(b).max()))
+        assert np.abs(a - b).max() <= 2e-5 * scale, (np.abs(a - b).max(), scale)   # fp32 torch bmm vs the explicit sums
+        assert np.abs(gc[m].reshape(-1, 3) - gc_ref[off:off + n]).max() <= 1e-6
+        off += int(n)
+    assert off == len(vi_ref)
+    assert not gv[inst == 0].any() and not gc[inst == 0].any()
