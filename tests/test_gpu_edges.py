@@ -135,3 +135,22 @@ def test_static_only_and_sleeping_scene(sl, oracle):
     gpu, ref = run_both(oracle, [rest], frames=250)      # long enough for every body to fall asleep
     assert_bodies_equal(gpu, ref)
     assert (gpu["flags"] & 2).all() or np.abs(gpu["lin_vel"]).max() < 1e-3
+
+
+# ---- post-render I/O ('next' row f4) -----------------------------------------------------------------
+def test_image_saver_takes_device_tensors(sl, tmp_path):
+    """ImageSaver copies render outputs off the device on a side stream; the files hold the exact bytes."""
+    from PIL import Image
+
+    scene = S.clutter_scene(sl, 5, n_objects=4, size=(160, 120))
+    result = sl.RenderPass().render(scene)
+    rgb = result.rgb()
+    inst = result.instance_index()
+    assert rgb.is_cuda
+    with sl.ImageSaver() as saver:
+        for i in range(12):
+            saver.save(rgb, str(tmp_path / ("rgb%d.png" % i)))
+        saver.save(inst.to(torch.uint8), str(tmp_path / "inst.png"))
+    for i in range(12):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / ("rgb%d.png" % i))), rgb.cpu().numpy())
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "inst.png")), inst.to(torch.uint8).cpu().numpy())

@@ -294,3 +294,89 @@ def test_hull_cache_invalidation_keys(sl, tmp_path):
     # in-memory / primitive meshes never touch the disk
     prim = sl.Mesh("primitive://cube")
     assert prim._hulls is not None and not os.path.exists("primitive://cube" + hulls.CACHE_SUFFIX)
+
+
+# ---- 'next' row f4: asynchronous ImageSaver, ImageLoader; Animator (reference src/image_saver.cpp,
+# src/image_loader.cpp, src/animator.cpp) --------------------------------------------------------------
+def test_image_saver_round_trip(tmp_path):
+    import stillleben_amd as sl
+    from PIL import Image
+
+    g = torch.Generator().manual_seed(3)
+    rgb = torch.randint(0, 256, (48, 64, 3), dtype=torch.uint8, generator=g)
+    rgba = torch.randint(0, 256, (48, 64, 4), dtype=torch.uint8, generator=g)
+    gray = torch.randint(0, 256, (48, 64), dtype=torch.uint8, generator=g)
+    depth = torch.randint(0, 30000, (48, 64), dtype=torch.int16, generator=g)
+    saver = sl.ImageSaver()
+    with pytest.raises(RuntimeError):
+        saver.save(rgb, str(tmp_path / "early.png"))          # py_image_saver.cpp:36-37
+    with saver:
+        for i in range(20):                                    # more jobs than the queue bound
+            saver.save(rgb, str(tmp_path / ("rgb%02d.png" % i)))
+        saver.save(rgba, str(tmp_path / "rgba.png"))
+        saver.save(gray, str(tmp_path / "gray.png"))
+        saver.save(depth, str(tmp_path / "depth.png"))
+        rgb_copy = rgb.clone()
+        rgb.zero_()                                            # the job owns its data once save() returned
+        with pytest.raises(ValueError):
+            saver.save(torch.zeros(4, 4, 2, dtype=torch.uint8), str(tmp_path / "bad.png"))
+        with pytest.raises(ValueError):
+            saver.save(torch.zeros(4, 4, 3), str(tmp_path / "bad.png"))
+        with pytest.raises(ValueError):
+            saver.save(torch.zeros(4, 4), str(tmp_path / "bad.png"))
+    for i in range(20):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / ("rgb%02d.png" % i))), rgb_copy.numpy())
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "rgba.png")), rgba.numpy())
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "gray.png")), gray.numpy())
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "depth.png")).astype(np.int16), depth.numpy())
+
+
+def test_image_loader_random_order(tmp_path):
+    import stillleben_amd as sl
+    from PIL import Image
+
+    imgs = {}
+    for i in range(5):
+        a = np.full((8 + i, 12, 3), 10 * i + 1, np.uint8)
+        Image.fromarray(a).save(tmp_path / ("im%d.png" % i))
+        imgs[a.shape[0]] = a
+    Image.fromarray(np.zeros((4, 4), np.uint8)).save(tmp_path / "gray.png")   # skipped: not RGB/RGBA
+    (tmp_path / "broken.jpg").write_bytes(b"not an image")                    # skipped: unreadable
+    loader = sl.ImageLoader(str(tmp_path), seed=1)
+    seen = set()
+    for _ in range(60):
+        t = loader.next()
+        assert isinstance(t, sl.Texture)
+        arr = t._rgba
+        assert arr.shape[2] == 4 and np.array_equal(arr[..., :3], imgs[arr.shape[0]])
+        seen.add(arr.shape[0])
+    assert seen == set(imgs)
+    assert isinstance(loader.next_texture2d(), sl.Texture2D)
+    assert isinstance(loader.next_rectangle_texture(), sl.Texture)
+    loader.close()
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    with pytest.raises(RuntimeError):
+        sl.ImageLoader(str(empty))
+
+
+def test_animator_interpolates_poses():
+    import stillleben_amd as sl
+    p1 = torch.eye(4)
+    p2 = p1.clone()
+    p2[:3, 3] = torch.tensor([0.0, 1.0, 0.0])
+    p2[:3, :3] = sl.quat_to_matrix([0.0, 0.0, np.sin(np.pi / 4), np.cos(np.pi / 4)])   # 90 deg about z
+    anim = sl.Animator([p1, p2], 100)
+    assert len(anim) == 100
+    poses = list(anim)
+    assert len(poses) == 100
+    assert torch.allclose(poses[0], p1, atol=1e-6)
+    assert torch.allclose(poses[50][:3, 3], torch.tensor([0.0, 0.5, 0.0]), atol=1e-6)
+    # nlerp at the midpoint of a 90 degree turn is exactly the 45 degree rotation
+    assert torch.allclose(poses[50][:3, :3], sl.quat_to_matrix([0.0, 0.0, np.sin(np.pi / 8), np.cos(np.pi / 8)]), atol=1e-6)
+    for p in poses:
+        assert torch.allclose(p[:3, :3] @ p[:3, :3].t(), torch.eye(3), atol=1e-5)
+    with pytest.raises(ValueError):
+        sl.Animator([p1], 10)
+    three = list(sl.Animator([p1, p2, p1], 10))                # keyframes at ticks 0, 5, 10
+    assert torch.allclose(three[5], p2, atol=1e-6)
