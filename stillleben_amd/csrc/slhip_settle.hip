@@ -16,6 +16,7 @@
 // Only + - * / sqrt and explicit fmaf are used and every reduction has a fixed order, so the
 // result is bit-identical to oracle/settle_ref.c (the parity contract) for any lane count.
 #include "slhip_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -113,7 +114,7 @@ struct WBody {
 struct DriveAcc { float dl[3], da[3]; };
 
 // solver contact, compacted in LDS (plane contacts first, then hull-pair contacts in pair order).
-// 68 bytes: the bodies and the friction coefficients come from the contact's group, the tangent
+// 72 bytes: the bodies and the friction coefficients come from the contact's group, the tangent
 // basis is a pure function of n and is recomputed in the solver, the restitution target is folded
 // into `bounce` (-inf = none).  Between fill_contact and prep_contact the fields ln / lt1 / bounce
 // carry the body indices (as integer bits) and the restitution.
@@ -122,8 +123,9 @@ struct Contact {
     float err;            // sep - rest
     float kn, kt1, kt2, ln, lt1, lt2;
     float bounce;         // required rebound velocity (-e * vn0) or a large negative number
+    float til;            // 1 / |a| of the tangent construction (prep_contact): spares the solver a sqrt and a division per row
 };
-static_assert(sizeof(Contact) == 68, "Contact layout");
+static_assert(sizeof(Contact) == 72, "Contact layout");
 
 // raw narrowphase result of one hull pair / one body-vs-plane test (registers)
 struct RawContacts {
@@ -387,15 +389,23 @@ __device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict
     return d > 1e-6f ? 1 : 0;
 }
 
-__device__ __forceinline__ void tangents(v3 n, v3* t1, v3* t2)
+__device__ __forceinline__ v3 tangent_axis(v3 n)
 {
-    v3 a;
-    if (fabsf(n.x) > 0.57735f) a = V(n.y, -n.x, 0.0f);
-    else a = V(0.0f, n.z, -n.y);
-    const float l = sqrtf(dot(a, a));
-    *t1 = scale(a, 1.0f / l);
+    if (fabsf(n.x) > 0.57735f) return V(n.y, -n.x, 0.0f);
+    return V(0.0f, n.z, -n.y);
+}
+__device__ __forceinline__ float tangent_inv_len(v3 n)
+{
+    const v3 a = tangent_axis(n);
+    return 1.0f / sqrtf(dot(a, a));
+}
+// same values as tangents() with the inverse length supplied
+__device__ __forceinline__ void tangents_cached(v3 n, float inv_len, v3* t1, v3* t2)
+{
+    *t1 = scale(tangent_axis(n), inv_len);
     *t2 = cross(n, *t1);
 }
+__device__ __forceinline__ void tangents(v3 n, v3* t1, v3* t2) { tangents_cached(n, tangent_inv_len(n), t1, t2); }
 
 __device__ void overlap_fallback(const Shape& A, const Shape& B, const f3* __restrict__ hv, v3 ca, v3 cb, v3* n,
                                  float* sep, v3* pa, v3* pb)
@@ -810,6 +820,7 @@ __device__ __forceinline__ void fill_contact(Contact* c, int a, int b, const WBo
     k.ln = __int_as_float(a); k.lt1 = __int_as_float(b);   // consumed (and zeroed) by prep_contact
     k.lt2 = 0.0f;
     k.bounce = e;                                          // restitution until prep_contact
+    k.til = 0.0f;
     *c = k;
 }
 
@@ -858,7 +869,8 @@ __device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_thresho
     const WBody& a = wbs[ia];
     const WBody* b = ib >= 0 ? &wbs[ib] : nullptr;
     v3 t1, t2;
-    tangents(c.n, &t1, &t2);
+    const float til = tangent_inv_len(c.n);
+    tangents_cached(c.n, til, &t1, &t2);
     c.kn = eff_mass(a, b, c.ra, c.rb, c.n);
     c.kt1 = eff_mass(a, b, c.ra, c.rb, t1);
     c.kt2 = eff_mass(a, b, c.ra, c.rb, t2);
@@ -869,13 +881,16 @@ __device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_thresho
     float bounce = -3.0e38f;
     if (vn0 < -bounce_threshold && e > 0.0f) bounce = -e * vn0;
     cp->kn = c.kn; cp->kt1 = c.kt1; cp->kt2 = c.kt2; cp->bounce = bounce;
-    cp->ln = 0.0f; cp->lt1 = 0.0f;
+    cp->ln = 0.0f; cp->lt1 = 0.0f; cp->til = til;
 }
 
-// Gauss-Seidel sweep over the contacts of ONE group (all share the same two bodies): the bodies'
-// velocities, inverse inertia and masses are held in registers for the whole group and written
-// back once, which removes an LDS round trip per contact.  Arithmetic and order are exactly
-// those of the oracle's solve_contact applied to the group's contacts in sequence.
+// Gauss-Seidel sweep over the contacts of ONE group (all share the same two bodies) by a PAIR of
+// adjacent lanes: lane `side` 0 owns body a, lane 1 owns body b (or nothing, for a plane group).
+// Each lane keeps its body's velocities, inverse inertia and mass in registers for the whole group
+// and writes them back once; the only exchange per row is the body's velocity at the contact point
+// (one DPP quad permute per component).  Lane 1 works with the negated relative velocity and the
+// negated impulse: IEEE negation commutes with every + - * fma, so its results are bit-for-bit
+// those of the oracle's solve_contact (a - b, then -J on body b) applied to the contacts in order.
 struct BodyRegs {
     v3 v, w;
     m3 Iinv;
@@ -888,37 +903,45 @@ __device__ __forceinline__ void load_regs(const WBody& b, BodyRegs& r)
     r.v = b.v; r.w = b.w; r.Iinv = b.Iinv_w; r.inv_mass = b.inv_mass; r.dynamic = b.dynamic != 0;
 }
 
-__device__ __forceinline__ v3 vel_at_r(const BodyRegs& b, v3 r) { return add(b.v, cross(b.w, r)); }
-
-__device__ __forceinline__ void apply_regs(BodyRegs& a, BodyRegs& b, bool has_b, v3 ra, v3 rb, v3 J)
+// value held by the other lane of the (2k, 2k+1) pair: DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float pair_swap(float x)
 {
-    if (a.dynamic) {
-        a.v = madd(a.v, J, a.inv_mass);
-        a.w = add(a.w, m3_mul(a.Iinv, cross(ra, J)));
-    }
-    if (has_b && b.dynamic) {
-        b.v = madd(b.v, J, -b.inv_mass);
-        b.w = sub(b.w, m3_mul(b.Iinv, cross(rb, J)));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ v3 pair_swap(v3 a) { return V(pair_swap(a.x), pair_swap(a.y), pair_swap(a.z)); }
+
+__device__ __forceinline__ void apply_mine(BodyRegs& m, v3 r, v3 J)
+{
+    if (m.dynamic) {
+        m.v = madd(m.v, J, m.inv_mass);
+        m.w = add(m.w, m3_mul(m.Iinv, cross(r, J)));
     }
 }
 
-__device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, WBody* wbs, float inv_dt, bool biased,
-                            float plane_mu_s, float plane_mu_d)
+__device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, int side, WBody* wbs, float inv_dt,
+                            bool biased, float plane_mu_s, float plane_mu_d)
 {
     if (begin >= end) return;
-    BodyRegs A, B;
-    load_regs(wbs[ia], A);
     const bool has_b = ib >= 0;
-    if (has_b) load_regs(wbs[ib], B);
-    else { B.v = V(0, 0, 0); B.w = V(0, 0, 0); B.inv_mass = 0.0f; B.dynamic = false; }
-    if (!A.dynamic && !B.dynamic) return;  // the oracle invalidates such contacts in prep
+    const int mine = side ? ib : ia;
+    BodyRegs M;
+    if (mine >= 0) load_regs(wbs[mine], M);
+    else {   // the idle lane of a plane group: +0 velocities, so a - b == a exactly
+        M.v = V(0, 0, 0); M.w = V(0, 0, 0); M.inv_mass = 0.0f; M.dynamic = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) M.Iinv.m[k] = 0.0f;
+    }
+    const bool other_dynamic = pair_swap(M.dynamic ? 1.0f : 0.0f) != 0.0f;
+    if (!M.dynamic && !other_dynamic) return;  // the oracle invalidates such contacts in prep
     const float mu_s = 0.5f * (wbs[ia].mu_s + (has_b ? wbs[ib].mu_s : plane_mu_s));
     const float mu_d = 0.5f * (wbs[ia].mu_d + (has_b ? wbs[ib].mu_d : plane_mu_d));
+    const float sgn = side ? -1.0f : 1.0f;
     for (int ci = begin; ci < end; ++ci) {
-        Contact c = ac[ci];
-        v3 rel = vel_at_r(A, c.ra);
-        if (has_b) rel = sub(rel, vel_at_r(B, c.rb));
-        const float vn = dot(rel, c.n);
+        const Contact c = ac[ci];
+        const v3 r = side ? c.rb : c.ra;
+        v3 pv = add(M.v, cross(M.w, r));
+        v3 d = sub(pv, pair_swap(pv));              // side 0: a - b, side 1: b - a
+        const float vn = sgn * dot(d, c.n);
         const float err = c.err;
         float target;
         if (err > 0.0f) target = -err * inv_dt;
@@ -928,27 +951,25 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, WBo
         float ln = c.ln + dl;
         if (ln < 0.0f) ln = 0.0f;
         dl = ln - c.ln;
-        c.ln = ln;
-        apply_regs(A, B, has_b, c.ra, c.rb, scale(c.n, dl));
-        rel = vel_at_r(A, c.ra);
-        if (has_b) rel = sub(rel, vel_at_r(B, c.rb));
+        apply_mine(M, r, scale(c.n, sgn * dl));
+        pv = add(M.v, cross(M.w, r));
+        d = sub(pv, pair_swap(pv));
         v3 t1, t2;
-        tangents(c.n, &t1, &t2);
-        float l1 = c.lt1 - dot(rel, t1) * c.kt1;
-        float l2 = c.lt2 - dot(rel, t2) * c.kt2;
+        tangents_cached(c.n, c.til, &t1, &t2);
+        float l1 = c.lt1 - (sgn * dot(d, t1)) * c.kt1;
+        float l2 = c.lt2 - (sgn * dot(d, t2)) * c.kt2;
         const float mag2 = fmaf(l2, l2, l1 * l1);
-        const float lim_s = mu_s * c.ln;
+        const float lim_s = mu_s * ln;
         if (mag2 > lim_s * lim_s) {
             const float mag = sqrtf(mag2);
-            const float k = (mu_d * c.ln) / mag;
+            const float k = (mu_d * ln) / mag;
             l1 *= k; l2 *= k;
         }
         const float d1 = l1 - c.lt1, d2 = l2 - c.lt2;
-        apply_regs(A, B, has_b, c.ra, c.rb, madd(scale(t1, d1), t2, d2));
-        ac[ci].ln = c.ln; ac[ci].lt1 = l1; ac[ci].lt2 = l2;
+        apply_mine(M, r, madd(scale(t1, sgn * d1), t2, sgn * d2));
+        if (side == 0) { ac[ci].ln = ln; ac[ci].lt1 = l1; ac[ci].lt2 = l2; }
     }
-    if (A.dynamic) { wbs[ia].v = A.v; wbs[ia].w = A.w; }
-    if (has_b && B.dynamic) { wbs[ib].v = B.v; wbs[ib].w = B.w; }
+    if (M.dynamic) { wbs[mine].v = M.v; wbs[mine].w = M.w; }
 }
 
 // D6 joint drive of ManipulationSim (same arithmetic as the oracle's solve_drive)
@@ -1117,6 +1138,7 @@ constexpr int kNoBody = 0xff;
 static_assert(sizeof(Group) == 5, "Group layout");
 static_assert(SLHIP_MAX_ACTIVE_CONTACTS < 256 && SLHIP_MAX_BODIES <= 64, "byte-sized group fields");
 static_assert(SLHIP_MAX_HULL_PAIRS * 4 >= 4 * kBandCap * (int)sizeof(BandPt), "the plane phase's band cache aliases the hull-pair list");
+static_assert(SLHIP_MAX_HULL_PAIRS * 4 >= (kMaxGroups + 65) * 2, "the solver's colour order aliases the hull-pair list");
 
 __host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_cap)
 {
@@ -1160,6 +1182,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     unsigned char* plist = reinterpret_cast<unsigned char*>(smem + L.off_misc + L.nb_cap * 16 + 64);   // bodies near the plane
     unsigned char* cpl = plist + 64;                 // lanes of the contact pairs of a narrowphase window
     BandPt* band = reinterpret_cast<BandPt*>(hp);    // plane phase only: 4 x kBandCap cached in-band vertices
+    unsigned short* order = reinterpret_cast<unsigned short*>(hp);   // solver only: groups sorted by colour ...
+    unsigned short* cstart = order + kMaxGroups;                     // ... and each colour's first slot
     const float4* gv = reinterpret_cast<const float4*>(hull_verts);
     DriveAcc* drv = drive_all + (size_t)blockIdx.x * SLHIP_MAX_BODIES;
 
@@ -1555,6 +1579,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
             __syncthreads();
             const int ncol = counters[1];
+            // groups listed colour by colour (ballot + popcount prefix, in group order); the list and the
+            // colour offsets alias the hull-pair list, which is dead until the next broadphase
+            {
+                int base = 0;
+                for (int col = 0; col < ncol; ++col) {
+                    if (lane == 0) cstart[col] = (unsigned short)base;
+                    for (int g0 = 0; g0 < n_groups; g0 += 64) {
+                        const int g = g0 + lane;
+                        const bool p = g < n_groups && groups[g].color == col;
+                        const int slot = compact_slot(p, base);
+                        if (p) order[slot] = (unsigned short)g;
+                        base += __popcll(__ballot(p));
+                    }
+                }
+                if (lane == 0) cstart[ncol] = (unsigned short)base;
+            }
+            __syncthreads();
             PROF(7);
             PROF_COUNT(2, n_groups); PROF_COUNT(3, ncol); PROF_COUNT(1, n_active);
 
@@ -1562,10 +1603,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const float inv_dt = 1.0f / prm.dt;
             for (unsigned it = 0; it < prm.pos_iters; ++it) {
                 for (int col = 0; col < ncol; ++col) {
-                    for (int g = lane; g < n_groups; g += 64) {
-                        const Group G = groups[g];
-                        if (G.color != col) continue;
-                        solve_group(ac, G.begin, G.end, G.a, G.b == kNoBody ? -1 : (int)G.b, wb, inv_dt, true, prm.plane_mu_s, prm.plane_mu_d);
+                    const int ce = cstart[col + 1];
+                    for (int k = cstart[col] + (lane >> 1); k < ce; k += 32) {   // a lane pair per group
+                        const Group G = groups[order[k]];
+                        solve_group(ac, G.begin, G.end, G.a, G.b == kNoBody ? -1 : (int)G.b, lane & 1, wb, inv_dt, true, prm.plane_mu_s, prm.plane_mu_d);
                     }
                     __syncthreads();
                 }
@@ -1597,10 +1638,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // (j) velocity iterations
             for (unsigned it = 0; it < prm.vel_iters; ++it) {
                 for (int col = 0; col < ncol; ++col) {
-                    for (int g = lane; g < n_groups; g += 64) {
-                        const Group G = groups[g];
-                        if (G.color != col) continue;
-                        solve_group(ac, G.begin, G.end, G.a, G.b == kNoBody ? -1 : (int)G.b, wb, inv_dt, false, prm.plane_mu_s, prm.plane_mu_d);
+                    const int ce = cstart[col + 1];
+                    for (int k = cstart[col] + (lane >> 1); k < ce; k += 32) {   // a lane pair per group
+                        const Group G = groups[order[k]];
+                        solve_group(ac, G.begin, G.end, G.a, G.b == kNoBody ? -1 : (int)G.b, lane & 1, wb, inv_dt, false, prm.plane_mu_s, prm.plane_mu_d);
                     }
                     __syncthreads();
                 }
@@ -1750,6 +1791,10 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
     }
     int resident = kLdsPerCu / fixed;
     if (resident > 8) resident = 8;
+    if (const char* e = getenv("SLHIP_SETTLE_RESIDENT")) {   // developer knob for co-residency experiments
+        const int r = atoi(e);
+        if (r >= 1 && r < resident) resident = r;
+    }
     int share = (kLdsPerCu / kGranule / resident) * kGranule;
     if (share < fixed) share = fixed;
     int hv_cap = (int)params->max_hull_verts_per_scene;

@@ -144,13 +144,16 @@ def test_image_saver_takes_device_tensors(sl, tmp_path):
 
     scene = S.clutter_scene(sl, 5, n_objects=4, size=(160, 120))
     result = sl.RenderPass().render(scene)
-    rgb = result.rgb()
-    inst = result.instance_index()
-    assert rgb.is_cuda
+    rgb = result.rgb().cuda()                    # device tensors, whatever the context's output mode
+    inst = result.instance_index().cuda().reshape(120, 160)
+    assert rgb.is_cuda and rgb.dtype == torch.uint8 and inst.dtype == torch.int16
     with sl.ImageSaver() as saver:
         for i in range(12):
             saver.save(rgb, str(tmp_path / ("rgb%d.png" % i)))
+        saver.save(inst, str(tmp_path / "inst16.png"))
         saver.save(inst.to(torch.uint8), str(tmp_path / "inst.png"))
     for i in range(12):
         assert np.array_equal(np.asarray(Image.open(tmp_path / ("rgb%d.png" % i))), rgb.cpu().numpy())
     assert np.array_equal(np.asarray(Image.open(tmp_path / "inst.png")), inst.to(torch.uint8).cpu().numpy())
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "inst16.png")).astype(np.int16), inst.cpu().numpy())
+    assert inst.max() > 0
