@@ -774,19 +774,35 @@ static void ssao_pass(const float* proj, const float* cam, const float* nrm, int
             normalize3(tg);
             float bt[3] = {n[1] * tg[2] - n[2] * tg[1], n[2] * tg[0] - n[0] * tg[2],
                            n[0] * tg[1] - n[1] * tg[0]};
+            /* The sample position frag + radius * TBN * kernel[k] is linear in the kernel vector, and so is
+               its projection: both are evaluated as fma chains over per-pixel bases (rows 0, 1, 3 of the
+               projection; row 2 is not needed).  The perspective division is one reciprocal shared by x
+               and y, and ((q * 0.5 + 0.5) * W) is a single fma -- GLSL leaves all of this to the compiler. */
+            float tgR[3], btR[3], nR[3];
+            for (int c = 0; c < 3; ++c) { tgR[c] = tg[c] * radius; btR[c] = bt[c] * radius; nR[c] = n[c] * radius; }
+            const float f4[4] = {frag[0], frag[1], frag[2], 1.0f};
+            float A[4], B[3], C[3], D[3];
+            mv4(proj, f4, A);
+            {
+                static const int rows[3] = {0, 1, 3};
+                for (int q = 0; q < 3; ++q) {
+                    const float* m = proj + 4 * rows[q];
+                    B[q] = dot3(m, tgR); C[q] = dot3(m, btR); D[q] = dot3(m, nR);
+                }
+            }
+            const float A3[3] = {A[0], A[1], A[3]};
+            const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
             float occlusion = 0.0f;
             for (int k = 0; k < 64; ++k) {
                 const float* s = &kern[3 * k];
-                float sp[3];
-                for (int c = 0; c < 3; ++c)
-                    sp[c] = frag[c] + (tg[c] * s[0] + bt[c] * s[1] + n[c] * s[2]) * radius;
-                float v4[4] = {sp[0], sp[1], sp[2], 1.0f}, off[4];
-                mv4(proj, v4, off);
-                float ox = (off[0] / off[3]) * 0.5f + 0.5f;
-                float oy = (off[1] / off[3]) * 0.5f + 0.5f;
-                float sd = rect_bilinear(cam, W, H, ox * (float)W, oy * (float)H, 2);
+                const float spz = fmaf(nR[2], s[2], fmaf(btR[2], s[1], fmaf(tgR[2], s[0], frag[2])));
+                float o[3];
+                for (int q = 0; q < 3; ++q) o[q] = fmaf(D[q], s[2], fmaf(C[q], s[1], fmaf(B[q], s[0], A3[q])));
+                const float rw = 1.0f / o[2];
+                const float x = fmaf(o[0] * rw, hw, hw), y = fmaf(o[1] * rw, hh, hh);
+                float sd = rect_bilinear(cam, W, H, x, y, 2);
                 float rc = smoothstep01(radius / fabsf(frag[2] - sd));
-                occlusion += (sd <= sp[2] - bias ? 1.0f : 0.0f) * rc;
+                occlusion += (sd <= spz - bias ? 1.0f : 0.0f) * rc;
             }
             ao[p] = 1.0f - occlusion / 64.0f;
         }

@@ -1446,7 +1446,7 @@ __device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, 
     // `img` is the compact camera-z plane written by k_shade (same values as channel 2 of the
     // camCoordinates target, 4 B/px instead of 16 B/px: the 64-tap gather stays L2 resident)
     // 32-bit offsets from the (wave-uniform) plane base: one scalar base + one VGPR offset per load
-    const unsigned r0 = (unsigned)y0 * (unsigned)W, r1 = (unsigned)y1 * (unsigned)W;
+    const unsigned r0 = __umul24((unsigned)y0, (unsigned)W), r1 = __umul24((unsigned)y1, (unsigned)W);   // both < 2^24
     const float a = img[r0 + (unsigned)x0], b = img[r0 + (unsigned)x1];
     const float c = img[r1 + (unsigned)x0], d = img[r1 + (unsigned)x1];
     const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - c, c);
@@ -1455,7 +1455,8 @@ __device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, 
 
 __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
                                               const float* __restrict__ cam, const float* __restrict__ nrm,
-                                              const float* __restrict__ zplane, float* __restrict__ ao)
+                                              const float* __restrict__ zplane, float* __restrict__ ao,
+                                              const float* __restrict__ kern)
 {
     const size_t P = (size_t)W * H;
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
@@ -1481,22 +1482,33 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
     normalize3(tg);
     const float bt[3] = {n[1] * tg[2] - n[2] * tg[1], n[2] * tg[0] - n[0] * tg[2], n[0] * tg[1] - n[1] * tg[0]};
     const float radius = 0.1f, bias = 0.0025f;
-    float occlusion = 0.0f;
-    for (int k = 0; k < 64; ++k) {
-        const float* s = &c_ssao_kernel[3 * k];
-        float sp[3];
+    // The sample position and its projection are linear in the kernel vector: per-pixel bases, then
+    // four 3-fma chains per tap (rows 0, 1, 3 of the projection + the sample's z); one reciprocal
+    // serves both perspective divisions -- the oracle's ssao_pass spells out the same arithmetic.
+    float tgR[3], btR[3], nR[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) sp[c] = frag[c] + (tg[c] * s[0] + bt[c] * s[1] + n[c] * s[2]) * radius;
-        const float v4[4] = {sp[0], sp[1], sp[2], 1.0f};
-        float off[4];
-        mv4(proj, v4, off);
-        const float ox = (off[0] / off[3]) * 0.5f + 0.5f;
-        const float oy = (off[1] / off[3]) * 0.5f + 0.5f;
-        const float sd = rect_bilinear_z(camS, W, H, ox * (float)W, oy * (float)H);
+    for (int c = 0; c < 3; ++c) { tgR[c] = tg[c] * radius; btR[c] = bt[c] * radius; nR[c] = n[c] * radius; }
+    const float fr4[4] = {frag[0], frag[1], frag[2], 1.0f};
+    float A[4];
+    mv4(proj, fr4, A);
+    const float B0 = dot3(proj, tgR), C0 = dot3(proj, btR), D0 = dot3(proj, nR);
+    const float B1 = dot3(proj + 4, tgR), C1 = dot3(proj + 4, btR), D1 = dot3(proj + 4, nR);
+    const float B3 = dot3(proj + 12, tgR), C3 = dot3(proj + 12, btR), D3 = dot3(proj + 12, nR);
+    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    float occlusion = 0.0f;
+#pragma unroll 4
+    for (int k = 0; k < 64; ++k) {
+        const float s0 = kern[3 * k], s1 = kern[3 * k + 1], s2 = kern[3 * k + 2];
+        const float spz = fmaf(nR[2], s2, fmaf(btR[2], s1, fmaf(tgR[2], s0, frag[2])));
+        const float o0 = fmaf(D0, s2, fmaf(C0, s1, fmaf(B0, s0, A[0])));
+        const float o1 = fmaf(D1, s2, fmaf(C1, s1, fmaf(B1, s0, A[1])));
+        const float o3 = fmaf(D3, s2, fmaf(C3, s1, fmaf(B3, s0, A[3])));
+        const float rw = 1.0f / o3;
+        const float sd = rect_bilinear_z(camS, W, H, fmaf(o0 * rw, hw, hw), fmaf(o1 * rw, hh, hh));
         // range check smoothstep(clamp(radius / |dz|)): exactly 1 whenever |dz| <= radius, and
         // irrelevant for taps that do not occlude -- the division runs only where it matters
         // (on open surfaces whole waves skip it)
-        const bool occludes = sd <= sp[2] - bias;
+        const bool occludes = sd <= spz - bias;
         const float adz = fabsf(frag[2] - sd);
         float rc = 1.0f;
         if (occludes && adz > radius) {
@@ -1813,7 +1825,10 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
         if (ssao) {
             mark(5, stream);
             const float* zpl = scratch->d_ao + (size_t)n_scenes * P;   // second half of d_ao
-            k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, out->d_cam_coord, out->d_normals, zpl, scratch->d_ao);
+            const float* d_kernel_table = nullptr;   // the table's device address as a plain kernel argument
+            SLHIP_CHECK(hipGetSymbolAddress((void**)&d_kernel_table, HIP_SYMBOL(c_ssao_kernel)));
+            k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, out->d_cam_coord, out->d_normals, zpl, scratch->d_ao,
+                                                   d_kernel_table);
             mark(6, stream);
             k_ssao_apply<<<pix_blocks, 256, 0, stream>>>(n_scenes, W, H, hdr0, scratch->d_ao, zpl, hdr1);
             tm_in = hdr1;
