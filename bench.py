@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--settle-streams", type=int, default=3,
                     help="settle launches kept in flight: scenes settle in very different times, and a second "
                          "launch on its own stream back-fills the CUs the tail of the first one leaves idle")
+    ap.add_argument("--settle-cus", type=int, default=0,
+                    help="compute units reserved for the settle streams; the render stream gets the rest (0 = share all CUs)")
     ap.add_argument("--no-ssao", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes per host thread of the bounded CPU-baseline sample")
@@ -62,7 +64,7 @@ def make_scene(sl, meshes, seed):
 
 
 class Pipeline:
-    def __init__(self, sl, batch, ssao):
+    def __init__(self, sl, batch, ssao, settle_cus=0, settle_streams=1):
         from stillleben_amd import _abi, physics
         from stillleben_amd._context import engine
 
@@ -73,8 +75,15 @@ class Pipeline:
         self.ssao = ssao
         self.mask = _abi.OUT_GT6
         self.buffers = []
-        self.s_settle = [torch.cuda.Stream(device=self.eng.device)]
-        self.s_render = torch.cuda.Stream(device=self.eng.device)
+        if settle_cus > 0:
+            # the two halves get disjoint CU ranges: settle workgroups hold their CU slots for ~100 ms, and
+            # short render workgroups sharing those CUs fragment both
+            from stillleben_amd.parallel import cu_partition_streams
+
+            self.s_settle, self.s_render = cu_partition_streams(settle_cus, settle_streams, self.eng.device)
+        else:
+            self.s_settle = [torch.cuda.Stream(device=self.eng.device)]
+            self.s_render = torch.cuda.Stream(device=self.eng.device)
         self.render_chunk = 128
         self.gatherer = None      # N > 1: BatchGatherer, one asynchronous RCCL all-gather per rendered chunk
         self.pending = {}         # chunk slot -> outstanding collectives reading that slot's render buffers
@@ -262,7 +271,7 @@ def main():
 
     sl.init_cuda(local_rank)
     meshes = synthetic.ycb_like_meshes(seed=0)
-    pipe = Pipeline(sl, args.batch, not args.no_ssao)
+    pipe = Pipeline(sl, args.batch, not args.no_ssao, args.settle_cus, max(1, args.settle_streams))
     pipe.params = SB.default_params(tabletop=True)
     pipe.render_chunk = args.render_chunk
     pipe.eng.L.slhip_timing_enable(1)
@@ -328,6 +337,12 @@ def main():
     for it in items[args.warmup:]:
         pipe.t_render.append(sum(a.elapsed_time(b) for a, b in it["render_events"]))
         pipe.t_settle.append(it["ev0"].elapsed_time(it["ev1"]))
+    if rank == 0 and os.environ.get("SLHIP_BENCH_TRACE"):
+        ref = items[args.warmup]["ev0"]
+        for k, it in enumerate(items[args.warmup:]):
+            print("[trace] step %d: settle %.0f..%.0f ms, render %.0f..%.0f ms" % (
+                k, ref.elapsed_time(it["ev0"]), ref.elapsed_time(it["ev1"]),
+                ref.elapsed_time(it["render_events"][0][0]), ref.elapsed_time(it["render_events"][-1][1])), file=sys.stderr)
         pipe.t_step_host.append(it["t_post"])
     pipe.phase_ms.append(np.array(list(ms_all)) / max(1, args.steps))
     # the render kernels overlap with the next batch's settle inside the timed region, which

@@ -429,6 +429,17 @@ const char* slhip_last_error(void);
  * device selection (reference src/context.cpp:411-560).                                      */
 int slhip_device_init(int device_index);
 
+/* Streams confined to a range of compute units of the current device (additive: the reference has
+ * one GL context per process and nothing to partition).  A data-generation loop runs the settle of
+ * batch k+1 and the render of batch k at the same time; the two halves have opposite resource
+ * shapes (settle: 256 VGPRs + 20 KiB LDS per single-wave workgroup held for ~100 ms; render: short
+ * 256-thread workgroups), and sharing CUs between them fragments both.  Giving each half its own CU
+ * range removes the interference.  Consecutive CUs of the mask order are dealt round-robin over
+ * the XCDs, so a contiguous range takes the same share of every XCD.  `*stream_out` is a
+ * hipStream_t usable as the `stream` argument of every call above.                              */
+int slhip_stream_create_cu_range(uint32_t first_cu, uint32_t n_cus, void** stream_out);
+int slhip_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,6 +223,8 @@ def lib():
     L.slhip_light_map_floats.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint64 * 4)]
     L.slhip_light_map_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.slhip_camera_model.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.slhip_stream_create_cu_range.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.slhip_stream_destroy.argtypes = [C.c_void_p]
     _LIB = L
     return L
 

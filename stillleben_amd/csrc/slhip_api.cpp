@@ -43,3 +43,39 @@ extern "C" int slhip_device_init(int device_index)
     }
     return 0;
 }
+
+// A stream whose kernels run only on CUs [first_cu, first_cu + n_cus) of the current device's CU mask
+// order (the driver deals consecutive mask bits round-robin over the XCDs and shader engines, so a
+// contiguous range takes the same share of every XCD).
+extern "C" int slhip_stream_create_cu_range(uint32_t first_cu, uint32_t n_cus, void** stream_out)
+{
+    if (!stream_out || n_cus == 0) {
+        slhip::set_error("slhip_stream_create_cu_range: null output or empty range");
+        return -1;
+    }
+    int dev = 0;
+    SLHIP_CHECK(hipGetDevice(&dev));
+    int total = 0;
+    SLHIP_CHECK(hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev));
+    if (first_cu + n_cus > (uint32_t)total) {
+        slhip::set_error("slhip_stream_create_cu_range: CUs [%u, %u) exceed the device's %d", first_cu, first_cu + n_cus, total);
+        return -1;
+    }
+    uint32_t mask[32] = {0};
+    const uint32_t words = ((uint32_t)total + 31u) / 32u;
+    if (words > 32u) {
+        slhip::set_error("slhip_stream_create_cu_range: %d CUs exceed the mask buffer", total);
+        return -1;
+    }
+    for (uint32_t c = first_cu; c < first_cu + n_cus; ++c) mask[c / 32u] |= 1u << (c % 32u);
+    hipStream_t st = nullptr;
+    SLHIP_CHECK(hipExtStreamCreateWithCUMask(&st, words, mask));
+    *stream_out = (void*)st;
+    return 0;
+}
+
+extern "C" int slhip_stream_destroy(void* stream)
+{
+    if (stream) SLHIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}

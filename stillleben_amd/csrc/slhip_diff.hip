@@ -75,10 +75,10 @@ __device__ __forceinline__ void pixel_gradients(const uint8_t* __restrict__ rgb,
     const size_t p = (size_t)h * W + w;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float l = w > 0 ? (float)rgb[4 * (p - 1) + c] / 255.0f : 0.0f;
-        const float r = w < W - 1 ? (float)rgb[4 * (p + 1) + c] / 255.0f : 0.0f;
-        const float u = h > 0 ? (float)rgb[4 * (p - W) + c] / 255.0f : 0.0f;
-        const float d = h < H - 1 ? (float)rgb[4 * (p + W) + c] / 255.0f : 0.0f;
+        const float l = w > 0 ? slhip::unorm8(rgb[4 * (p - 1) + c]) : 0.0f;
+        const float r = w < W - 1 ? slhip::unorm8(rgb[4 * (p + 1) + c]) : 0.0f;
+        const float u = h > 0 ? slhip::unorm8(rgb[4 * (p - W) + c]) : 0.0f;
+        const float d = h < H - 1 ? slhip::unorm8(rgb[4 * (p + W) + c]) : 0.0f;
         gx[c] = -((r - l) * sx);
         gy[c] = -((d - u) * sy);
     }

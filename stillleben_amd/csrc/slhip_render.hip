@@ -380,7 +380,7 @@ __device__ __forceinline__ int wrap_coord(int i, int n, unsigned mode)
 __device__ __forceinline__ void texel_rgba(const uint8_t* __restrict__ lvl, int w, int x, int y, float* out)
 {
     const uchar4 t = reinterpret_cast<const uchar4*>(lvl)[(size_t)y * w + x];
-    out[0] = (float)t.x / 255.0f; out[1] = (float)t.y / 255.0f; out[2] = (float)t.z / 255.0f; out[3] = (float)t.w / 255.0f;
+    out[0] = slhip::unorm8(t.x); out[1] = slhip::unorm8(t.y); out[2] = slhip::unorm8(t.z); out[3] = slhip::unorm8(t.w);
 }
 
 // one level, nearest or bilinear
@@ -515,8 +515,8 @@ __device__ __forceinline__ void tex_rect_bilinear(const uint8_t* __restrict__ te
     const unsigned char c01[4] = {t01.x, t01.y, t01.z, t01.w}, c11[4] = {t11.x, t11.y, t11.z, t11.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float a = (float)c00[c] / 255.0f, b = (float)c10[c] / 255.0f;
-        const float cc = (float)c01[c] / 255.0f, d = (float)c11[c] / 255.0f;
+        const float a = slhip::unorm8(c00[c]), b = slhip::unorm8(c10[c]);
+        const float cc = slhip::unorm8(c01[c]), d = slhip::unorm8(c11[c]);
         const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - cc, cc);
         out[c] = fmaf(ay, bot - top, top);
     }

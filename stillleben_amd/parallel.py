@@ -16,6 +16,31 @@ def shard_scenes(n_scenes, rank, world):
     return list(range(rank, n_scenes, world))
 
 
+def cu_partition_streams(settle_cus, n_settle_streams=1, device=None):
+    """Streams for a generation loop that settles batch k+1 while it renders batch k: `n_settle_streams`
+    streams confined to the first `settle_cus` compute units and one render stream confined to the rest
+    (slhip_stream_create_cu_range, include/slhip.h).  Returns (settle_streams, render_stream) as
+    torch ExternalStreams; the caller keeps them alive."""
+    import ctypes as C
+
+    from . import _abi
+
+    L = _abi.lib()
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    total = torch.cuda.get_device_properties(dev).multi_processor_count
+    if not 0 < settle_cus < total:
+        raise ValueError("settle_cus must be in (0, %d)" % total)
+
+    def make(first, count):
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            _abi.check(L.slhip_stream_create_cu_range(first, count, C.byref(h)), "slhip_stream_create_cu_range")
+        return torch.cuda.ExternalStream(h.value, device=dev)
+
+    settle = [make(0, settle_cus) for _ in range(max(1, n_settle_streams))]
+    return settle, make(settle_cus, total - settle_cus)
+
+
 class BatchGatherer:
     """all_gather_into_tensor of a list of per-rank tensors into a small ring of persistent
     [world, ...] staging buffers (`depth` sets per distinct shape signature).

@@ -160,3 +160,30 @@ def test_ssao_tables_match_generator(oracle):
     # kernel samples live in the +z hemisphere with length <= 1
     k = k2.reshape(64, 3)
     assert np.all(k[:, 2] >= 0) and np.all(np.linalg.norm(k, axis=1) <= 1.0)
+
+
+def test_unorm8_shortcut_is_exact():
+    """The kernels convert texture bytes with q = x * (1/255); q' = fma(fma(-q, 255, x), 1/255, q) instead of
+    the IEEE division the oracle writes ((float)x / 255.0f, render_ref.c / diff_ref.c).  Checked here for all
+    256 bytes with exactly rounded fma emulation (rational arithmetic, round to nearest even)."""
+    from fractions import Fraction
+
+    def rn32(fr):
+        c = np.float32(float(fr))
+        best = None
+        for cand in (np.nextafter(c, np.float32(-np.inf)), c, np.nextafter(c, np.float32(np.inf))):
+            err = abs(Fraction(float(cand)) - fr)
+            even = (int(np.float32(cand).view(np.uint32)) & 1) == 0
+            if best is None or err < best[0] or (err == best[0] and even and not best[2]):
+                best = (err, cand, even)
+        return np.float32(best[1])
+
+    def fma(a, b, c):
+        return rn32(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+
+    c = np.float32(1.0) / np.float32(255.0)
+    for x in range(256):
+        xf = np.float32(x)
+        q = xf * c
+        fast = fma(fma(-q, np.float32(255.0), xf), c, q)
+        assert fast == xf / np.float32(255.0), x

@@ -28,8 +28,20 @@ scr = se.scratch(B, torch.cuda.current_stream().cuda_stream)
 scr.zero_()
 d = se.eng.upload_records(bodies)
 torch.cuda.synchronize()
+stream = torch.cuda.current_stream()
+if os.environ.get("SLHIP_SETTLE_CUS"):   # confine the launch to a CU range: "first,count"
+    import ctypes as C
+    from stillleben_amd import _abi
+    first, count = [int(v) for v in os.environ["SLHIP_SETTLE_CUS"].split(",")]
+    h = C.c_void_p()
+    _abi.check(_abi.lib().slhip_stream_create_cu_range(first, count, C.byref(h)), "slhip_stream_create_cu_range")
+    stream = torch.cuda.ExternalStream(h.value)
+    scr = se.scratch(B, stream.cuda_stream)
+    scr.zero_()
+    torch.cuda.synchronize()
 t = time.perf_counter()
-se.run_device(srec, None, prm, d_bodies=d)
+with torch.cuda.stream(stream):
+    se.run_device(srec, None, prm, d_bodies=d)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
 print("B=%d frames=%d: %.1f ms  (%.3f ms per scene-step-batch, %.0f scene-steps/s)" % (B, FRAMES, dt * 1e3, dt * 1e3 / (FRAMES * 4), B * FRAMES * 4 / dt))
@@ -48,3 +60,21 @@ if os.environ.get("SLHIP_SETTLE_PROFILE"):
         print("  %-18s %8.2f us/step" % (n, tot[i] / steps / 100.0))
     print("  total %.2f us/step" % (tot[:12].sum() / steps / 100.0))
     print("  avg hull pairs %.1f, active contacts %.1f, groups %.1f, colours %.1f" % tuple(cnt[:4] / steps))
+if os.environ.get("SLHIP_SETTLE_PROFILE"):
+    # per-scene cost against a-priori features (for longest-first launch order)
+    per_scene = np.array([np.frombuffer(sc[b * 256:b * 256 + 128].tobytes(), dtype=np.uint64).astype(np.float64)[:12].sum() for b in range(B)])
+    hulls_a = se.pool.arrays()[0]
+    cnt = hulls_a["vtx_count"].astype(np.int64)
+    csum = np.concatenate([[0], np.cumsum(cnt)])
+    pbv = csum[bodies["hull_end"]] - csum[bodies["hull_begin"]]
+    pbh = bodies["hull_end"].astype(np.int64) - bodies["hull_begin"].astype(np.int64)
+    b0, b1 = srec["body_begin"].astype(np.int64), srec["body_end"].astype(np.int64)
+    bh = np.concatenate([[0], np.cumsum(pbh)]); bv = np.concatenate([[0], np.cumsum(pbv)])
+    sh, sv = (bh[b1] - bh[b0]).astype(np.float64), (bv[b1] - bv[b0]).astype(np.float64)
+    sh2 = np.array([np.sum(pbh[a:b].astype(np.float64) ** 2) for a, b in zip(b0, b1)])
+    print("  per-scene cost: mean %.1f ms max %.1f ms min %.1f ms" % (per_scene.mean() / 1e5, per_scene.max() / 1e5, per_scene.min() / 1e5))
+    for name, f in (("hulls", sh), ("hull verts", sv), ("sum hulls^2", sh2)):
+        print("  corr(cost, %s) = %.3f" % (name, np.corrcoef(per_scene, f)[0, 1]))
+    order = np.argsort(-sh2)
+    top = set(np.argsort(-per_scene)[:B // 8].tolist())
+    print("  of the heaviest 1/8 of the scenes, %.0f%% are in the first quarter of the sum-hulls^2 order" % (100.0 * len(top & set(order[:B // 4].tolist())) / len(top)))
