@@ -165,7 +165,14 @@ typedef struct {
     v3 t;
 } shape;
 
-static inline v3 support(const shape* s, v3 d)
+static inline v3 shape_vertex(const shape* s, int i)
+{
+    v3 p = V(s->verts[4 * i], s->verts[4 * i + 1], s->verts[4 * i + 2]);
+    return add(m3_mul(&s->R, p), s->t);
+}
+
+/* support point along d; *index receives the vertex number (first maximum) */
+static inline v3 support_i(const shape* s, v3 d, int* index)
 {
     v3 dl = m3_tmul(&s->R, d);
     int best = 0;
@@ -174,11 +181,24 @@ static inline v3 support(const shape* s, v3 d)
         float dd = dot(V(s->verts[4 * i], s->verts[4 * i + 1], s->verts[4 * i + 2]), dl);
         if (dd > bd) { bd = dd; best = i; }
     }
-    v3 p = V(s->verts[4 * best], s->verts[4 * best + 1], s->verts[4 * best + 2]);
-    return add(m3_mul(&s->R, p), s->t);
+    *index = best;
+    return shape_vertex(s, best);
 }
 
-typedef struct { v3 w, a, b; } sv; /* simplex vertex: w = a - b */
+static inline v3 support(const shape* s, v3 d)
+{
+    int unused;
+    return support_i(s, d, &unused);
+}
+
+/* simplex vertex: w = a - b; idx = vertex of A | vertex of B << 16 (hulls have < 65536 vertices) */
+typedef struct { v3 w, a, b; int idx; } sv;
+
+/* The vertices of a converged simplex.  The tilted runs of the perturbation manifold start from the
+   main run's simplex (same vertex numbers, re-evaluated in the tilted pose) instead of from scratch:
+   the tilt is small, so the closest features are the same or adjacent ones and the run converges
+   in 2-3 iterations instead of 6-7. */
+typedef struct { int n; int idx[3]; } gjk_seed;
 
 /* closest point to the origin on segment / triangle; returns barycentric weights and the mask
    of vertices that stay in the simplex (Ericson, Real-Time Collision Detection 5.1.2/5.1.5) */
@@ -293,7 +313,8 @@ static int reduce_simplex(sv* s, int n, float* lam, v3* v)
    for any direction v, min over the Minkowski difference of v.x = v.w bounds the distance from
    below by v.w/|v|). */
 #define GJK_MAX_ITER 32
-static int gjk_distance(const shape* A, const shape* B, v3 init_dir, float margin, v3* pa, v3* pb, float* dist)
+static int gjk_distance_seeded(const shape* A, const shape* B, v3 init_dir, float margin, v3* pa, v3* pb, float* dist,
+                               const gjk_seed* seed_in, gjk_seed* seed_out)
 {
     sv s[4];
     float lam[4] = {1, 0, 0, 0};
@@ -302,10 +323,24 @@ static int gjk_distance(const shape* A, const shape* B, v3 init_dir, float margi
     if (dot(v, v) < 1e-12f) v = V(1, 0, 0);
     float vv = dot(v, v);
     const float m2 = margin * margin;
+    if (seed_out) seed_out->n = 0;
+    if (seed_in && seed_in->n > 0) {
+        for (int k = 0; k < seed_in->n; ++k) {
+            s[k].idx = seed_in->idx[k];
+            s[k].a = shape_vertex(A, seed_in->idx[k] & 0xffff);
+            s[k].b = shape_vertex(B, (int)((unsigned)seed_in->idx[k] >> 16));
+            s[k].w = sub(s[k].a, s[k].b);
+        }
+        n = reduce_simplex(s, seed_in->n, lam, &v); /* <= 3 vertices: never 0 */
+        vv = dot(v, v);
+        if (vv < 1e-12f) return 0;
+    }
     for (int it = 0; it < GJK_MAX_ITER; ++it) {
         sv w;
-        w.a = support(A, neg(v));
-        w.b = support(B, v);
+        int ia, ib;
+        w.a = support_i(A, neg(v), &ia);
+        w.b = support_i(B, v, &ib);
+        w.idx = ia | (ib << 16);
         w.w = sub(w.a, w.b);
         float vw = dot(v, w.w);
         if (vw > 0.0f && vw * vw > m2 * vv) return 2;
@@ -332,9 +367,18 @@ static int gjk_distance(const shape* A, const shape* B, v3 init_dir, float margi
     v3 a = V(0, 0, 0), b = V(0, 0, 0);
     for (int i = 0; i < n; ++i) { a = madd(a, s[i].a, lam[i]); b = madd(b, s[i].b, lam[i]); }
     *pa = a; *pb = b;
+    if (seed_out) {
+        seed_out->n = n;   /* 1..3 after reduce_simplex */
+        for (int i = 0; i < n; ++i) seed_out->idx[i] = s[i].idx;
+    }
     float d = sqrtf(vv);
     *dist = d;
     return d > 1e-6f ? 1 : 0;
+}
+
+static int gjk_distance(const shape* A, const shape* B, v3 init_dir, float margin, v3* pa, v3* pb, float* dist)
+{
+    return gjk_distance_seeded(A, B, init_dir, margin, pa, pb, dist, NULL, NULL);
 }
 
 /* tangent basis (deterministic) */
@@ -446,7 +490,8 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     float mu_s = 0.5f * (bodies[ia].mu_s + bodies[ib].mu_s);
     float mu_d = 0.5f * (bodies[ia].mu_d + bodies[ib].mu_d);
     float e = 0.5f * (bodies[ia].restitution + bodies[ib].restitution);
-    int code = gjk_distance(&A, &B, sub(ca, cb), margin, &pa, &pb, &dist);
+    gjk_seed seed;
+    int code = gjk_distance_seeded(&A, &B, sub(ca, cb), margin, &pa, &pb, &dist, NULL, &seed);
     if (code == 2) return 3.0e38f;
     if (code == 0) {
         float sep;
@@ -489,8 +534,8 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
         T.t = sub(cw, m3_mul(&T.R, cl));
         v3 qa, qb;
         float d2;
-        int ok = tilt_a ? gjk_distance(&T, &B, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2)
-                        : gjk_distance(&A, &T, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2);
+        int ok = tilt_a ? gjk_distance_seeded(&T, &B, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, &seed, NULL)
+                        : gjk_distance_seeded(&A, &T, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, &seed, NULL);
         if (ok != 1) continue;
         /* map the witness on the tilted shape back to the untilted pose */
         if (tilt_a) {

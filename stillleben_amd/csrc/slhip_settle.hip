@@ -160,7 +160,17 @@ struct Shape {
 // that the (LDS or L1) latency of the batch overlaps; the compare chain stays in index order.
 struct f3 { float x, y, z; };   // 12-byte LDS vertex
 
-__device__ __forceinline__ v3 support(const Shape& s, const f3* __restrict__ hv, v3 d)
+__device__ __forceinline__ v3 shape_vertex(const Shape& s, const f3* __restrict__ hv, int i)
+{
+    if (s.lds >= 0) {
+        const f3 q = hv[s.lds + i];
+        return add(m3_mul(s.R, V(q.x, q.y, q.z)), s.t);
+    }
+    const float4 q = s.g[i];
+    return add(m3_mul(s.R, V(q.x, q.y, q.z)), s.t);
+}
+
+__device__ __forceinline__ v3 support(const Shape& s, const f3* __restrict__ hv, v3 d, int& index)
 {
     const v3 dl = m3_tmul(s.R, d);
     int best = 0;
@@ -182,6 +192,7 @@ __device__ __forceinline__ v3 support(const Shape& s, const f3* __restrict__ hv,
             }
         }
         const f3 q = v[best];
+        index = best;
         return add(m3_mul(s.R, V(q.x, q.y, q.z)), s.t);
     }
     for (int base = 0; base < n; base += 8) {
@@ -195,10 +206,21 @@ __device__ __forceinline__ v3 support(const Shape& s, const f3* __restrict__ hv,
         }
     }
     const float4 q = s.g[best];
+    index = best;
     return add(m3_mul(s.R, V(q.x, q.y, q.z)), s.t);
 }
 
-struct SV { v3 w, a, b; };
+__device__ __forceinline__ v3 support(const Shape& s, const f3* __restrict__ hv, v3 d)
+{
+    int unused;
+    return support(s, hv, d, unused);
+}
+
+// simplex vertex: w = a - b; idx = vertex of A | vertex of B << 16
+struct SV { v3 w, a, b; int idx; };
+
+// vertices of a converged simplex: the tilted runs start from the main run's simplex (oracle gjk_seed)
+struct GjkSeed { int n; int i0, i1, i2; };
 
 __device__ __forceinline__ int closest_segment(const SV* s, float* l)
 {
@@ -343,8 +365,18 @@ __device__ __forceinline__ bool same_w(const SV& a, const SV& b)
 }
 
 // returns 1 (separated, witnesses valid), 0 (touching / overlapping), 2 (farther than margin)
+__device__ __forceinline__ SV seed_vertex(const Shape& A, const Shape& B, const f3* __restrict__ hv, int idx)
+{
+    SV p;
+    p.idx = idx;
+    p.a = shape_vertex(A, hv, idx & 0xffff);
+    p.b = shape_vertex(B, hv, (int)((unsigned)idx >> 16));
+    p.w = sub(p.a, p.b);
+    return p;
+}
+
 __device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict__ hv, v3 init_dir, float margin,
-                            v3* pa, v3* pb, float* dist)
+                            v3* pa, v3* pb, float* dist, const GjkSeed seed_in, GjkSeed* seed_out)
 {
     Simplex S;
     S.n = 0;
@@ -353,10 +385,21 @@ __device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict
     if (dot(v, v) < 1e-12f) v = V(1, 0, 0);
     float vv = dot(v, v);
     const float m2 = margin * margin;
+    if (seed_in.n > 0) {
+        S.p0 = seed_vertex(A, B, hv, seed_in.i0);
+        if (seed_in.n > 1) S.p1 = seed_vertex(A, B, hv, seed_in.i1);
+        if (seed_in.n > 2) S.p2 = seed_vertex(A, B, hv, seed_in.i2);
+        S.n = seed_in.n;
+        reduce_simplex(S, &v);      // at most a triangle: never 0
+        vv = dot(v, v);
+        if (vv < 1e-12f) return 0;
+    }
     for (int it = 0; it < kGjkMaxIter; ++it) {
         SV w;
-        w.a = support(A, hv, neg(v));
-        w.b = support(B, hv, v);
+        int ia, ib;
+        w.a = support(A, hv, neg(v), ia);
+        w.b = support(B, hv, v, ib);
+        w.idx = ia | (ib << 16);
         w.w = sub(w.a, w.b);
         const float vw = dot(v, w.w);
         if (vw > 0.0f && vw * vw > m2 * vv) return 2;
@@ -384,9 +427,18 @@ __device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict
     if (S.n > 1) { a = madd(a, S.p1.a, S.l1); b = madd(b, S.p1.b, S.l1); }
     if (S.n > 2) { a = madd(a, S.p2.a, S.l2); b = madd(b, S.p2.b, S.l2); }
     *pa = a; *pb = b;
+    if (seed_out) { seed_out->n = S.n; seed_out->i0 = S.p0.idx; seed_out->i1 = S.p1.idx; seed_out->i2 = S.p2.idx; }
     const float d = sqrtf(vv);
     *dist = d;
     return d > 1e-6f ? 1 : 0;
+}
+
+__device__ __forceinline__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict__ hv, v3 init_dir, float margin,
+                                            v3* pa, v3* pb, float* dist)
+{
+    GjkSeed none;
+    none.n = 0; none.i0 = none.i1 = none.i2 = 0;
+    return gjk_distance(A, B, hv, init_dir, margin, pa, pb, dist, none, nullptr);
 }
 
 __device__ __forceinline__ v3 tangent_axis(v3 n)
@@ -566,6 +618,7 @@ struct MainResult {       // stage 1: plain GJK
     int type;             // 0 none, 1 contact pair (tilt runs follow), 2 overlap (single fallback contact)
     v3 n, pa, pb;
     float dist;           // distance (type 1) or fallback separation (type 2)
+    GjkSeed seed;         // type 1: the converged simplex, start of the tilt runs
 };
 
 __device__ void pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
@@ -579,7 +632,10 @@ __device__ void pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, c
     const v3 cb = add(m3_mul(wb.R, hb.sc), wb.t);
     v3 pa, pb, n;
     float dist;
-    const int code = gjk_distance(A, B, hv, sub(ca, cb), margin, &pa, &pb, &dist);
+    GjkSeed none;
+    none.n = 0; none.i0 = none.i1 = none.i2 = 0;
+    r.seed = none;
+    const int code = gjk_distance(A, B, hv, sub(ca, cb), margin, &pa, &pb, &dist, none, &r.seed);
     if (code == 2) return;
     if (code == 0) {
         float sep;
@@ -597,7 +653,7 @@ __device__ void pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, c
 // stage 2: tilt run k (0..3) of a contact pair -> candidate (qa, qb, sp); returns false if rejected
 // before the duplicate test
 __device__ bool pair_tilt(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
-                          const f3* __restrict__ hv, const float4* __restrict__ gv, const slhip_settle_params& prm, float margin, v3 n, int k, v3* qa_out,
+                          const f3* __restrict__ hv, const float4* __restrict__ gv, const slhip_settle_params& prm, float margin, v3 n, const GjkSeed seed, int k, v3* qa_out,
                           v3* qb_out, float* sp_out)
 {
     Shape A, B;
@@ -626,8 +682,8 @@ __device__ bool pair_tilt(const WBody& wa, const WBody& wb, const HullRef& ha, c
     T.t = sub(cw, m3_mul(T.R, cl));
     v3 qa, qb;
     float d2;
-    const int ok = tilt_a ? gjk_distance(T, B, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2)
-                          : gjk_distance(A, T, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2);
+    const int ok = tilt_a ? gjk_distance(T, B, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, nullptr)
+                          : gjk_distance(A, T, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, nullptr);
     if (ok != 1) return false;
     if (tilt_a) {
         const v3 loc = m3_tmul(T.R, sub(qa, T.t));
@@ -1405,6 +1461,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 MainResult mr;
                 mr.type = 0; mr.dist = 0.0f;
                 mr.n = V(0, 0, 0); mr.pa = V(0, 0, 0); mr.pb = V(0, 0, 0);
+                mr.seed.n = 0; mr.seed.i0 = mr.seed.i1 = mr.seed.i2 = 0;
                 if (k < n_hp) {
                     const unsigned e = hp[k];
                     const int ba = hp_ba(e), bb = hp_bb(e);
@@ -1427,6 +1484,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     mm.pa = V(__shfl(mr.pa.x, src, 64), __shfl(mr.pa.y, src, 64), __shfl(mr.pa.z, src, 64));
                     mm.pb = V(__shfl(mr.pb.x, src, 64), __shfl(mr.pb.y, src, 64), __shfl(mr.pb.z, src, 64));
                     mm.dist = __shfl(mr.dist, src, 64);
+                    mm.seed.n = __shfl(mr.seed.n, src, 64);
+                    mm.seed.i0 = __shfl(mr.seed.i0, src, 64); mm.seed.i1 = __shfl(mr.seed.i1, src, 64);
+                    mm.seed.i2 = __shfl(mr.seed.i2, src, 64);
                     const int kk = base + src;   // hull pair of this item
                     bool have = false;
                     v3 qa = V(0, 0, 0), qb = V(0, 0, 0);
@@ -1441,7 +1501,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         const HullRef& ha = lh[body_lh[bi] + hp_ha(e)];
                         const HullRef& hb = lh[body_lh[bj] + hp_hb(e)];
                         radius = ha.sr <= hb.sr ? ha.sr : hb.sr;
-                        if (mm.type == 1) have = pair_tilt(wb[bi], wb[bj], ha, hb, hv, gv, prm, margin, mm.n, t, &qa, &qb, &sp);
+                        if (mm.type == 1) have = pair_tilt(wb[bi], wb[bj], ha, hb, hv, gv, prm, margin, mm.n, mm.seed, t, &qa, &qb, &sp);
                     }
                     // gather the four candidates of a pair into its tilt-0 lane
                     Cand5 c;
