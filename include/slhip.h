@@ -321,6 +321,7 @@ typedef struct {
 /* per-scene scratch (device), sized by slhip_settle_scratch_bytes */
 #define SLHIP_MAX_BODIES     64   /* bodies per scene                                          */
 #define SLHIP_MAX_HULL_PAIRS 512  /* candidate hull pairs per scene and step                   */
+#define SLHIP_PAIR_CACHE_MAX_HULLS 256 /* scenes with more convex hulls settle without the pair cache */
 #define SLHIP_MAX_ACTIVE_CONTACTS 160 /* solver contacts per scene and step: plane contacts first,
                                          then hull-pair contacts in pair order; later ones are dropped */
 
@@ -333,7 +334,9 @@ int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
                  slhip_body* d_bodies, const slhip_hull* d_hulls, const float* d_hull_verts,
                  const slhip_settle_params* params, void* d_scratch, uint64_t scratch_bytes,
                  void* stream);
-int slhip_settle_scratch_bytes(uint32_t n_scenes, uint64_t* bytes_out);
+/* scratch for n_scenes scenes: accumulators + the per-scene pair cache, sized from the hints in
+ * `params` (NULL or zero hints: the worst case, SLHIP_PAIR_CACHE_MAX_HULLS^2 entries per scene)   */
+int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out);
 
 /* Boolean any-overlap query per body against all OTHER bodies of its scene (and the plane if
  * present): d_flags[body] = 1 if it collides.  Replaces Scene::isObjectColliding /

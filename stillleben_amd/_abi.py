@@ -218,7 +218,7 @@ def lib():
     L.slhip_diff_vertex_backward.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     L.slhip_settle.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint64, C.c_void_p]
-    L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.POINTER(C.c_uint64)]
+    L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
     L.slhip_overlap_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.slhip_light_map_floats.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint64 * 4)]
     L.slhip_light_map_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

@@ -221,6 +221,7 @@ struct SV { v3 w, a, b; int idx; };
 
 // vertices of a converged simplex: the tilted runs start from the main run's simplex (oracle gjk_seed)
 struct GjkSeed { int n; int i0, i1, i2; };
+static_assert(sizeof(GjkSeed) == 16, "GjkSeed is stored as one int4");
 
 __device__ __forceinline__ int closest_segment(const SV* s, float* l)
 {
@@ -402,7 +403,14 @@ __device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict
         w.idx = ia | (ib << 16);
         w.w = sub(w.a, w.b);
         const float vw = dot(v, w.w);
-        if (vw > 0.0f && vw * vw > m2 * vv) return 2;
+        if (vw > 0.0f && vw * vw > m2 * vv) {
+            // separated beyond the margin: hand the simplex back too (the pair cache restarts from it)
+            if (seed_out) {
+                if (S.n == 0) { seed_out->n = 1; seed_out->i0 = w.idx; seed_out->i1 = 0; seed_out->i2 = 0; }
+                else { seed_out->n = S.n; seed_out->i0 = S.p0.idx; seed_out->i1 = S.p1.idx; seed_out->i2 = S.p2.idx; }
+            }
+            return 2;
+        }
         const int n = S.n;
         if (n > 0) {
             if (vv - vw <= 1e-6f * vv) break;
@@ -621,8 +629,9 @@ struct MainResult {       // stage 1: plain GJK
     GjkSeed seed;         // type 1: the converged simplex, start of the tilt runs
 };
 
-__device__ void pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
-                          const f3* __restrict__ hv, const float4* __restrict__ gv, float margin, MainResult& r)
+__device__ bool pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
+                          const f3* __restrict__ hv, const float4* __restrict__ gv, float margin, const GjkSeed cached,
+                          MainResult& r)
 {
     r.type = 0;
     Shape A, B;
@@ -632,22 +641,21 @@ __device__ void pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, c
     const v3 cb = add(m3_mul(wb.R, hb.sc), wb.t);
     v3 pa, pb, n;
     float dist;
-    GjkSeed none;
-    none.n = 0; none.i0 = none.i1 = none.i2 = 0;
-    r.seed = none;
-    const int code = gjk_distance(A, B, hv, sub(ca, cb), margin, &pa, &pb, &dist, none, &r.seed);
-    if (code == 2) return;
+    r.seed.n = 0; r.seed.i0 = r.seed.i1 = r.seed.i2 = 0;
+    const int code = gjk_distance(A, B, hv, sub(ca, cb), margin, &pa, &pb, &dist, cached, &r.seed);
+    if (code == 2) return true;
     if (code == 0) {
         float sep;
         overlap_fallback(A, B, hv, ca, cb, &n, &sep, &pa, &pb);
         if (sep > 0.0f) sep = 0.0f;
         r.type = 2; r.n = n; r.pa = pa; r.pb = pb; r.dist = sep;
-        return;
+        return false;   // overlap keeps the previous cache entry
     }
-    if (dist > margin) return;
+    if (dist > margin) return true;
     r.type = 1;
     r.n = scale(sub(pa, pb), 1.0f / dist);
     r.pa = pa; r.pb = pb; r.dist = dist;
+    return true;
 }
 
 // stage 2: tilt run k (0..3) of a contact pair -> candidate (qa, qb, sp); returns false if rejected
@@ -1220,7 +1228,8 @@ __host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_settle(const slhip_settle_scene* __restrict__ scenes, slhip_body* bodies_all,
                                                const slhip_hull* __restrict__ hulls,
                                                const float* __restrict__ hull_verts, slhip_settle_params prm,
-                                               LdsLayout L, ProfScratch* prof_all, DriveAcc* drive_all)
+                                               LdsLayout L, ProfScratch* prof_all, DriveAcc* drive_all,
+                                               GjkSeed* cache_all, unsigned cache_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WBody* wb = reinterpret_cast<WBody*>(smem + L.off_wb);
@@ -1288,6 +1297,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         if (lane == 0) body_lh[nb] = n_lh;
         if (!fits) return;  // more hulls than the host sized for
+    }
+    __syncthreads();
+    // pair cache (oracle scene_ws.cache): [n_hulls][n_hulls] seeds in global scratch, cleared per launch;
+    // scenes with more than SLHIP_PAIR_CACHE_MAX_HULLS hulls run without it
+    const int n_hulls = body_lh[nb];
+    GjkSeed* cache = nullptr;
+    if (n_hulls > 0 && n_hulls <= SLHIP_PAIR_CACHE_MAX_HULLS && (unsigned)(n_hulls * n_hulls) <= cache_stride) {
+        cache = cache_all + (size_t)blockIdx.x * cache_stride;
+        int4* z = reinterpret_cast<int4*>(cache);
+        for (int k = lane; k < n_hulls * n_hulls; k += 64) z[k] = make_int4(0, 0, 0, 0);
     }
     __syncthreads();
 
@@ -1467,8 +1486,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const int ba = hp_ba(e), bb = hp_bb(e);
                     const v3 dv = sub(wb[ba].v, wb[bb].v);
                     const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
-                    pair_main(wb[ba], wb[bb], lh[body_lh[ba] + hp_ha(e)], lh[body_lh[bb] + hp_hb(e)], hv, gv, margin, mr);
+                    const int la = body_lh[ba] + hp_ha(e), lb = body_lh[bb] + hp_hb(e);
+                    GjkSeed cached;
+                    cached.n = 0; cached.i0 = cached.i1 = cached.i2 = 0;
+                    GjkSeed* slot_c = cache ? cache + (size_t)la * n_hulls + lb : nullptr;
+                    if (slot_c) {
+                        const int4 q = *reinterpret_cast<const int4*>(slot_c);
+                        cached.n = q.x; cached.i0 = q.y; cached.i1 = q.z; cached.i2 = q.w;
+                    }
+                    const bool rewrite = pair_main(wb[ba], wb[bb], lh[la], lh[lb], hv, gv, margin, cached, mr);
+                    if (slot_c && rewrite) *reinterpret_cast<int4*>(slot_c) = make_int4(mr.seed.n, mr.seed.i0, mr.seed.i1, mr.seed.i2);
                 }
+                PROF(12);   // d1: main GJK
                 const int slot = compact_slot(mr.type != 0, 0);
                 const int ncp = __popcll(__ballot(mr.type != 0));
                 if (mr.type != 0) cpl[slot] = (unsigned char)lane;
@@ -1546,6 +1575,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     n_active = min(n_active + total, kMaxActive);
                 }
                 __syncthreads();
+                PROF(13);   // d2 + d3: tilt runs, manifold, contact fill
             }
             // contact offsets per hull pair: exclusive prefix of the counts, in place
             {
@@ -1620,11 +1650,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // (f) prep
             for (int c = lane; c < n_active; c += 64) prep_contact(&ac[c], wb, prm.bounce_threshold);
             PROF(6);
-            // (g) greedy colouring in group order (serial by definition)
+            // (g) greedy colouring, largest group first (oracle color_groups): every lane ranks its group by
+            // (contacts descending, index ascending), the ranked list goes to `order` (rewritten below),
+            // lane 0 walks it -- the greedy pass itself is serial by definition
+            for (int g0 = 0; g0 < n_groups; g0 += 64) {
+                const int g = g0 + lane;
+                if (g < n_groups) {
+                    const int sz = (int)groups[g].end - (int)groups[g].begin;
+                    int rank = 0;
+                    for (int h = 0; h < n_groups; ++h) {
+                        const int sh = (int)groups[h].end - (int)groups[h].begin;
+                        rank += (sh > sz || (sh == sz && h < g)) ? 1 : 0;
+                    }
+                    order[rank] = (unsigned short)g;
+                }
+            }
+            __syncthreads();
             if (lane == 0) {
                 for (int i = 0; i < nb; ++i) used[i] = 0ull;
                 int ncol = 0;
-                for (int g = 0; g < n_groups; ++g) {
+                for (int q = 0; q < n_groups; ++q) {
+                    const int g = order[q];
                     const int a = groups[g].a, b = groups[g].b == kNoBody ? -1 : (int)groups[g].b;
                     unsigned long long m = used[a];
                     if (b >= 0) m |= used[b];
@@ -1806,15 +1852,32 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
 
 }  // namespace
 
-// per-scene scratch: [n_scenes x ProfScratch][n_scenes x SLHIP_MAX_BODIES x DriveAcc]
-static uint64_t settle_scratch_bytes(uint32_t n_scenes)
+// entries of one scene's pair cache: (hulls per scene)^2, from the hint (0 or beyond the cap: the cap)
+static uint32_t pair_cache_stride(const slhip_settle_params* params)
 {
-    return (uint64_t)n_scenes * (sizeof(ProfScratch) + SLHIP_MAX_BODIES * sizeof(DriveAcc)) + 256;
+    uint32_t h = params ? params->max_hulls_per_scene : 0u;
+    if (h == 0u || h > SLHIP_PAIR_CACHE_MAX_HULLS) h = SLHIP_PAIR_CACHE_MAX_HULLS;
+    return h * h;
 }
 
-extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, uint64_t* bytes_out)
+// per-scene scratch: [n_scenes x ProfScratch][n_scenes x SLHIP_MAX_BODIES x DriveAcc][n_scenes x pair cache]
+static uint64_t settle_fixed_bytes(uint32_t n_scenes)
 {
-    *bytes_out = settle_scratch_bytes(n_scenes);
+    const uint64_t b = (uint64_t)n_scenes * (sizeof(ProfScratch) + SLHIP_MAX_BODIES * sizeof(DriveAcc));
+    return (b + 255u) & ~(uint64_t)255u;
+}
+static uint64_t settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params)
+{
+    return settle_fixed_bytes(n_scenes) + (uint64_t)n_scenes * pair_cache_stride(params) * sizeof(GjkSeed) + 256;
+}
+
+extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out)
+{
+    if (!bytes_out) {
+        slhip::set_error("slhip_settle_scratch_bytes: null output");
+        return -1;
+    }
+    *bytes_out = settle_scratch_bytes(n_scenes, params);
     return 0;
 }
 
@@ -1828,7 +1891,7 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         return -1;
     }
     if (n_scenes == 0) return 0;
-    if (scratch_bytes < settle_scratch_bytes(n_scenes)) {
+    if (scratch_bytes < settle_scratch_bytes(n_scenes, params)) {
         slhip::set_error("slhip_settle: scratch too small");
         return -1;
     }
@@ -1864,7 +1927,9 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                                     L.total));
     ProfScratch* prof = reinterpret_cast<ProfScratch*>(d_scratch);
     DriveAcc* drive = reinterpret_cast<DriveAcc*>(prof + n_scenes);
-    k_settle<<<n_scenes, 64, L.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, L, prof, drive);
+    GjkSeed* cache = reinterpret_cast<GjkSeed*>(reinterpret_cast<char*>(d_scratch) + settle_fixed_bytes(n_scenes));
+    k_settle<<<n_scenes, 64, L.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, L, prof, drive, cache,
+                                                pair_cache_stride(params));
     SLHIP_LAUNCH_CHECK();
     return 0;
 }

@@ -35,10 +35,12 @@ class SettleEngine:
             self.pool.dirty = False
         return self._dev
 
-    def scratch(self, n_scenes, stream=0):
-        """Scratch per stream: launches on different streams may run concurrently."""
+    def scratch(self, n_scenes, stream=0, params=None):
+        """Scratch per stream: launches on different streams may run concurrently.  `params` carries
+        the sizing hints of the batch (None: worst-case pair cache)."""
         need = C.c_uint64()
-        self.eng.L.slhip_settle_scratch_bytes(n_scenes, C.byref(need))
+        prm = None if params is None else np.ascontiguousarray(params)
+        self.eng.L.slhip_settle_scratch_bytes(n_scenes, C.c_void_p(prm.ctypes.data) if prm is not None else None, C.byref(need))
         cur = self._scratch.get(stream)
         if cur is None or cur.numel() < need.value:
             cur = torch.empty(int(need.value), dtype=torch.uint8, device=self.eng.device)
@@ -58,10 +60,10 @@ class SettleEngine:
         if d_bodies is None:
             d_bodies = eng.upload_records(bodies)
         stream = torch.cuda.current_stream(eng.device).cuda_stream
-        scratch = self.scratch(len(srec), stream)
         if bodies is not None:
             params = SB.sizing_hints(params, srec, bodies, self.pool.arrays()[0])
         prm = np.ascontiguousarray(params)
+        scratch = self.scratch(len(srec), stream, prm)
         with torch.cuda.device(eng.device):
             st = eng.L.slhip_settle(_abi_ptr(d_s), len(srec), _abi_ptr(d_bodies), _abi_ptr(d_hulls), _abi_ptr(d_verts),
                                     C.c_void_p(prm.ctypes.data), _abi_ptr(scratch), scratch.numel(), C.c_void_p(stream))

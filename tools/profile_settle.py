@@ -24,7 +24,7 @@ planes = [(physics.prepare_tabletop(s), physics.PLANE_HALF_Z) for s in scenes]
 srec, bodies = SB.build_settle_batch(scenes, se.pool, planes)
 prm = SB.sizing_hints(SB.default_params(tabletop=True, frames=FRAMES), srec, bodies, se.pool.arrays()[0])
 print("hints: bodies %d hull verts %d hulls %d" % (prm["max_bodies_per_scene"], prm["max_hull_verts_per_scene"], prm["max_hulls_per_scene"]))
-scr = se.scratch(B, torch.cuda.current_stream().cuda_stream)
+scr = se.scratch(B, torch.cuda.current_stream().cuda_stream, prm)
 scr.zero_()
 d = se.eng.upload_records(bodies)
 torch.cuda.synchronize()
@@ -36,7 +36,7 @@ if os.environ.get("SLHIP_SETTLE_CUS"):   # confine the launch to a CU range: "fi
     h = C.c_void_p()
     _abi.check(_abi.lib().slhip_stream_create_cu_range(first, count, C.byref(h)), "slhip_stream_create_cu_range")
     stream = torch.cuda.ExternalStream(h.value)
-    scr = se.scratch(B, stream.cuda_stream)
+    scr = se.scratch(B, stream.cuda_stream, prm)
     scr.zero_()
     torch.cuda.synchronize()
 t = time.perf_counter()
@@ -56,13 +56,13 @@ if os.environ.get("SLHIP_SETTLE_PROFILE"):
     steps = FRAMES * 4 * B
     # wall_clock64 ticks at 100 MHz
     for i, n in enumerate(["a load", "b plane", "c broadphase", "d narrow", "d2 ranges+minsep", "wake", "f prep",
-                           "g color", "h pos iters", "i integrate", "j vel iters", "k store"]):
+                           "g color", "h pos iters", "i integrate", "j vel iters", "k store", "d1 main gjk", "d2+d3 tilt/manifold"]):
         print("  %-18s %8.2f us/step" % (n, tot[i] / steps / 100.0))
-    print("  total %.2f us/step" % (tot[:12].sum() / steps / 100.0))
+    print("  total %.2f us/step" % (tot[:14].sum() / steps / 100.0))
     print("  avg hull pairs %.1f, active contacts %.1f, groups %.1f, colours %.1f" % tuple(cnt[:4] / steps))
 if os.environ.get("SLHIP_SETTLE_PROFILE"):
     # per-scene cost against a-priori features (for longest-first launch order)
-    per_scene = np.array([np.frombuffer(sc[b * 256:b * 256 + 128].tobytes(), dtype=np.uint64).astype(np.float64)[:12].sum() for b in range(B)])
+    per_scene = np.array([np.frombuffer(sc[b * 256:b * 256 + 128].tobytes(), dtype=np.uint64).astype(np.float64)[:14].sum() for b in range(B)])
     hulls_a = se.pool.arrays()[0]
     cnt = hulls_a["vtx_count"].astype(np.int64)
     csum = np.concatenate([[0], np.cumsum(cnt)])
@@ -78,3 +78,13 @@ if os.environ.get("SLHIP_SETTLE_PROFILE"):
     order = np.argsort(-sh2)
     top = set(np.argsort(-per_scene)[:B // 8].tolist())
     print("  of the heaviest 1/8 of the scenes, %.0f%% are in the first quarter of the sum-hulls^2 order" % (100.0 * len(top & set(order[:B // 4].tolist())) / len(top)))
+if os.environ.get("SLHIP_SETTLE_PROFILE"):
+    names = ["a load", "b plane", "c broadphase", "d narrow", "d2 ranges+minsep", "wake", "f prep", "g color", "h pos iters",
+             "i integrate", "j vel iters", "k store", "d1 main gjk", "d2+d3 tilt/manifold"]
+    allc = np.stack([np.frombuffer(sc[b * 256:b * 256 + 128].tobytes(), dtype=np.uint64).astype(np.float64)[:14] for b in range(B)])
+    alln = np.stack([np.frombuffer(sc[b * 256 + 128:b * 256 + 256].tobytes(), dtype=np.uint64).astype(np.float64)[:4] for b in range(B)])
+    heavy = np.argsort(-allc.sum(1))[:max(1, B // 20)]
+    print("  heaviest 5%% of the scenes (mean %.1f ms):" % (allc[heavy].sum(1).mean() / 1e5))
+    for i, n in enumerate(names):
+        print("    %-22s %8.2f us/step   (all scenes %8.2f)" % (n, allc[heavy, i].mean() / (FRAMES * 4) / 100.0, allc[:, i].mean() / (FRAMES * 4) / 100.0))
+    print("    hull pairs %.1f contacts %.1f groups %.1f colours %.1f" % tuple(alln[heavy].mean(0) / (FRAMES * 4)))
