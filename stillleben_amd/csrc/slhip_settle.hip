@@ -746,14 +746,22 @@ __device__ __forceinline__ float4 hull_vertex(const HullRef& h, const f3* __rest
 struct BandPt { v3 p; float d; };
 constexpr int kBandCap = 32;   // in-band vertices cached per body; beyond that the passes re-walk the hulls
 
+// A 16-lane sub-group is one DPP row: rotating the row by 8, 4, 2, 1 lanes and combining leaves the
+// reduction of all 16 lanes in every lane (the (value, ordinal) minimum is a total order, so the
+// combine is associative and commutative) -- full-rate VALU moves instead of eight ds_bpermute trips.
+template <int CTRL>
+__device__ __forceinline__ void sg16_argmin_step(float& val, int& idx)
+{
+    const float ov = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(val), CTRL, 0xF, 0xF, true));
+    const int oi = __builtin_amdgcn_mov_dpp(idx, CTRL, 0xF, 0xF, true);
+    if (ov < val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+}
 __device__ __forceinline__ void sg16_argmin(float& val, int& idx)
 {
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-        const float ov = __shfl_xor(val, m, 64);
-        const int oi = __shfl_xor(idx, m, 64);
-        if (ov < val || (ov == val && oi < idx)) { val = ov; idx = oi; }
-    }
+    sg16_argmin_step<0x128>(val, idx);   // row_ror:8
+    sg16_argmin_step<0x124>(val, idx);   // row_ror:4
+    sg16_argmin_step<0x122>(val, idx);   // row_ror:2
+    sg16_argmin_step<0x121>(val, idx);   // row_ror:1
 }
 
 // broadcast the winning lane's point within the 16-lane sub-group
