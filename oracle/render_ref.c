@@ -104,10 +104,11 @@ static inline void mm4(const float* A, const float* B, float* C)
 
 static inline void normalize3(float* v)
 {
-    float s = sqrtf(dot3(v, v));
-    v[0] = v[0] / s;
-    v[1] = v[1] / s;
-    v[2] = v[2] / s;
+    /* one reciprocal and three products: GLSL normalize() is x * inversesqrt(dot(x, x)) */
+    const float s = 1.0f / sqrtf(dot3(v, v));
+    v[0] = v[0] * s;
+    v[1] = v[1] * s;
+    v[2] = v[2] * s;
 }
 
 static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -265,7 +266,7 @@ static inline void bary_at(const tri_setup* t, int px, int py, float b[3])
     }
     float pw0 = l[0] * t->invw[0], pw1 = l[1] * t->invw[1], pw2 = l[2] * t->invw[2];
     float sw = (pw0 + pw1) + pw2;
-    float bs[3] = {pw0 / sw, pw1 / sw, pw2 / sw};
+    float bs[3] = {pw0 * (1.0f / sw), pw1 * (1.0f / sw), pw2 * (1.0f / sw)};
     for (int k = 0; k < 3; ++k) b[k] = fmaf(bs[2], t->bary[2][k], fmaf(bs[1], t->bary[1][k], bs[0] * t->bary[0][k]));
 }
 
@@ -536,6 +537,8 @@ static void shade_fragment(const shade_ctx* cx, const slhip_draw* dr, const floa
         kS[c] = F0[c] + Fr * p5;
     }
 
+    /* Lambert term base / pi once per pixel; the divisions below are one reciprocal each */
+    const float base_pi[3] = {base[0] / REF_PI, base[1] / REF_PI, base[2] / REF_PI};
     for (int i = 0; i < SLHIP_NUM_LIGHTS; ++i) {
         const float* lc = sc->light_color[i];
         const float* ld = sc->light_dir[i];
@@ -547,9 +550,10 @@ static void shade_fragment(const shade_ctx* cx, const slhip_draw* dr, const floa
         if ((cx->flags & SLHIP_RENDER_SHADOWS) && cx->shadow) {
             float w4[4] = {world[0], world[1], world[2], 1.0f}, pc[4];
             mv4(sc->shadow_mat[i], w4, pc);
-            float px = 0.5f * (pc[0] / pc[3]) + 0.5f;
-            float py = 0.5f * (pc[1] / pc[3]) + 0.5f;
-            float pz = 0.5f * (pc[2] / pc[3]) + 0.5f;
+            const float rpw = 1.0f / pc[3];   /* shared by the three perspective divisions */
+            float px = fmaf(pc[0] * rpw, 0.5f, 0.5f);
+            float py = fmaf(pc[1] * rpw, 0.5f, 0.5f);
+            float pz = fmaf(pc[2] * rpw, 0.5f, 0.5f);
             const float* sm = cx->shadow + (size_t)i * cx->S * cx->S;
             float scale = 1.0f / (float)cx->S;
             float acc = 0.0f;
@@ -569,10 +573,11 @@ static void shade_fragment(const shade_ctx* cx, const slhip_draw* dr, const floa
         float G = geometry_smith(normal, V, L, roughness);
         float NdotL = fmaxf(dot3(normal, L), 0.0f);
         float denominator = fmaxf(4.0f * NoV * NdotL, 0.001f);
+        const float rden = 1.0f / denominator;
         for (int c = 0; c < 3; ++c) {
-            float specular = (NDF * G * kS[c]) / denominator;
+            float specular = (NDF * G * kS[c]) * rden;
             float kD = (1.0f - kS[c]) * (1.0f - metallic);
-            color[c] += inverse_shadow * (kD * base[c] / REF_PI + specular) * lc[c] * NdotL;
+            color[c] += inverse_shadow * (kD * base_pi[c] + specular) * lc[c] * NdotL;
         }
     }
     for (int c = 0; c < 3; ++c) color[c] += sc->ambient[c] * base[c];
@@ -985,7 +990,7 @@ int slref_render(const slhip_mesh_pool* pool, const slhip_scene* scenes, const s
                             /* perspective-correct barycentrics of the sub-triangle ... */
                             float pw0 = l[0] * ts.invw[0], pw1 = l[1] * ts.invw[1], pw2 = l[2] * ts.invw[2];
                             float sw = (pw0 + pw1) + pw2;
-                            float bs[3] = {pw0 / sw, pw1 / sw, pw2 / sw};
+                            float bs[3] = {pw0 * (1.0f / sw), pw1 * (1.0f / sw), pw2 * (1.0f / sw)};
                             /* ... mapped to the original triangle */
                             float b[3];
                             for (int k = 0; k < 3; ++k)

@@ -83,10 +83,10 @@ __device__ __forceinline__ void mm4(const float* __restrict__ A, const float* B,
 
 __device__ __forceinline__ void normalize3(float* v)
 {
-    float s = sqrtf(dot3(v, v));
-    v[0] = v[0] / s;
-    v[1] = v[1] / s;
-    v[2] = v[2] / s;
+    const float s = 1.0f / sqrtf(dot3(v, v));   // one reciprocal, three products (oracle normalize3)
+    v[0] = v[0] * s;
+    v[1] = v[1] * s;
+    v[2] = v[2] * s;
 }
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -493,7 +493,7 @@ __device__ __forceinline__ void bary_at(const Setup& t, const float* b0, const f
     }
     const float pw0 = l[0] * t.invw[0], pw1 = l[1] * t.invw[1], pw2 = l[2] * t.invw[2];
     const float sw = (pw0 + pw1) + pw2;
-    const float bs[3] = {pw0 / sw, pw1 / sw, pw2 / sw};
+    const float bs[3] = {pw0 * (1.0f / sw), pw1 * (1.0f / sw), pw2 * (1.0f / sw)};
 #pragma unroll
     for (int k = 0; k < 3; ++k) b[k] = fmaf(bs[2], b2[k], fmaf(bs[1], b1[k], bs[0] * b0[k]));
 }
@@ -553,7 +553,7 @@ struct MainTarget {
         if (need_attr) {
             const float pw0 = l[0] * t.invw[0], pw1 = l[1] * t.invw[1], pw2 = l[2] * t.invw[2];
             const float sw = (pw0 + pw1) + pw2;
-            const float bs[3] = {pw0 / sw, pw1 / sw, pw2 / sw};
+            const float bs[3] = {pw0 * (1.0f / sw), pw1 * (1.0f / sw), pw2 * (1.0f / sw)};
             float b[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -1048,6 +1048,7 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
         const float Fr = fmaxf(1.0f - roughness, F0[c]) - F0[c];
         kS[c] = F0[c] + Fr * p5;
     }
+    const float base_pi[3] = {base[0] / kPi, base[1] / kPi, base[2] / kPi};   // Lambert term, once per pixel
     for (int i = 0; i < SLHIP_NUM_LIGHTS; ++i) {
         if (!light_active(sc, i)) continue;
         const float* lc = sc->light_color[i];
@@ -1057,9 +1058,10 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
             const float w4[4] = {world[0], world[1], world[2], 1.0f};
             float pc[4];
             mv4(sc->shadow_mat[i], w4, pc);
-            const float px = 0.5f * (pc[0] / pc[3]) + 0.5f;
-            const float py = 0.5f * (pc[1] / pc[3]) + 0.5f;
-            const float pz = 0.5f * (pc[2] / pc[3]) + 0.5f;
+            const float rpw = 1.0f / pc[3];   /* shared by the three perspective divisions */
+            const float px = fmaf(pc[0] * rpw, 0.5f, 0.5f);
+            const float py = fmaf(pc[1] * rpw, 0.5f, 0.5f);
+            const float pz = fmaf(pc[2] * rpw, 0.5f, 0.5f);
             const float* sm = shadow + (size_t)i * S * S;
             inverse_shadow = shadow_pcf16(sm, S, px, py, pz - 0.00003f);
         }
@@ -1072,11 +1074,12 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
         const float NdotL = fmaxf(dot3(normal, L), 0.0f);
         const float G = geometry_schlick_ggx(NdotL, roughness) * geometry_schlick_ggx(NdotVg, roughness);
         const float denominator = fmaxf(4.0f * NoV * NdotL, 0.001f);
+        const float rden = 1.0f / denominator;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float specular = (NDF * G * kS[c]) / denominator;
+            const float specular = (NDF * G * kS[c]) * rden;
             const float kD = (1.0f - kS[c]) * (1.0f - metallic);
-            color[c] += inverse_shadow * (kD * base[c] / kPi + specular) * lc[c] * NdotL;
+            color[c] += inverse_shadow * (kD * base_pi[c] + specular) * lc[c] * NdotL;
         }
     }
 #pragma unroll
@@ -1259,7 +1262,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                 if (!coverage(t, px, py, l)) continue;
                 const float pw0 = l[0] * t.invw[0], pw1 = l[1] * t.invw[1], pw2 = l[2] * t.invw[2];
                 const float sw = (pw0 + pw1) + pw2;
-                const float bs[3] = {pw0 / sw, pw1 / sw, pw2 / sw};
+                const float bs[3] = {pw0 * (1.0f / sw), pw1 * (1.0f / sw), pw2 * (1.0f / sw)};
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     b[k] = fmaf(bs[2], poly[sub + 2].bary[k],
