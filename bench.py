@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 RESOLUTION = (640, 480)
 INTRINSICS = (1066.778, 1067.487, 312.9869, 241.3109)  # reference examples/ycb.py:32
+VALU_INSTS_PER_SCENE = 56420078504 / 2048   # rocprofv3 --pmc SQ_INSTS_VALU, tools/profile_settle.py 2048 100 (profiles/r01)
 N_OBJECTS = 20
 
 
@@ -337,13 +338,13 @@ def main():
     for it in items[args.warmup:]:
         pipe.t_render.append(sum(a.elapsed_time(b) for a, b in it["render_events"]))
         pipe.t_settle.append(it["ev0"].elapsed_time(it["ev1"]))
+        pipe.t_step_host.append(it["t_post"])
     if rank == 0 and os.environ.get("SLHIP_BENCH_TRACE"):
         ref = items[args.warmup]["ev0"]
         for k, it in enumerate(items[args.warmup:]):
             print("[trace] step %d: settle %.0f..%.0f ms, render %.0f..%.0f ms" % (
                 k, ref.elapsed_time(it["ev0"]), ref.elapsed_time(it["ev1"]),
                 ref.elapsed_time(it["render_events"][0][0]), ref.elapsed_time(it["render_events"][-1][1])), file=sys.stderr)
-        pipe.t_step_host.append(it["t_post"])
     pipe.phase_ms.append(np.array(list(ms_all)) / max(1, args.steps))
     # the render kernels overlap with the next batch's settle inside the timed region, which
     # stretches their event-to-event times; one extra NON-overlapped render pass of the last
@@ -404,8 +405,12 @@ def main():
             "algorithmic_bytes_per_launch": settle_bytes,
             "measured": "HIP events around each slhip_settle launch; up to --settle-streams launches share the GPU, "
                         "so a launch's duration is longer than when it runs alone",
-            "note": "latency-bound persistent kernel (400 dependent steps/scene in LDS, ~10 cycles per dependent "
-                    "instruction); an HBM fraction is not meaningful -- see steps_scenes_per_s",
+            "note": "VALU-issue-bound persistent kernel (400 dependent steps per scene in LDS): neither HBM nor MFMA "
+                    "bounds it, the HBM fraction is reported because the schema asks for one -- see valu_frac "
+                    "(SQ_INSTS_VALU per scene from profiles/r01/settle_sq_counters_v30.txt x scenes / launch time, "
+                    "against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction) and steps_scenes_per_s",
+            "valu_insts_per_scene": VALU_INSTS_PER_SCENE,
+            "valu_frac": VALU_INSTS_PER_SCENE * args.batch / (t_settle * 1e-3) / (1024 * 2.4e9 / 4),
             "steps_scenes_per_s": args.batch * 400 / (t_settle * 1e-3),
         }
         roof_settle["frac"] = roof_settle["achieved"] / roof_settle["peak"]
