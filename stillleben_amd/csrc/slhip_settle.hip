@@ -1540,6 +1540,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         radius = ha.sr <= hb.sr ? ha.sr : hb.sr;
                         if (mm.type == 1) have = pair_tilt(wb[bi], wb[bj], ha, hb, hv, gv, prm, margin, mm.n, mm.seed, t, &qa, &qb, &sp);
                     }
+                    PROF(14);   // d2: tilt runs
                     // gather the four candidates of a pair into its tilt-0 lane
                     Cand5 c;
                     c.ok = 0u;

@@ -157,3 +157,31 @@ def test_image_saver_takes_device_tensors(sl, tmp_path):
     assert np.array_equal(np.asarray(Image.open(tmp_path / "inst.png")), inst.to(torch.uint8).cpu().numpy())
     assert np.array_equal(np.asarray(Image.open(tmp_path / "inst16.png")).astype(np.int16), inst.cpu().numpy())
     assert inst.max() > 0
+
+
+def test_cu_range_stream_runs_the_path(sl, oracle):
+    """slhip_stream_create_cu_range: a settle launched on a stream confined to 32 CUs gives the same
+    bits as the oracle (placement never affects results); bad ranges fail loudly."""
+    from stillleben_amd import physics
+    from stillleben_amd.parallel import cu_partition_streams
+
+    cube = scaled(sl, S.CUBE, 0.15)
+    scs = [heap(sl, 900 + i, 5, cube) for i in range(8)]
+    se = physics.settle_engine()
+    srec, bodies = SB.build_settle_batch(scs, se.pool, [(True, 0.04)] * len(scs))
+    prm = SB.default_params(frames=20)
+    settle_streams, render_stream = cu_partition_streams(32, 1)
+    with torch.cuda.stream(settle_streams[0]):
+        gpu = se.run(srec, bodies.copy(), prm)
+    torch.cuda.synchronize()
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    oracle.settle(srec, ref, hulls, verts, prm)
+    assert_bodies_equal(gpu, ref)
+    assert render_stream.cuda_stream != settle_streams[0].cuda_stream
+    L = _abi.lib()
+    h = C.c_void_p()
+    assert L.slhip_stream_create_cu_range(250, 100, C.byref(h)) != 0
+    assert b"exceed" in L.slhip_last_error()
+    with pytest.raises(ValueError):
+        cu_partition_streams(0)

@@ -56,13 +56,13 @@ if os.environ.get("SLHIP_SETTLE_PROFILE"):
     steps = FRAMES * 4 * B
     # wall_clock64 ticks at 100 MHz
     for i, n in enumerate(["a load", "b plane", "c broadphase", "d narrow", "d2 ranges+minsep", "wake", "f prep",
-                           "g color", "h pos iters", "i integrate", "j vel iters", "k store", "d1 main gjk", "d2+d3 tilt/manifold"]):
+                           "g color", "h pos iters", "i integrate", "j vel iters", "k store", "d1 main gjk", "d3 manifold+fill", "d2 tilt runs"]):
         print("  %-18s %8.2f us/step" % (n, tot[i] / steps / 100.0))
-    print("  total %.2f us/step" % (tot[:14].sum() / steps / 100.0))
+    print("  total %.2f us/step" % (tot[:15].sum() / steps / 100.0))
     print("  avg hull pairs %.1f, active contacts %.1f, groups %.1f, colours %.1f" % tuple(cnt[:4] / steps))
 if os.environ.get("SLHIP_SETTLE_PROFILE"):
     # per-scene cost against a-priori features (for longest-first launch order)
-    per_scene = np.array([np.frombuffer(sc[b * 256:b * 256 + 128].tobytes(), dtype=np.uint64).astype(np.float64)[:14].sum() for b in range(B)])
+    per_scene = np.array([np.frombuffer(sc[b * 256:b * 256 + 128].tobytes(), dtype=np.uint64).astype(np.float64)[:15].sum() for b in range(B)])
     hulls_a = se.pool.arrays()[0]
     cnt = hulls_a["vtx_count"].astype(np.int64)
     csum = np.concatenate([[0], np.cumsum(cnt)])
@@ -80,8 +80,8 @@ if os.environ.get("SLHIP_SETTLE_PROFILE"):
     print("  of the heaviest 1/8 of the scenes, %.0f%% are in the first quarter of the sum-hulls^2 order" % (100.0 * len(top & set(order[:B // 4].tolist())) / len(top)))
 if os.environ.get("SLHIP_SETTLE_PROFILE"):
     names = ["a load", "b plane", "c broadphase", "d narrow", "d2 ranges+minsep", "wake", "f prep", "g color", "h pos iters",
-             "i integrate", "j vel iters", "k store", "d1 main gjk", "d2+d3 tilt/manifold"]
-    allc = np.stack([np.frombuffer(sc[b * 256:b * 256 + 128].tobytes(), dtype=np.uint64).astype(np.float64)[:14] for b in range(B)])
+             "i integrate", "j vel iters", "k store", "d1 main gjk", "d3 manifold+fill", "d2 tilt runs"]
+    allc = np.stack([np.frombuffer(sc[b * 256:b * 256 + 128].tobytes(), dtype=np.uint64).astype(np.float64)[:15] for b in range(B)])
     alln = np.stack([np.frombuffer(sc[b * 256 + 128:b * 256 + 256].tobytes(), dtype=np.uint64).astype(np.float64)[:4] for b in range(B)])
     heavy = np.argsort(-allc.sum(1))[:max(1, B // 20)]
     print("  heaviest 5%% of the scenes (mean %.1f ms):" % (allc[heavy].sum(1).mean() / 1e5))
