@@ -166,7 +166,7 @@ class Pipeline:
                 th1 = time.perf_counter()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                buf = self.eng.render_records(srec, drec, t.crec, W, H, self.mask, ssao=self.ssao, shadows=True,
+                buf = self.eng.render_records(srec, drec, t.crec, W, H, self.mask, ssao=self.ssao, shadows=not os.environ.get("SLHIP_BENCH_NO_SHADOWS"),
                                               buffers=self.buffers[ci] if ci < len(self.buffers) else None)
                 e1.record()
                 if self.gatherer is not None:

@@ -359,6 +359,7 @@ __device__ int reduce_simplex(Simplex& S, v3* v)
 }
 
 constexpr int kGjkMaxIter = 32;
+constexpr int kGjkTiltMaxIter = 4;   // oracle GJK_TILT_MAX_ITER: tilt runs after the warm start
 
 __device__ __forceinline__ bool same_w(const SV& a, const SV& b)
 {
@@ -377,7 +378,7 @@ __device__ __forceinline__ SV seed_vertex(const Shape& A, const Shape& B, const 
 }
 
 __device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict__ hv, v3 init_dir, float margin,
-                            v3* pa, v3* pb, float* dist, const GjkSeed seed_in, GjkSeed* seed_out)
+                            v3* pa, v3* pb, float* dist, const GjkSeed seed_in, GjkSeed* seed_out, int max_iter)
 {
     Simplex S;
     S.n = 0;
@@ -395,7 +396,7 @@ __device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict
         vv = dot(v, v);
         if (vv < 1e-12f) return 0;
     }
-    for (int it = 0; it < kGjkMaxIter; ++it) {
+    for (int it = 0; it < max_iter; ++it) {
         SV w;
         int ia, ib;
         w.a = support(A, hv, neg(v), ia);
@@ -446,7 +447,7 @@ __device__ __forceinline__ int gjk_distance(const Shape& A, const Shape& B, cons
 {
     GjkSeed none;
     none.n = 0; none.i0 = none.i1 = none.i2 = 0;
-    return gjk_distance(A, B, hv, init_dir, margin, pa, pb, dist, none, nullptr);
+    return gjk_distance(A, B, hv, init_dir, margin, pa, pb, dist, none, nullptr, kGjkMaxIter);
 }
 
 __device__ __forceinline__ v3 tangent_axis(v3 n)
@@ -642,7 +643,7 @@ __device__ bool pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, c
     v3 pa, pb, n;
     float dist;
     r.seed.n = 0; r.seed.i0 = r.seed.i1 = r.seed.i2 = 0;
-    const int code = gjk_distance(A, B, hv, sub(ca, cb), margin, &pa, &pb, &dist, cached, &r.seed);
+    const int code = gjk_distance(A, B, hv, sub(ca, cb), margin, &pa, &pb, &dist, cached, &r.seed, kGjkMaxIter);
     if (code == 2) return true;
     if (code == 0) {
         float sep;
@@ -690,8 +691,8 @@ __device__ bool pair_tilt(const WBody& wa, const WBody& wb, const HullRef& ha, c
     T.t = sub(cw, m3_mul(T.R, cl));
     v3 qa, qb;
     float d2;
-    const int ok = tilt_a ? gjk_distance(T, B, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, nullptr)
-                          : gjk_distance(A, T, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, nullptr);
+    const int ok = tilt_a ? gjk_distance(T, B, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, nullptr, kGjkTiltMaxIter)
+                          : gjk_distance(A, T, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, nullptr, kGjkTiltMaxIter);
     if (ok != 1) return false;
     if (tilt_a) {
         const v3 loc = m3_tmul(T.R, sub(qa, T.t));
