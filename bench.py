@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 RESOLUTION = (640, 480)
 INTRINSICS = (1066.778, 1067.487, 312.9869, 241.3109)  # reference examples/ycb.py:32
-VALU_INSTS_PER_SCENE = 56420078504 / 2048   # rocprofv3 --pmc SQ_INSTS_VALU, tools/profile_settle.py 2048 100 (profiles/r01)
+VALU_INSTS_PER_SCENE = 52762516188 / 2048   # rocprofv3 --pmc SQ_INSTS_VALU, tools/profile_settle.py 2048 100 (profiles/r01/settle_sq_counters_v32.txt)
 N_OBJECTS = 20
 
 
@@ -407,7 +407,7 @@ def main():
                         "so a launch's duration is longer than when it runs alone",
             "note": "VALU-issue-bound persistent kernel (400 dependent steps per scene in LDS): neither HBM nor MFMA "
                     "bounds it, the HBM fraction is reported because the schema asks for one -- see valu_frac "
-                    "(SQ_INSTS_VALU per scene from profiles/r01/settle_sq_counters_v30.txt x scenes / launch time, "
+                    "(SQ_INSTS_VALU per scene from profiles/r01/settle_sq_counters_v32.txt x scenes / launch time, "
                     "against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction) and steps_scenes_per_s",
             "valu_insts_per_scene": VALU_INSTS_PER_SCENE,
             "valu_frac": VALU_INSTS_PER_SCENE * args.batch / (t_settle * 1e-3) / (1024 * 2.4e9 / 4),
