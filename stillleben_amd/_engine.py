@@ -85,8 +85,8 @@ class Engine:
         return p
 
     # ---- scratch ---------------------------------------------------------------------------
-    def scratch(self, B, H, W, want_rgb, ssao, shadows):
-        key = (B, H, W, want_rgb, ssao, shadows)
+    def scratch(self, B, H, W, want_rgb, ssao, shadows, stream=0):
+        key = (B, H, W, want_rgb, ssao, shadows, stream)   # per stream: launches on different streams may overlap
         s = self._scratch.get(key)
         if s is None:
             sizes = (C.c_uint64 * 6)()
@@ -101,7 +101,7 @@ class Engine:
                 "shadow": buf(sizes[3], shadows), "queue": buf(sizes[4]), "lum": buf(sizes[5], want_rgb),
                 "qcap": qcap,
             }
-            if len(self._scratch) > 4:
+            if len(self._scratch) > 6:
                 self._scratch.clear()
             self._scratch[key] = s
         a = _abi.RenderScratch()
@@ -140,16 +140,17 @@ class Engine:
         if buffers is None or (buffers.B, buffers.H, buffers.W, buffers.mask) != (B, H, W, mask):
             buffers = RenderBuffers(self.device, B, H, W, mask)
         out = buffers.abi()
-        scratch, keep = self.scratch(B, H, W, want_rgb, ssao, shadows)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        scratch, keep = self.scratch(B, H, W, want_rgb, ssao, shadows, stream)
         n_clip = int(drec["n_verts"].sum()) if len(drec) else 0
         planes = 1 + (_abi.NUM_LIGHTS if shadows else 0)
         need = max(16, n_clip * planes * 16)
-        if getattr(self, "_clip", None) is None or self._clip.numel() < need:
-            self._clip = torch.empty(need, dtype=torch.uint8, device=self.device)
-        scratch.d_clip = _ptr(self._clip)
+        clips = self.__dict__.setdefault("_clips", {})
+        if clips.get(stream) is None or clips[stream].numel() < need:
+            clips[stream] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        scratch.d_clip = _ptr(clips[stream])
         scratch.n_clip_verts = n_clip
         flags = mask | (_abi.RENDER_SSAO if ssao else 0) | (_abi.RENDER_SHADOWS if shadows else 0)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
             st = self.L.slhip_render(C.byref(pool), _ptr(d_s), _ptr(d_d), _ptr(d_c), B, len(drec), len(crec), W, H, flags,
                                      _ptr(depth_peel), C.byref(out), C.byref(scratch), C.c_void_p(stream))
