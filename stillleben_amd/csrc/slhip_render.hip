@@ -1443,15 +1443,20 @@ __device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, 
     const float xs = x - 0.5f, ys = y - 0.5f;
     const float fx = floorf(xs), fy = floorf(ys);
     const float ax = xs - fx, ay = ys - fy;
-    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
-    x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
-    y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
+    // clamp(int(f), 0, n-1) == int(med3(f, 0, n-1)) for every non-NaN f (integers below 2^24 are exact in
+    // fp32): one v_med3_f32 per coordinate instead of a max/min pair
+    const float wm = (float)(W - 1), hm = (float)(H - 1);
+    const unsigned x0 = (unsigned)(int)__builtin_amdgcn_fmed3f(fx, 0.0f, wm), x1 = (unsigned)(int)__builtin_amdgcn_fmed3f(fx + 1.0f, 0.0f, wm);
+    const unsigned y0 = (unsigned)(int)__builtin_amdgcn_fmed3f(fy, 0.0f, hm), y1 = (unsigned)(int)__builtin_amdgcn_fmed3f(fy + 1.0f, 0.0f, hm);
     // `img` is the compact camera-z plane written by k_shade (same values as channel 2 of the
-    // camCoordinates target, 4 B/px instead of 16 B/px: the 64-tap gather stays L2 resident)
-    // 32-bit offsets from the (wave-uniform) plane base: one scalar base + one VGPR offset per load
-    const unsigned r0 = __umul24((unsigned)y0, (unsigned)W), r1 = __umul24((unsigned)y1, (unsigned)W);   // both < 2^24
-    const float a = img[r0 + (unsigned)x0], b = img[r0 + (unsigned)x1];
-    const float c = img[r1 + (unsigned)x0], d = img[r1 + (unsigned)x1];
+    // camCoordinates target, 4 B/px instead of 16 B/px: the 64-tap gather stays L2 resident).
+    // Byte offsets in 32 bits from the wave-uniform plane base: scalar base + one VGPR offset per load
+    const unsigned w4 = (unsigned)W * 4u;
+    const unsigned r0 = __umul24(y0, w4), r1 = __umul24(y1, w4);   // < 2^24 rows * bytes: fits (W * H * 4 < 2^24 * 4)
+    const unsigned xb0 = x0 * 4u, xb1 = x1 * 4u;
+    const char* base = reinterpret_cast<const char*>(img);
+    const float a = *reinterpret_cast<const float*>(base + (r0 + xb0)), b = *reinterpret_cast<const float*>(base + (r0 + xb1));
+    const float c = *reinterpret_cast<const float*>(base + (r1 + xb0)), d = *reinterpret_cast<const float*>(base + (r1 + xb1));
     const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - c, c);
     return fmaf(ay, bot - top, top);
 }
