@@ -238,11 +238,18 @@ def cpu_baseline(sl, meshes, scenes_per_thread, ssao, max_threads=32):
         w3 = time.perf_counter()
     n = threads * scenes_per_thread
     wall = (w1 - w0) + (w3 - w2)
+    cpu_model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "?")
+    except OSError:
+        pass
     return {
         "value": n / wall, "unit": "scenes/s", "cores": threads, "kind": "port",
-        "sample": "%d scenes on %d threads (host has %d cores): settle %.2f s + render %.2f s wall; per scene on one "
-                  "thread: settle %.3f s, render %.3f s (oracle/, same C2 workload)"
-                  % (n, threads, os.cpu_count() or 0, w1 - w0, w3 - w2, sum(t_settle) / n, sum(t_render) / n),
+        "sample": "%d scenes on %d threads (host: %d x %s): settle %.2f s + render %.2f s wall; per scene on one "
+                  "thread: settle %.3f s, render %.3f s, i.e. %.2f scenes/s single-threaded (oracle/, same C2 workload)"
+                  % (n, threads, os.cpu_count() or 0, cpu_model, w1 - w0, w3 - w2, sum(t_settle) / n, sum(t_render) / n,
+                     n / (sum(t_settle) + sum(t_render))),
     }
 
 
