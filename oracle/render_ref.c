@@ -737,11 +737,12 @@ static float rect_bilinear(const float* img, int W, int H, float x, float y, int
     float xs = x - 0.5f, ys = y - 0.5f;
     float fx = floorf(xs), fy = floorf(ys);
     float ax = xs - fx, ay = ys - fy;
-    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
-    if (x0 < 0) x0 = 0; if (x0 > W - 1) x0 = W - 1;
-    if (x1 < 0) x1 = 0; if (x1 > W - 1) x1 = W - 1;
-    if (y0 < 0) y0 = 0; if (y0 > H - 1) y0 = H - 1;
-    if (y1 < 0) y1 = 0; if (y1 > H - 1) y1 = H - 1;
+    /* clamp-to-edge BEFORE the float -> int conversion: the same texels for every finite coordinate, and a
+       defined result (edge texel; 0 for NaN) when a sample projects to infinity -- (int)inf is undefined
+       in C and saturates on the GPU */
+    const float wm = (float)(W - 1), hm = (float)(H - 1);
+    int x0 = (int)clampf(fx, 0.0f, wm), x1 = (int)clampf(fx + 1.0f, 0.0f, wm);
+    int y0 = (int)clampf(fy, 0.0f, hm), y1 = (int)clampf(fy + 1.0f, 0.0f, hm);
     float a = img[4 * ((size_t)y0 * W + x0) + ch], b = img[4 * ((size_t)y0 * W + x1) + ch];
     float c = img[4 * ((size_t)y1 * W + x0) + ch], d = img[4 * ((size_t)y1 * W + x1) + ch];
     float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - c, c);

@@ -185,3 +185,21 @@ def test_cu_range_stream_runs_the_path(sl, oracle):
     assert b"exceed" in L.slhip_last_error()
     with pytest.raises(ValueError):
         cu_partition_streams(0)
+
+
+def test_ssao_samples_behind_the_camera(sl, oracle, eng):
+    """Surfaces 0.11-0.2 m from the eye: part of the 0.1 m SSAO hemisphere lies behind the camera plane, the
+    perspective division of those samples overflows, and the z fetch is clamped to the edge texel on both
+    sides (float clamp before the integer conversion) -- geometry bit-exact, RGB within the usual bar."""
+    m = sl.Mesh(S.CUBE, physics=False)      # 2 m cube at the origin
+    scene = sl.Scene((160, 120))
+    scene.add_object(sl.Object(m))
+    scene.ambient_light = torch.tensor([0.3, 0.3, 0.3])
+    scene.manual_exposure = 1.0
+    # eye 0.13 m off the +x face, looking along the face at a grazing angle
+    scene.set_camera_look_at(torch.tensor([1.13, 0.0, 0.0]), torch.tensor([1.0, 0.6, 0.2]))
+    bufs, ref = both(eng, oracle, [scene])
+    assert_geometry_equal(bufs, ref)
+    assert_rgb_close(bufs, ref)
+    z = ref.cam_coord[0, :, :, 2]
+    assert (z[z > 0] < 0.2).any()          # the case is exercised: fragments closer than 0.2 m
