@@ -225,3 +225,23 @@ def test_c2_bench_workload_full_launch(sl, oracle):
     # the settle did something: most objects came to rest (a rolling can or a fresh redrop may still move)
     speed = np.linalg.norm(gpu[:hi]["lin_vel"][:, :3], axis=1)
     assert np.mean(speed < 0.05) > 0.7     # 0.82 over 96 such scenes (chaotic: 0.76-0.83 on these six)
+
+
+def test_c2_soak_distinct_scenes(sl, oracle):
+    """24 further C2 scenes (other seeds than the launch test), full 400-step settle, every body bit for bit:
+    exercises the pair cache, the warm-started and capped tilt runs and the size-ordered colouring on
+    many more contact configurations than the hand-built heaps."""
+    import bench
+    from stillleben_amd import physics, synthetic
+
+    meshes = synthetic.ycb_like_meshes(seed=0, tex_size=64)
+    scs = [bench.make_scene(sl, meshes, 77000 + i) for i in range(24)]
+    se = physics.settle_engine()
+    planes = [(physics.prepare_tabletop(s), physics.PLANE_HALF_Z) for s in scs]
+    srec, bodies = SB.build_settle_batch(scs, se.pool, planes)
+    prm = SB.default_params(tabletop=True)
+    gpu = se.run(srec, bodies.copy(), prm)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    oracle.settle(srec, ref, hulls, verts, prm)
+    assert_bodies_equal(gpu, ref)
