@@ -43,7 +43,8 @@ class HostPool:
         self.n_indices = 6
         self.n_tex_bytes = 0
         self.dirty = True
-        self._textures = {}  # id(array) -> (offset, w, h)
+        self._textures = {}  # (id(array), mips) -> (offset, w, h); _tex_refs pins the arrays so that ids stay unique
+        self._tex_refs = []
 
     def add_texture(self, rgba, mips=True):
         """Appends an RGBA8 image (row 0 = top) and, for 2D textures, its mip chain (include/slhip.h:
@@ -60,6 +61,7 @@ class HostPool:
             self.tex.append(lv.reshape(-1))
             self.n_tex_bytes += lv.size
         self._textures[key] = (off, a.shape[1], a.shape[0])
+        self._tex_refs.append(rgba)   # a collected array's id() may be handed to a new one: keep the keyed object alive
         self.dirty = True
         return self._textures[key]
 

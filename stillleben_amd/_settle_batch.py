@@ -74,6 +74,7 @@ class HullPool:
         self.hulls = []
         self.n_verts = 0
         self._ranges = {}
+        self._mesh_refs = []   # the keyed meshes, kept alive: id() of a collected mesh may be reused by a new one
         self.dirty = True
 
     def register(self, mesh):
@@ -105,6 +106,7 @@ class HullPool:
         br = f32((np.sqrt(((centers - bc) ** 2).sum(axis=1)) + radii).max())
         r = (begin, len(self.hulls), bc.astype(np.float32), br)
         self._ranges[key] = r
+        self._mesh_refs.append(mesh)
         self.dirty = True
         return r
 

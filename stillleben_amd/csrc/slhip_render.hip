@@ -544,7 +544,9 @@ struct MainTarget {
     {
         const float z = interp(l, t.z[0], t.z[1], t.z[2]);
         if (!(z >= 0.0f && z <= 1.0f)) return;
-        const unsigned long long key = ((unsigned long long)depth24(z) << 32) | prim;
+        const unsigned d24 = depth24(z);
+        if (d24 >= 0xFFFFFFu) return;   // GL_LESS against the cleared depth 1.0: a fragment AT the far plane loses (R6)
+        const unsigned long long key = ((unsigned long long)d24 << 32) | prim;
         unsigned long long* slot = vis + (size_t)py * W + px;
         // monotone pre-test only where the (rare, expensive) discard tests follow: keys only ever
         // decrease, so a stale read is conservative.  The plain path fires the atomic without

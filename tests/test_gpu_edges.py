@@ -203,3 +203,21 @@ def test_ssao_samples_behind_the_camera(sl, oracle, eng):
     assert_rgb_close(bufs, ref)
     z = ref.cam_coord[0, :, :, 2]
     assert (z[z > 0] < 0.2).any()          # the case is exercised: fragments closer than 0.2 m
+
+
+def test_fragment_at_the_far_plane_loses(sl, oracle, eng):
+    """Found by tools/soak_render.py (seed 610184): a background-plane fragment whose 24-bit depth rounds to
+    0xFFFFFF equals the cleared depth, and GL_LESS rejects it -- the visibility key must not accept it."""
+    import bench
+    from stillleben_amd import physics, synthetic
+
+    meshes = synthetic.ycb_like_meshes(seed=0, tex_size=64)
+    scene = bench.make_scene(sl, meshes, 610184)
+    physics.settle_batch([scene])
+    scene.choose_random_camera_pose()
+    scene.choose_random_light_direction()
+    mask = _abi.OUT_GT6 | _abi.OUT_CAM_COORD
+    bufs, ref = both(eng, oracle, [scene], mask=mask, ssao=False, shadows=False)
+    assert_geometry_equal(bufs, ref, mask=mask)
+    z = ref.cam_coord[0, :, :, 2]
+    assert z[(z < 2000.0)].max() > 9.9        # the far plane (10 m) is in view

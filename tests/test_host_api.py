@@ -380,3 +380,25 @@ def test_animator_interpolates_poses():
         sl.Animator([p1], 10)
     three = list(sl.Animator([p1, p2, p1], 10))                # keyframes at ticks 0, 5, 10
     assert torch.allclose(three[5], p2, atol=1e-6)
+
+
+def test_pools_pin_the_objects_their_caches_are_keyed_by():
+    """The texture cache of HostPool and the hull cache of HullPool are keyed by id(); a collected array's
+    id can be handed to a new object (found by the render soak: one object per scene drew another mesh's
+    texture), so the pools keep the keyed objects alive."""
+    import gc
+
+    from stillleben_amd._batch import HostPool
+
+    pool = HostPool()
+    seen = {}
+    for i in range(64):
+        tex = np.full((4, 4, 4), i, np.uint8)       # same shape every time: a freed block is reused at once
+        off, w, h = pool.add_texture(tex, mips=False)
+        assert off not in seen, "texture %d was given the pool slot of texture %d" % (i, seen[off])
+        seen[off] = i
+        del tex
+        gc.collect()
+    data = np.concatenate(pool.tex)
+    for off, i in seen.items():
+        assert (data[off:off + 64] == i).all()
