@@ -57,6 +57,9 @@ class HostPool:
         levels = [a]
         while mips and max(levels[-1].shape[0], levels[-1].shape[1]) > 1:
             levels.append(mip_down(levels[-1]))
+        if off + sum(lv.size for lv in levels) >= 1 << 32:
+            raise RuntimeError("texel pool would exceed 4 GiB (slhip_draw texture offsets are 32 bit): reuse Mesh objects "
+                               "instead of loading the same asset again -- every sl.Mesh registers its textures for good")
         for lv in levels:
             self.tex.append(lv.reshape(-1))
             self.n_tex_bytes += lv.size
