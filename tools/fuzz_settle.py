@@ -62,6 +62,12 @@ for k in range(N):
                 if rng.random() < 0.3:
                     o.linear_velocity = torch.tensor(rng.uniform(-2, 2, 3).astype(np.float32))
             planes.append((bool(rng.integers(2)), 0.04))
+        for o in scene._objects:                               # a few driven bodies (ManipulationSim's D6 joint)
+            if rng.random() < 0.04 and not o._static:
+                q = rng.standard_normal(4)
+                o._drive = {"flags": 1 | (int(rng.integers(8)) << 1), "target": rng.uniform(-0.3, 0.3, 3).astype(np.float32),
+                            "frame": (q / np.linalg.norm(q)).astype(np.float32), "stiffness": np.float32(rng.uniform(100, 900)),
+                            "damping": np.float32(rng.uniform(0.05, 2.0)), "force_limit": np.float32(rng.uniform(5, 80))}
         scs.append(scene)
     prm = SB.default_params(tabletop=bool(rng.integers(2)), frames=int(rng.choice([1, 3, 10, 25, 60, 100, 250])),
                             substeps=int(rng.choice([1, 2, 4])), dt=float(rng.choice([0.002, 0.005, 0.01])))
@@ -70,12 +76,16 @@ for k in range(N):
     hulls, verts = se.pool.arrays()
     ref = bodies.copy()
     oracle.settle(srec, ref, hulls, verts, prm)
+    ov_gpu = se.overlap(srec, bodies)                          # slhip_overlap_any on the initial state
+    ov_ref = oracle.overlap_any(srec, bodies, hulls, verts)
     diff = [f for f in fields if not np.array_equal(np.ascontiguousarray(gpu[f]).view(np.uint8), np.ascontiguousarray(ref[f]).view(np.uint8))]
     if os.environ.get("FUZZ_VERBOSE"):
         moved = np.abs(gpu["pose"] - bodies["pose"]).max(axis=1)
         print("seed %d: %d scenes, bodies %s, frames %d x %d dt %.3f: moved>1mm %.2f, max |v| %.2f, asleep %.2f" % (
             seed, len(scs), [len(s._objects) for s in scs], prm["frames"], prm["substeps"], prm["dt"],
             float((moved > 1e-3).mean()), float(np.abs(gpu["lin_vel"]).max()), float(((gpu["flags"] & 2) != 0).mean())))
+    if not np.array_equal(ov_gpu, ov_ref):
+        diff.append("overlap_any")
     if diff:
         bad += 1
         print("MISMATCH seed %d (%d scenes, bodies %s, frames %d x %d, dt %.3f, tabletop %d): %s" % (
