@@ -206,7 +206,7 @@ def test_ssao_samples_behind_the_camera(sl, oracle, eng):
 
 
 def test_fragment_at_the_far_plane_loses(sl, oracle, eng):
-    """Found by tools/soak_render.py (seed 610184): a background-plane fragment whose 24-bit depth rounds to
+    """Found by tests/soak/soak_render.py (seed 610184): a background-plane fragment whose 24-bit depth rounds to
     0xFFFFFF equals the cleared depth, and GL_LESS rejects it -- the visibility key must not accept it."""
     import bench
     from stillleben_amd import physics, synthetic
