@@ -34,8 +34,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=2048,
-                    help="scenes per GPU per step (one settle launch; 2048 = 256 CUs x 8 resident scenes)")
+    ap.add_argument("--batch", type=int, default=4096,
+                    help="scenes per GPU per step (one settle launch: two rounds of the 2048 resident scenes = 256 CUs x 8; the second round back-fills the tail of the first)")
     ap.add_argument("--render-chunk", type=int, default=128, help="scenes per render launch sequence")
     ap.add_argument("--settle-streams", type=int, default=3,
                     help="settle launches kept in flight: scenes settle in very different times, and a second "
