@@ -36,7 +36,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096,
                     help="scenes per GPU per step (one settle launch: two rounds of the 2048 resident scenes = 256 CUs x 8; the second round back-fills the tail of the first)")
-    ap.add_argument("--render-chunk", type=int, default=128, help="scenes per render launch sequence")
+    ap.add_argument("--render-chunk", type=int, default=None,
+                    help="scenes per render launch sequence (fewer, larger sequences: every kernel boundary is a chance for "
+                         "queued settle workgroups to take the freed SIMDs); default 512, 256 when the rendered chunks are "
+                         "all-gathered (N > 1: the [world, chunk, ...] staging ring grows with it)")
     ap.add_argument("--settle-streams", type=int, default=3,
                     help="settle launches kept in flight: scenes settle in very different times, and a second "
                          "launch on its own stream back-fills the CUs the tail of the first one leaves idle")
@@ -281,6 +284,8 @@ def main():
     meshes = synthetic.ycb_like_meshes(seed=0)
     pipe = Pipeline(sl, args.batch, not args.no_ssao, args.settle_cus, max(1, args.settle_streams))
     pipe.params = SB.default_params(tabletop=True)
+    if args.render_chunk is None:
+        args.render_chunk = 512 if world == 1 else 256
     pipe.render_chunk = args.render_chunk
     pipe.eng.L.slhip_timing_enable(1)
 
