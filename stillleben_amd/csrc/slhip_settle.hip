@@ -195,16 +195,25 @@ __device__ __forceinline__ v3 support(const Shape& s, const f3* __restrict__ hv,
         index = best;
         return add(m3_mul(s.R, V(q.x, q.y, q.z)), s.t);
     }
+    // the winner's slot within a batch is tracked as an inline constant (one v_cndmask per vertex) and the
+    // batch base once per batch; unsigned indices keep the address arithmetic in 32 bits until the final add
+    const unsigned last = (unsigned)(n - 1);
+    int best_base = 0, best_j = 0;
     for (int base = 0; base < n; base += 8) {
         float4 p[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) p[j] = s.g[min(base + j, n - 1)];
+        for (int j = 0; j < 8; ++j) p[j] = s.g[min((unsigned)(base + j), last)];
+        const float before = bd;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float dd = dot(V(p[j].x, p[j].y, p[j].z), dl);
-            if (dd > bd) { bd = dd; best = base + j; }
+            const bool win = dd > bd;
+            bd = win ? dd : bd;
+            best_j = win ? j : best_j;
         }
+        if (bd != before) best_base = base;   // a win strictly raises bd; without one best_j is untouched too
     }
+    best = best_base + best_j;
     const float4 q = s.g[best];
     index = best;
     return add(m3_mul(s.R, V(q.x, q.y, q.z)), s.t);
