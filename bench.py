@@ -256,8 +256,29 @@ def cpu_baseline(sl, meshes, scenes_per_thread, ssao, max_threads=32):
     }
 
 
+def respawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU,
+    exactly what the driver's `python -m torch.distributed.run --nproc-per-node N` does) and pass
+    rank 0's JSON line through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(respawn_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ.get("WORLD_SIZE")))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

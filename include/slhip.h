@@ -334,6 +334,14 @@ int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
                  slhip_body* d_bodies, const slhip_hull* d_hulls, const float* d_hull_verts,
                  const slhip_settle_params* params, void* d_scratch, uint64_t scratch_bytes,
                  void* stream);
+/* Per-scene outcome of the last slhip_settle that used `d_scratch` (synchronises `stream`): h_status[i]
+ * (may be NULL) = 0 when scene i was stepped, SLHIP_SETTLE_REFUSED_* when the kernel left it untouched
+ * because it exceeds the sizing hints; *h_n_refused counts those.  Returns -2 (and sets the error
+ * message) when any scene was refused -- a wrong hint must never pass silently.                       */
+#define SLHIP_SETTLE_REFUSED_BODIES 1u   /* more bodies than max_bodies_per_scene                      */
+#define SLHIP_SETTLE_REFUSED_HULLS  2u   /* more hulls than max_hulls_per_scene, or > 1024 in one body */
+int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_status, uint32_t* h_n_refused,
+                        void* stream);
 /* scratch for n_scenes scenes: accumulators + the per-scene pair cache, sized from the hints in
  * `params` (NULL or zero hints: the worst case, SLHIP_PAIR_CACHE_MAX_HULLS^2 entries per scene)   */
 int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out);
@@ -442,6 +450,118 @@ int slhip_device_init(int device_index);
  * hipStream_t usable as the `stream` argument of every call above.                              */
 int slhip_stream_create_cu_range(uint32_t first_cu, uint32_t n_cus, void** stream_out);
 int slhip_stream_destroy(void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scene synthesis on the device: the host work either side of the settle, moved into HBM.
+ *
+ * In the reference every scene is built by host C++ behind pybind11: the tabletop set-up of
+ * Scene::simulateTableTopScene (src/scene.cpp:612-678: plane yaw, the stack of randomly oriented
+ * objects), after the settle Scene::chooseRandomCameraPose (scene.cpp:472-610) and
+ * chooseRandomLightDirection (scene.cpp:453-470), and per render the shadow matrices
+ * (render_pass.cpp:69-211) and the per-drawable uniforms (render_pass.cpp:534-621,
+ * render_shader.cpp:233-265).  For a batch that is ~4 ms of host time per scene against 0.15 ms of
+ * device time, so a batch is described ONCE by an asset table (one record per sl.Mesh in use) and two
+ * kernels write the records the settle and render kernels consume -- nothing crosses PCIe per scene.
+ *
+ * Randomness: Philox4x32-10 keyed by (seed_lo, seed_hi), counter (scene id, stream, index,
+ * 0x51DE5EED); uniform = ((x >> 8) + 0.5) * 2^-24; normals by Box-Muller on deterministic log /
+ * sin / cos polynomials (the DISTRIBUTIONS of the reference are the contract, its libstdc++ streams are
+ * not reproducible: it seeds from std::random_device, scene.cpp:147-148).
+ * ------------------------------------------------------------------------------------------- */
+
+/* One mesh class: what sl.Mesh (+ the defaults of sl.Object) contributes to a scene. */
+typedef struct {
+    float mesh_to_object[16];   /* Mesh::pretransform, row-major                                     */
+    float bbox_min[4], bbox_max[4]; /* Mesh::bbox() incl. quirk q6 (mesh.cpp:1075-1081), object frame  */
+    float com[4];               /* centre of mass (object frame) at the default density               */
+    float inv_inertia[12];      /* inverse inertia about the COM, object axes, rows padded to 4       */
+    float mass;                 /* density 1000 (object.h:287) x hull volumes                         */
+    float mu_s, mu_d, restitution;  /* default material 0.3 / 0.2 / 0.1 (context.cpp:250-252)       */
+    float bsphere[4];           /* bounding sphere of all hulls                                       */
+    uint32_t hull_begin, hull_end;  /* range in the hull table handed to slhip_settle                */
+    uint32_t draw_begin, draw_count; /* sub-mesh draw templates of this class in d_templates          */
+    uint32_t n_verts;           /* vertices of the mesh (every draw of the class indexes all of them) */
+    uint32_t n_chunks;          /* sum over the class's draws of ceil(n_tris / SLHIP_CHUNK_TRIS)      */
+    uint32_t _pad[2];
+} slhip_asset;                  /* 224 bytes */
+
+#define SLHIP_SYNTH_SAMPLE_DISTINCT 1u  /* draw each scene's n_objects classes without replacement
+                                           (examples/ycb.py:60: random.sample(meshes, 20)); needs
+                                           n_objects <= n_assets <= SLHIP_SYNTH_MAX_ASSETS; otherwise
+                                           d_asset_ids names every object's class                     */
+#define SLHIP_SYNTH_RANDOM_PBR      2u  /* metallic, roughness ~ U(0,1) per object (examples/ycb.py:63-64:
+                                           obj.metallic / obj.roughness); otherwise the file's values   */
+#define SLHIP_SYNTH_SHADOWS         4u  /* fill shadow_mat of the active light (render_pass.cpp:131-211) */
+#define SLHIP_SYNTH_MAX_ASSETS   1024u
+#define SLHIP_SYNTH_MAX_OBJECTS    64u  /* == SLHIP_MAX_BODIES */
+
+typedef struct {
+    uint32_t n_scenes, n_objects, n_assets, flags;
+    uint32_t seed_lo, seed_hi;
+    uint32_t scene_id_base;     /* global id of scene 0: shards and steps draw disjoint random streams  */
+    uint32_t render_chunk;      /* scenes per slhip_render call: `scene`, `draw`, draw_begin/end and
+                                   clip_base in the written records are relative to the first scene of
+                                   the call's chunk (scene s belongs to chunk s / render_chunk)         */
+    uint32_t max_draws_per_scene;      /* record strides: scene s owns draws [s*max_draws, ...), chunks */
+    uint32_t max_chunks_per_scene;     /* [s*max_chunks, ...) and clip vertices [s*max_clip, ...)        */
+    uint32_t max_clip_verts_per_scene; /* (chunk-relative); unused slots are written with zero counts   */
+    float plane_z;              /* top of the table box: BOX_HALF_EXTENTS.z = 0.04 (scene.cpp:638)       */
+    float proj[16];             /* Scene::projectionMatrix, row-major (scene.cpp:222-253)                */
+    float proj_inv[16];         /* its inverse (render_pass.cpp:73)                                      */
+    float plane_size[2];        /* Scene::backgroundPlaneSize; 0,0 = no plane drawn                      */
+    float manual_exposure;
+    float _pad0;
+    float light_color[4];       /* light 0; its direction is drawn per scene (scene.cpp:453-470)         */
+    float ambient[4];
+} slhip_synth_params;           /* 224 bytes */
+
+typedef struct {
+    uint32_t asset;             /* class of the object                                                  */
+    uint32_t instance_index;    /* 1 + position in the scene (scene.cpp:285-287)                         */
+    float metallic, roughness;  /* per-object override, < 0 = the file's value (render_shader.cpp:355-377) */
+} slhip_synth_object;
+
+typedef struct {
+    float plane_pose[16];       /* Scene::backgroundPlanePose set by the tabletop set-up (scene.cpp:650-657) */
+    float camera_pose[16];      /* out of slhip_synth_place: Scene::cameraPose                            */
+} slhip_synth_scene;
+
+/* Tabletop set-up of every scene of the batch (scene.cpp:612-678): d_bodies [n_scenes * n_objects],
+ * d_settle_scenes [n_scenes] (has_plane = 1), d_objects [n_scenes * n_objects], d_scenes [n_scenes].
+ * d_asset_ids: u16 [n_scenes * n_objects] or NULL with SLHIP_SYNTH_SAMPLE_DISTINCT.                   */
+int slhip_synth_stage(const slhip_synth_params* params, const slhip_asset* d_assets, const uint16_t* d_asset_ids,
+                      slhip_body* d_bodies, slhip_settle_scene* d_settle_scenes, slhip_synth_object* d_objects,
+                      slhip_synth_scene* d_scenes, void* stream);
+
+/* After the settle: camera pose, light direction, shadow matrix, and the slhip_scene / slhip_draw /
+ * slhip_chunk records of the batch (strides from `params`), ready for slhip_render chunk by chunk.
+ * d_templates: the sub-mesh draws of every class with all static fields filled (materials, textures,
+ * vertex / index ranges, class index); transforms, ids and bases are written here.                    */
+int slhip_synth_place(const slhip_synth_params* params, const slhip_asset* d_assets, const slhip_draw* d_templates,
+                      const slhip_body* d_bodies, const slhip_synth_object* d_objects, slhip_synth_scene* d_scenes,
+                      slhip_scene* d_out_scenes, slhip_draw* d_out_draws, slhip_chunk* d_out_chunks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU exchange: scenes are independent, every rank (one process per GPU, as
+ * the reference runs it: python/src/py_context.cpp:34-52) settles and renders its own shard; the one
+ * exchange step is the all-gather of rendered batches, RCCL over xGMI.  RCCL is bound at run time
+ * (the copy the process already maps -- PyTorch's -- else librccl.so.1 of the ROCm install).
+ * ------------------------------------------------------------------------------------------- */
+#define SLHIP_COMM_ID_BYTES 128   /* == NCCL_UNIQUE_ID_BYTES */
+typedef struct slhip_comm slhip_comm;
+/* Rank 0 draws an id and hands it to the other ranks out of band (the host layer uses the
+ * torch.distributed store; a file or MPI works as well).                                            */
+int slhip_comm_unique_id(uint8_t id_out[SLHIP_COMM_ID_BYTES]);
+/* Collective over all ranks; binds the communicator to the calling thread's current HIP device.     */
+int slhip_comm_create(const uint8_t id[SLHIP_COMM_ID_BYTES], int n_ranks, int rank, slhip_comm** comm_out);
+int slhip_comm_destroy(slhip_comm* comm);
+int slhip_comm_info(const slhip_comm* comm, int* n_ranks, int* rank);
+/* d_recv (n_ranks * bytes) receives every rank's d_send (bytes) in rank order; asynchronous on `stream`. */
+int slhip_allgather(slhip_comm* comm, const void* d_send, void* d_recv, uint64_t bytes, void* stream);
+/* The buffers of one rendered chunk (rgb, coord, class, instance, normals) in ONE fused RCCL group:
+ * d_recv[i] (n_ranks * bytes[i]) <- all ranks' d_send[i].                                           */
+int slhip_allgather_group(slhip_comm* comm, uint32_t n_buffers, const void* const* d_send, void* const* d_recv,
+                          const uint64_t* bytes, void* stream);
 
 #ifdef __cplusplus
 }

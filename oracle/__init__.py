@@ -272,3 +272,73 @@ def vertex_backward(rgb, coord, inst, bary, grad_img, P, poses, obj_inst):
     L.slref_vertex_backward(_p(rgb), _p(coord), _p(inst), _p(bary), _p(grad_img), _p(P), _p(poses), _p(obj_inst), len(poses), H, W,
                             _p(gv), _p(gc))
     return gv, gc
+
+
+def synth_stage(params, assets, asset_ids=None):
+    """oracle/synth_ref.c: tabletop set-up of a batch.  Returns (bodies, settle_scenes, objects, scenes)."""
+    from stillleben_amd import _abi
+    from stillleben_amd import _settle_batch as SB
+
+    L = lib()
+    p = np.array(params)
+    n, m = int(p["n_scenes"]), int(p["n_objects"])
+    bodies = np.zeros(n * m, dtype=SB.BODY_DTYPE)
+    ss = np.zeros(n, dtype=SB.SETTLE_SCENE_DTYPE)
+    objs = np.zeros(n * m, dtype=_abi.SYNTH_OBJECT_DTYPE)
+    scs = np.zeros(n, dtype=_abi.SYNTH_SCENE_DTYPE)
+    assets = np.ascontiguousarray(assets)
+    ids = None if asset_ids is None else np.ascontiguousarray(asset_ids, dtype=np.uint16)
+    L.slref_synth_stage.argtypes = [C.c_void_p] * 7
+    st = L.slref_synth_stage(_p(p), _p(assets), _p(ids) if ids is not None else None, _p(bodies), _p(ss), _p(objs), _p(scs))
+    if st != 0:
+        raise RuntimeError("slref_synth_stage failed: %d" % st)
+    return bodies, ss, objs, scs
+
+
+def synth_place(params, assets, templates, bodies, objects, scenes):
+    """oracle/synth_ref.c: camera / light / shadow matrix / render records.  `scenes` gets camera_pose filled.
+    Returns (scene_records, draw_records, chunk_records)."""
+    from stillleben_amd import _abi
+
+    L = lib()
+    p = np.array(params)
+    n = int(p["n_scenes"])
+    srec = np.zeros(n, dtype=_abi.SCENE_DTYPE)
+    drec = np.zeros(n * int(p["max_draws_per_scene"]), dtype=_abi.DRAW_DTYPE)
+    crec = np.zeros(n * int(p["max_chunks_per_scene"]), dtype=_abi.CHUNK_DTYPE)
+    assets, templates = np.ascontiguousarray(assets), np.ascontiguousarray(templates)
+    bodies, objects = np.ascontiguousarray(bodies), np.ascontiguousarray(objects)
+    assert scenes.flags["C_CONTIGUOUS"]
+    L.slref_synth_place.argtypes = [C.c_void_p] * 9
+    st = L.slref_synth_place(_p(p), _p(assets), _p(templates), _p(bodies), _p(objects), _p(scenes), _p(srec), _p(drec), _p(crec))
+    if st != 0:
+        raise RuntimeError("slref_synth_place failed: %d" % st)
+    return srec, drec, crec
+
+
+def synth_draws(params, scene):
+    """The raw random draws of one scene: dict(yaw, azimuth, elevation, light_normals[3], quat[n,4], pbr[n,2])."""
+    L = lib()
+    p = np.array(params)
+    m = int(p["n_objects"])
+    out = np.zeros(6 + 6 * m, np.float32)
+    L.slref_synth_draws.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.slref_synth_draws(_p(p), scene, _p(out))
+    per = out[6:].reshape(m, 6)
+    return {"yaw": out[0], "azimuth": out[1], "elevation": out[2], "light_normals": out[3:6].copy(),
+            "quat": per[:, :4].copy(), "pbr": per[:, 4:].copy()}
+
+
+def det_logf(x):
+    L = lib()
+    L.slref_det_logf.restype = C.c_float
+    L.slref_det_logf.argtypes = [C.c_float]
+    return L.slref_det_logf(float(x))
+
+
+def det_sincosf(x):
+    L = lib()
+    L.slref_det_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    s, c = C.c_float(), C.c_float()
+    L.slref_det_sincosf(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value

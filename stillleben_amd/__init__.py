@@ -19,12 +19,13 @@ from .extras import (Animator, ImageLoader, ImageSaver, LightMap, MeshCache, Tex
                      Viewer, view, render_debug_image)
 from .manipulation_sim import ManipulationSim  # noqa: F401
 from .job_queue import JobQueue  # noqa: F401
+from .scene_batch import AssetTable, SceneBatch  # noqa: F401  (additive: the batch dimension of the GPU path)
 from . import camera_model, diff, losses, extension, profiling  # noqa: F401
 
 __all__ = [
     'init', 'init_cuda', 'render_debug_image', 'Animator', 'ImageLoader', 'ImageSaver', 'LightMap',
     'Mesh', 'MeshCache', 'Object', 'Range3D', 'RenderPass', 'RenderPassResult', 'Scene', 'Texture',
-    'Texture2D', 'Viewer', 'view', 'ManipulationSim', 'JobQueue',
+    'Texture2D', 'Viewer', 'view', 'ManipulationSim', 'JobQueue', 'AssetTable', 'SceneBatch',
     'camera_model', 'diff', 'extension', 'losses', 'quat_to_matrix', 'matrix_to_quat',
 ]
 

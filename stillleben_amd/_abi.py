@@ -37,6 +37,7 @@ OUT_ALL = 0xFF
 OUT_GT6 = 0x1F
 RENDER_SSAO = 0x100
 RENDER_SHADOWS = 0x200
+COMM_ID_BYTES = 128
 
 
 class MeshPool(C.Structure):
@@ -175,6 +176,31 @@ CAMERA_DTYPE = np.dtype([
 ])
 assert CAMERA_DTYPE.itemsize == 268
 
+# slhip_asset / slhip_synth_params / slhip_synth_object / slhip_synth_scene (include/slhip.h)
+ASSET_DTYPE = np.dtype([
+    ("mesh_to_object", np.float32, (16,)), ("bbox_min", np.float32, (4,)), ("bbox_max", np.float32, (4,)),
+    ("com", np.float32, (4,)), ("inv_inertia", np.float32, (12,)), ("mass", np.float32), ("mu_s", np.float32),
+    ("mu_d", np.float32), ("restitution", np.float32), ("bsphere", np.float32, (4,)), ("hull_begin", np.uint32),
+    ("hull_end", np.uint32), ("draw_begin", np.uint32), ("draw_count", np.uint32), ("n_verts", np.uint32),
+    ("n_chunks", np.uint32), ("_pad", np.uint32, (2,)),
+])
+assert ASSET_DTYPE.itemsize == 224
+SYNTH_PARAMS_DTYPE = np.dtype([
+    ("n_scenes", np.uint32), ("n_objects", np.uint32), ("n_assets", np.uint32), ("flags", np.uint32),
+    ("seed_lo", np.uint32), ("seed_hi", np.uint32), ("scene_id_base", np.uint32), ("render_chunk", np.uint32),
+    ("max_draws_per_scene", np.uint32), ("max_chunks_per_scene", np.uint32), ("max_clip_verts_per_scene", np.uint32),
+    ("plane_z", np.float32), ("proj", np.float32, (16,)), ("proj_inv", np.float32, (16,)), ("plane_size", np.float32, (2,)),
+    ("manual_exposure", np.float32), ("_pad0", np.float32), ("light_color", np.float32, (4,)), ("ambient", np.float32, (4,)),
+])
+assert SYNTH_PARAMS_DTYPE.itemsize == 224
+SYNTH_OBJECT_DTYPE = np.dtype([("asset", np.uint32), ("instance_index", np.uint32), ("metallic", np.float32),
+                               ("roughness", np.float32)])
+SYNTH_SCENE_DTYPE = np.dtype([("plane_pose", np.float32, (16,)), ("camera_pose", np.float32, (16,))])
+SYNTH_SAMPLE_DISTINCT = 1
+SYNTH_RANDOM_PBR = 2
+SYNTH_SHADOWS = 4
+SYNTH_MAX_ASSETS = 1024
+
 # SLHIP_LIB selects another build of the same library (developer A/B runs); there is no fallback
 _LIB_PATH = os.environ.get("SLHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libslhip.so")
 
@@ -218,6 +244,7 @@ def lib():
     L.slhip_diff_vertex_backward.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     L.slhip_settle.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint64, C.c_void_p]
+    L.slhip_settle_status.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]
     L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
     L.slhip_overlap_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.slhip_light_map_floats.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint64 * 4)]
@@ -225,6 +252,14 @@ def lib():
     L.slhip_camera_model.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.slhip_stream_create_cu_range.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.slhip_stream_destroy.argtypes = [C.c_void_p]
+    L.slhip_synth_stage.argtypes = [C.c_void_p] * 8
+    L.slhip_synth_place.argtypes = [C.c_void_p] * 10
+    L.slhip_comm_unique_id.argtypes = [C.c_void_p]
+    L.slhip_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.slhip_comm_destroy.argtypes = [C.c_void_p]
+    L.slhip_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.slhip_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.slhip_allgather_group.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _LIB = L
     return L
 

@@ -171,6 +171,64 @@ def scene_record(scene, rec, shadow_mats=None):
             rec["shadow_mat"][i] = shadow_mats[i].reshape(-1)
 
 
+def object_draws(obj, pool):
+    """One slhip_draw per sub-mesh of the object: what RenderShader::setTransformations / setMaterial /
+    setClassIndex / setInstanceIndex upload for it (render_pass.cpp:583-621, render_shader.cpp:233-265,
+    :326-417).  `scene` and `prim_base` are left to the caller."""
+    out = []
+    mesh = obj._mesh
+    slot = pool.register(mesh)
+    m2o = mesh._pretransform
+    o2w = obj._pose
+    nm = np.zeros((3, 4), np.float32)
+    nm[:, :3] = M.normal_matrix((o2w @ m2o).astype(np.float32))
+    for sm in mesh._data.submeshes:
+        mat = mesh._data.materials[sm.material]
+        d = np.zeros((), dtype=_abi.DRAW_DTYPE)
+        d["mesh_to_object"] = m2o.reshape(-1)
+        d["object_to_world"] = o2w.reshape(-1)
+        d["normal_to_world"] = nm.reshape(-1)
+        d["base_color"] = mat.base_color if obj._color is None or not obj._force_color else obj._color
+        d["emissive"][:3] = mat.emissive
+        d["alpha_cutoff"] = 0.5  # render_shader.cpp:382
+        d["metallic"], d["roughness"] = _effective_material(mat, obj)
+        d["class_index"] = mesh._class_index
+        d["instance_index"] = obj._instance_index
+        flags = _abi.DRAW_CASTS_SHADOW if obj._casts_shadows else 0
+        if mat.base_texture is not None:
+            flags |= _abi.DRAW_HAS_BASE_TEX
+            if slot.tex_alpha[mat.base_texture]:
+                flags |= _abi.DRAW_ALPHA_TEST
+            d["tex_offset"] = slot.tex_offsets[mat.base_texture]
+            d["tex_w"], d["tex_h"] = slot.tex_sizes[mat.base_texture]
+            d["tex_sampler"][0] = slot.tex_samplers[mat.base_texture]
+        for k, (attr, field, bit) in enumerate((("normal_texture", "normal_tex", _abi.DRAW_HAS_NORMAL_TEX),
+                                                ("mr_texture", "mr_tex", _abi.DRAW_HAS_MR_TEX),
+                                                ("occlusion_texture", "occlusion_tex", _abi.DRAW_HAS_OCCLUSION_TEX),
+                                                ("emissive_texture", "emissive_tex", _abi.DRAW_HAS_EMISSIVE_TEX))):
+            ti = getattr(mat, attr, None)
+            if ti is not None:
+                flags |= bit
+                d[field] = (slot.tex_offsets[ti],) + tuple(slot.tex_sizes[ti])
+                d["tex_sampler"][k + 1] = slot.tex_samplers[ti]
+        st = obj._sticker_texture
+        if st is not None and obj._sticker_range is not None:
+            # render_pass.cpp:601-606: projection + range per object, the rectangle texture if one is set
+            off, w, h = pool.add_texture(st._rgba, mips=False)    # rectangle texture: one level
+            flags |= _abi.DRAW_HAS_STICKER
+            d["sticker_tex"] = (off, w, h)
+            d["sticker_projection"] = obj.sticker_view_projection().reshape(-1)
+            r = np.asarray(obj._sticker_range, dtype=np.float32)   # min.x, min.y, max.x, max.y
+            d["sticker_range"] = (r[0], r[1], max(f32(1e-6), r[2] - r[0]), max(f32(1e-6), r[3] - r[1]))
+        d["flags"] = flags
+        d["vtx_base"] = slot.vtx_base
+        d["idx_base"] = slot.idx_base + sm.first_index
+        d["n_tris"] = sm.n_indices // 3
+        d["n_verts"] = slot.n_vertices
+        out.append(d)
+    return out
+
+
 def build_batch(scenes, pool, predicate=None, with_shadows=True):
     """Returns (scene_records, draw_records, chunk_records) as numpy structured arrays."""
     from . import _shadow
@@ -216,57 +274,10 @@ def build_batch(scenes, pool, predicate=None, with_shadows=True):
             prim += 2
             draws.append(d)
         for obj in objs:
-            mesh = obj._mesh
-            slot = pool.register(mesh)
-            m2o = mesh._pretransform
-            o2w = obj._pose
-            nm = np.zeros((3, 4), np.float32)
-            nm[:, :3] = M.normal_matrix((o2w @ m2o).astype(np.float32))
-            for sm in mesh._data.submeshes:
-                mat = mesh._data.materials[sm.material]
-                d = np.zeros((), dtype=_abi.DRAW_DTYPE)
-                d["mesh_to_object"] = m2o.reshape(-1)
-                d["object_to_world"] = o2w.reshape(-1)
-                d["normal_to_world"] = nm.reshape(-1)
-                d["base_color"] = mat.base_color if obj._color is None or not obj._force_color else obj._color
-                d["emissive"][:3] = mat.emissive
-                d["alpha_cutoff"] = 0.5  # render_shader.cpp:382
-                d["metallic"], d["roughness"] = _effective_material(mat, obj)
-                d["class_index"] = mesh._class_index
-                d["instance_index"] = obj._instance_index
-                flags = _abi.DRAW_CASTS_SHADOW if obj._casts_shadows else 0
-                if mat.base_texture is not None:
-                    flags |= _abi.DRAW_HAS_BASE_TEX
-                    if slot.tex_alpha[mat.base_texture]:
-                        flags |= _abi.DRAW_ALPHA_TEST
-                    d["tex_offset"] = slot.tex_offsets[mat.base_texture]
-                    d["tex_w"], d["tex_h"] = slot.tex_sizes[mat.base_texture]
-                    d["tex_sampler"][0] = slot.tex_samplers[mat.base_texture]
-                for k, (attr, field, bit) in enumerate((("normal_texture", "normal_tex", _abi.DRAW_HAS_NORMAL_TEX),
-                                                        ("mr_texture", "mr_tex", _abi.DRAW_HAS_MR_TEX),
-                                                        ("occlusion_texture", "occlusion_tex", _abi.DRAW_HAS_OCCLUSION_TEX),
-                                                        ("emissive_texture", "emissive_tex", _abi.DRAW_HAS_EMISSIVE_TEX))):
-                    ti = getattr(mat, attr, None)
-                    if ti is not None:
-                        flags |= bit
-                        d[field] = (slot.tex_offsets[ti],) + tuple(slot.tex_sizes[ti])
-                        d["tex_sampler"][k + 1] = slot.tex_samplers[ti]
-                st = obj._sticker_texture
-                if st is not None and obj._sticker_range is not None:
-                    # render_pass.cpp:601-606: projection + range per object, the rectangle texture if one is set
-                    off, w, h = pool.add_texture(st._rgba, mips=False)    # rectangle texture: one level
-                    flags |= _abi.DRAW_HAS_STICKER
-                    d["sticker_tex"] = (off, w, h)
-                    d["sticker_projection"] = obj.sticker_view_projection().reshape(-1)
-                    r = np.asarray(obj._sticker_range, dtype=np.float32)   # min.x, min.y, max.x, max.y
-                    d["sticker_range"] = (r[0], r[1], max(f32(1e-6), r[2] - r[0]), max(f32(1e-6), r[3] - r[1]))
-                d["flags"] = flags
-                d["vtx_base"] = slot.vtx_base
-                d["idx_base"] = slot.idx_base + sm.first_index
-                d["n_tris"] = sm.n_indices // 3
+            for d in object_draws(obj, pool):
                 d["prim_base"] = prim
-                d["scene"], d["n_verts"] = si, slot.n_vertices
-                prim += sm.n_indices // 3
+                d["scene"] = si
+                prim += int(d["n_tris"])
                 draws.append(d)
         srec[si]["draw_end"] = len(draws)
         srec[si]["n_prims"] = prim

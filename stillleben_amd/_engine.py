@@ -128,21 +128,29 @@ class Engine:
 
     def render_records(self, srec, drec, crec, W, H, mask=_abi.OUT_ALL, ssao=True, shadows=True, depth_peel=None,
                        buffers=None):
-        """Renders a batch described by prebuilt slhip_scene / slhip_draw / slhip_chunk records."""
-        B = len(srec)
+        """Renders a batch described by prebuilt slhip_scene / slhip_draw / slhip_chunk records (host arrays)."""
+        d_s, d_d, d_c = self.upload_records(srec), self.upload_records(drec), self.upload_records(crec)
+        n_clip = int(drec["n_verts"].sum()) if len(drec) else 0
+        buffers = self.render_device(d_s, d_d, d_c, len(srec), len(drec), len(crec), n_clip, W, H, mask, ssao, shadows,
+                                     depth_peel, buffers)
+        buffers._keepalive += (d_s, d_d, d_c)   # alive until the stream has consumed them
+        return buffers
+
+    def render_device(self, d_s, d_d, d_c, B, n_draws, n_chunks, n_clip, W, H, mask=_abi.OUT_ALL, ssao=True, shadows=True,
+                      depth_peel=None, buffers=None):
+        """slhip_render on records that already live in HBM (device tensors or raw device addresses):
+        `n_clip` = clip-position slots the draws' clip_base + n_verts ranges span."""
         want_rgb = bool(mask & _abi.OUT_RGB)
         ssao = ssao and want_rgb
         shadows = shadows and want_rgb
         if ssao:
             mask |= _abi.OUT_CAM_COORD | _abi.OUT_NORMALS
         pool = self.pool_abi()
-        d_s, d_d, d_c = self.upload_records(srec), self.upload_records(drec), self.upload_records(crec)
         if buffers is None or (buffers.B, buffers.H, buffers.W, buffers.mask) != (B, H, W, mask):
             buffers = RenderBuffers(self.device, B, H, W, mask)
         out = buffers.abi()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         scratch, keep = self.scratch(B, H, W, want_rgb, ssao, shadows, stream)
-        n_clip = int(drec["n_verts"].sum()) if len(drec) else 0
         planes = 1 + (_abi.NUM_LIGHTS if shadows else 0)
         need = max(16, n_clip * planes * 16)
         clips = self.__dict__.setdefault("_clips", {})
@@ -151,10 +159,13 @@ class Engine:
         scratch.d_clip = _ptr(clips[stream])
         scratch.n_clip_verts = n_clip
         flags = mask | (_abi.RENDER_SSAO if ssao else 0) | (_abi.RENDER_SHADOWS if shadows else 0)
+
+        def addr(t):
+            return C.c_void_p(t) if isinstance(t, int) else _ptr(t)
+
         with torch.cuda.device(self.device):
-            st = self.L.slhip_render(C.byref(pool), _ptr(d_s), _ptr(d_d), _ptr(d_c), B, len(drec), len(crec), W, H, flags,
+            st = self.L.slhip_render(C.byref(pool), addr(d_s), addr(d_d), addr(d_c), B, n_draws, n_chunks, W, H, flags,
                                      _ptr(depth_peel), C.byref(out), C.byref(scratch), C.c_void_p(stream))
         _abi.check(st, "slhip_render")
-        # keep the record tensors alive until the stream has consumed them
-        buffers._keepalive = (d_s, d_d, d_c, keep)
+        buffers._keepalive = (keep,)
         return buffers

@@ -319,10 +319,10 @@ __global__ __launch_bounds__(256) void k_vertex_xform(slhip_mesh_pool pool, cons
                                                       const slhip_draw* __restrict__ draws, float4* __restrict__ clip,
                                                       unsigned n_clip_verts, int with_lights)
 {
-    const slhip_draw* dr = draws + blockIdx.y;
+    const slhip_draw* dr = draws + blockIdx.x;
     const unsigned nv = dr->n_verts;
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if ((blockIdx.x * 4 + wave) * 64 >= nv) return;
+    if ((blockIdx.y * 4 + wave) * 64 >= nv) return;
     const slhip_scene* sc = scenes + dr->scene;
     // composite matrices (wave-uniform inputs; every lane evaluates the same chains)
     float T1[16], T2[16], M[16];
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_vertex_xform(slhip_mesh_pool pool, cons
     }
     const float* pos = pool.d_pos + 4 * (size_t)dr->vtx_base;
     // 64 vertices per wave and pass = 4 MFMA batches; grid-stride over the draw's vertices
-    for (unsigned first = (blockIdx.x * 4 + wave) * 64; first < nv; first += gridDim.x * 256)
+    for (unsigned first = (blockIdx.y * 4 + wave) * 64; first < nv; first += gridDim.y * 256)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const unsigned v0 = first + 16 * b;
@@ -1635,12 +1635,12 @@ __global__ __launch_bounds__(256) void k_tonemap(const slhip_scene* __restrict__
 __global__ __launch_bounds__(256) void k_clear_shadow(const slhip_scene* __restrict__ scenes, unsigned* __restrict__ shadow,
                                                       int S)
 {
-    const unsigned scene = blockIdx.y / SLHIP_NUM_LIGHTS, light = blockIdx.y % SLHIP_NUM_LIGHTS;
+    const unsigned scene = blockIdx.x / SLHIP_NUM_LIGHTS, light = blockIdx.x % SLHIP_NUM_LIGHTS;
     if (!light_active(scenes + scene, (int)light)) return;
-    uint4* p = reinterpret_cast<uint4*>(shadow + (size_t)blockIdx.y * S * S);
+    uint4* p = reinterpret_cast<uint4*>(shadow + (size_t)blockIdx.x * S * S);
     const size_t n4 = (size_t)S * S / 4;
     const uint4 v = make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = v;
+    for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.y * 256) p[i] = v;
 }
 
 bool g_ssao_tables_uploaded[16] = {};
@@ -1778,7 +1778,7 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     }
     // vertex transform on the matrix cores: camera clip + (if shadows) the three light clips
     if (n_chunks > 0) {
-        k_vertex_xform<<<dim3(32, n_draws), 256, 0, stream>>>(*pool, d_scenes, d_draws,
+        k_vertex_xform<<<dim3(n_draws, 32), 256, 0, stream>>>(*pool, d_scenes, d_draws,
                                                                       reinterpret_cast<float4*>(scratch->d_clip),
                                                                       scratch->n_clip_verts, shadows ? 1 : 0);
         SLHIP_LAUNCH_CHECK();
@@ -1786,7 +1786,7 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     // shadow pass
     if (shadows && n_chunks > 0) {
         mark(0, stream);
-        k_clear_shadow<<<dim3(64, n_scenes * SLHIP_NUM_LIGHTS), 256, 0, stream>>>(
+        k_clear_shadow<<<dim3(n_scenes * SLHIP_NUM_LIGHTS, 64), 256, 0, stream>>>(
             d_scenes, reinterpret_cast<unsigned*>(scratch->d_shadow), S);
         SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
         k_shadow_raster<<<n_chunks, 256, 0, stream>>>(

@@ -16,6 +16,7 @@
 // Only + - * / sqrt and explicit fmaf are used and every reduction has a fixed order, so the
 // result is bit-identical to oracle/settle_ref.c (the parity contract) for any lane count.
 #include "slhip_common.h"
+#include <vector>
 #include <cstdlib>
 
 namespace {
@@ -136,12 +137,12 @@ struct RawContacts {
 };
 
 #ifdef SLHIP_SETTLE_PROFILE
-struct ProfScratch { unsigned long long cycles[16]; unsigned long long counts[16]; };
+struct ProfScratch { unsigned long long status; unsigned long long cycles[16]; unsigned long long counts[16]; };
 #define PROF_T0() unsigned long long _pt = wall_clock64()
 #define PROF(i) do { unsigned long long _n = wall_clock64(); if (threadIdx.x == 0) X.cycles[i] += _n - _pt; _pt = _n; } while (0)
 #define PROF_COUNT(i, v) do { if (threadIdx.x == 0) X.counts[i] += (v); } while (0)
 #else
-struct ProfScratch { unsigned long long unused; };
+struct ProfScratch { unsigned long long status; };   // per scene: 0 = stepped, else SLHIP_SETTLE_REFUSED_*
 #define PROF_T0()
 #define PROF(i)
 #define PROF_COUNT(i, v)
@@ -1278,7 +1279,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
     const int lane = threadIdx.x;
     const float dt = prm.dt;
-    if (nb > L.nb_cap) return;  // host sizing error: refuse rather than corrupt LDS
+    if (nb > L.nb_cap) {  // host sizing error: refuse rather than corrupt LDS, and say so (slhip_settle_status)
+        if (lane == 0) prof_all[blockIdx.x].status = SLHIP_SETTLE_REFUSED_BODIES;
+        return;
+    }
+    if (lane == 0) prof_all[blockIdx.x].status = 0;
 
     // ---- prologue (once per settle): local hull table, hull vertices into LDS ----
     // serial over bodies/hulls (<= a few hundred), lanes copy the vertices
@@ -1314,7 +1319,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (!fits) break;
         }
         if (lane == 0) body_lh[nb] = n_lh;
-        if (!fits) return;  // more hulls than the host sized for
+        if (!fits) {  // more hulls than the host sized for
+            if (lane == 0) prof_all[blockIdx.x].status = SLHIP_SETTLE_REFUSED_HULLS;
+            return;
+        }
     }
     __syncthreads();
     // pair cache (oracle scene_ws.cache): [n_hulls][n_hulls] seeds in global scratch, cleared per launch;
@@ -1950,6 +1958,34 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
     k_settle<<<n_scenes, 64, L.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, L, prof, drive, cache,
                                                 pair_cache_stride(params));
     SLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_status, uint32_t* h_n_refused,
+                                   void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_scratch || !h_n_refused) {
+        slhip::set_error("slhip_settle_status: null argument");
+        return -1;
+    }
+    *h_n_refused = 0;
+    if (n_scenes == 0) return 0;
+    std::vector<unsigned long long> st(n_scenes);
+    SLHIP_CHECK(hipMemcpy2DAsync(st.data(), sizeof(unsigned long long), d_scratch, sizeof(ProfScratch),
+                                 sizeof(unsigned long long), n_scenes, hipMemcpyDeviceToHost, stream));
+    SLHIP_CHECK(hipStreamSynchronize(stream));
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < n_scenes; ++i) {
+        if (h_status) h_status[i] = (uint32_t)st[i];
+        if (st[i] != 0) ++bad;
+    }
+    *h_n_refused = bad;
+    if (bad) {
+        slhip::set_error("slhip_settle: %u of %u scenes exceeded the sizing hints of slhip_settle_params and were left "
+                         "untouched", bad, n_scenes);
+        return -2;
+    }
     return 0;
 }
 

@@ -25,12 +25,17 @@ class JobQueue:
         return self._num_threads
 
     def add_scene(self, scene):
+        scene.load_physics()              # job_queue.cpp:58 (hull decomposition happens on the caller's thread)
         self._pending.append(scene)
+
+    def stop(self):
+        """job_queue.cpp:84-93: joins the workers; nothing to join here."""
 
     def retrieve_scene(self):
         if not self._done:
             if not self._pending:
-                raise RuntimeError("JobQueue.retrieve_scene(): no scene was queued")
+                # std::logic_error -> RuntimeError through pybind11 (job_queue.cpp:70-71)
+                raise RuntimeError("PhysicsSim::retrieveScene(): No scenes in work queue. You need to add scenes first!")
             from . import physics
 
             batch = list(self._pending)

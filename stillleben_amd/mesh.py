@@ -2,6 +2,7 @@
 src/mesh.cpp, python/src/py_mesh.cpp:25-67,357-514)."""
 import enum
 import os
+import sys
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -114,13 +115,20 @@ class Mesh:
             raise ValueError("flags must be empty or have the same length as filenames")
 
         def job(i):
-            return Mesh(filenames[i], visual, physics, flags[i] if flags else Mesh.Flag.NONE)
+            try:
+                return Mesh(filenames[i], visual, physics, flags[i] if flags else Mesh.Flag.NONE)
+            except Exception as e:   # mesh.cpp:972-975: report, keep loading the others, fail at the end
+                print("Could not load file %s: %s" % (filenames[i], e), file=sys.stderr)
+                return None
 
         from ._context import require_context
 
         require_context()
         with ThreadPoolExecutor(max_workers=max(1, (os.cpu_count() or 2))) as ex:
-            return list(ex.map(job, range(len(filenames))))
+            meshes = list(ex.map(job, range(len(filenames))))
+        if any(m is None for m in meshes):
+            raise RuntimeError("Could not load one of the meshes")   # mesh.cpp:989-990
+        return meshes
 
     # ---- geometry ------------------------------------------------------------------------
     def _update_bounding_box(self):  # mesh.cpp:1001-1018
@@ -217,31 +225,84 @@ class Mesh:
         self._version += 1
         self._update_bounding_box()
 
+    def _recompute_normals(self):
+        """Mesh::recomputeNormals (mesh.cpp:763-815): per vertex, the normalised sum over its faces of
+        (unit face normal x face area), faces visited in index order; a face counts once per corner."""
+        d = self._data
+        idx = d.indices.astype(np.int64).reshape(-1, 3)
+        p = d.positions
+        v1, v2, v3 = p[idx[:, 0]], p[idx[:, 1]], p[idx[:, 2]]
+        cr = np.cross(v1 - v2, v1 - v3).astype(np.float32)
+        area = np.sqrt((cr * cr).sum(axis=1, dtype=np.float32)).astype(np.float32)
+        with np.errstate(all="ignore"):
+            contrib = ((cr / area[:, None]).astype(np.float32) * area[:, None]).astype(np.float32)
+        acc = np.zeros_like(p)
+        for k in range(3):                      # np.add.at accumulates in index order (unbuffered)
+            np.add.at(acc, idx[:, k], contrib)
+        ln = np.sqrt((acc * acc).sum(axis=1, dtype=np.float32)).astype(np.float32)
+        with np.errstate(all="ignore"):
+            d.normals = (acc / ln[:, None]).astype(np.float32)
+
+    @staticmethod
+    def _check_update(vertex_indices, update, width, what):
+        # argument checks of Mesh_updatePositions / Mesh_updateColors (py_mesh.cpp:69-160)
+        vi = vertex_indices if hasattr(vertex_indices, "dim") else torch.as_tensor(np.asarray(vertex_indices))
+        up = update if hasattr(update, "dim") else torch.as_tensor(np.asarray(update))
+        if vi.dim() != 1:
+            raise ValueError("vertex_indices (1st argument) should be one dimensional")
+        if up.dim() != 2:
+            raise ValueError("%s should be two dimensional" % what)
+        if vi.shape[0] != up.shape[0]:
+            raise ValueError("vertex_indices and %s should be of same size" % what)
+        if up.shape[1] != width:
+            raise ValueError("%s should be of shape (N,%d)" % (what, width))
+        if vi.device.type != "cpu" or up.device.type != "cpu":
+            raise ValueError("vertex_indices and %s should be CPU tensors" % what)
+        return vi.detach().numpy().astype(np.int64) - 1, up.detach().numpy().astype(np.float32)
+
+    def _index_range_check(self, vi):
+        if len(vi) and (vi.min() < 0 or vi.max() >= len(self._data.positions)):
+            raise ValueError("vertex index out of range (ids are 1-based, as the renderer writes them)")
+
     def update_positions(self, vertex_indices, position_update):
-        vi = self._np(vertex_indices, None).astype(np.int64).reshape(-1) - 1
-        self._data.positions[vi] = self._np(position_update, (3,)).astype(np.float32)
+        """Mesh::updateVertexPositions (mesh.cpp:823-841): ADDS the update to the addressed vertices --
+        duplicate ids accumulate, in argument order -- then recomputes the normals."""
+        vi, upd = self._check_update(vertex_indices, position_update, 3, "position_update")
+        self._index_range_check(vi)
+        np.add.at(self._data.positions, vi, upd)
+        self._recompute_normals()
         self._touch()
 
     def update_colors(self, vertex_indices, color_update):
-        vi = self._np(vertex_indices, None).astype(np.int64).reshape(-1) - 1
-        self._data.colors[vi] = self._np(color_update, (4,)).astype(np.float32)
+        """Mesh::updateVertexColors (mesh.cpp:843-852): colour += update (Nx4)."""
+        vi, upd = self._check_update(vertex_indices, color_update, 4, "color_update")
+        self._index_range_check(vi)
+        np.add.at(self._data.colors, vi, upd)
         self._touch()
 
     def update_positions_and_colors(self, vertex_indices, position_update, color_update):
-        self.update_positions(vertex_indices, position_update)
-        self.update_colors(vertex_indices, color_update)
+        vi, upd = self._check_update(vertex_indices, position_update, 3, "position_update")
+        _, cupd = self._check_update(vertex_indices, color_update, 4, "color_update")
+        self._index_range_check(vi)
+        np.add.at(self._data.positions, vi, upd)
+        self._recompute_normals()
+        np.add.at(self._data.colors, vi, cupd)
+        self._touch()
 
     def set_new_positions(self, new_positions):
+        """Mesh::setVertexPositions (mesh.cpp:857-871)."""
         p = self._np(new_positions, (3,)).astype(np.float32)
         if p.shape != self._data.positions.shape:
-            raise ValueError("set_new_positions: shape mismatch")
+            raise ValueError("Number of new vertices should match the existing mesh vertices")
         self._data.positions = p.copy()
+        self._recompute_normals()
         self._touch()
 
     def set_new_colors(self, new_colors):
+        """Mesh::setVertexColors (mesh.cpp:873-886)."""
         c = self._np(new_colors, (4,)).astype(np.float32)
         if c.shape != self._data.colors.shape:
-            raise ValueError("set_new_colors: shape mismatch")
+            raise ValueError("Number of new vertices should match the existing mesh vertices for vertex color update")
         self._data.colors = c.copy()
         self._touch()
 

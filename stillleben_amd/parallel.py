@@ -41,6 +41,77 @@ def cu_partition_streams(settle_cus, n_settle_streams=1, device=None):
     return settle, make(settle_cus, total - settle_cus)
 
 
+class _EventWork:
+    """What `all_gather(..., async_op=True)` returns for the C-ABI transport: `wait()` orders the CURRENT
+    stream after the collective (same meaning as torch's Work.wait() for RCCL)."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class SlhipComm:
+    """slhip_comm (include/slhip.h): an RCCL communicator owned by libslhip.so, one rank per GPU.  The
+    128-byte id is drawn on rank 0 and distributed through torch.distributed (any backend) -- or pass
+    `unique_id` when the ranks exchange it some other way; `world == 1` needs no peer at all."""
+
+    def __init__(self, rank, world, dist=None, unique_id=None, device=None):
+        import ctypes as C
+
+        from . import _abi
+
+        self.L = _abi.lib()
+        self.rank, self.world = rank, world
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if unique_id is None:
+            buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()
+            if rank == 0:
+                _abi.check(self.L.slhip_comm_unique_id(buf), "slhip_comm_unique_id")
+            box = [bytes(buf)]
+            if world > 1:
+                if dist is None:
+                    raise ValueError("SlhipComm: world > 1 needs `dist` (or a shared `unique_id`)")
+                dist.broadcast_object_list(box, src=0)
+            unique_id = box[0]
+        idbuf = (C.c_uint8 * _abi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _abi.check(self.L.slhip_comm_create(idbuf, world, rank, C.byref(h)), "slhip_comm_create")
+        self.handle = h
+        self.stream = torch.cuda.Stream(device=self.device)   # collectives run beside the render stream
+
+    def all_gather(self, tensors, outs):
+        """outs[i] ([world * B, ...]) <- every rank's tensors[i], one fused RCCL group, enqueued on the
+        communicator's stream AFTER the work already queued on the current stream; returns an _EventWork."""
+        import ctypes as C
+
+        from . import _abi
+
+        n = len(tensors)
+        send = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        recv = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
+        nbytes = (C.c_uint64 * n)(*[t.numel() * t.element_size() for t in tensors])
+        produced = torch.cuda.Event()
+        produced.record()
+        self.stream.wait_event(produced)
+        with torch.cuda.device(self.device):
+            st = self.L.slhip_allgather_group(self.handle, n, send, recv, nbytes, C.c_void_p(self.stream.cuda_stream))
+        _abi.check(st, "slhip_allgather_group")
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        for t in list(tensors) + list(outs):
+            t.record_stream(self.stream)
+        return _EventWork(done)
+
+    def close(self):
+        if self.handle is not None:
+            self.stream.synchronize()
+            self.L.slhip_comm_destroy(self.handle)
+            self.handle = None
+
+
 class BatchGatherer:
     """all_gather_into_tensor of a list of per-rank tensors into a small ring of persistent
     [world, ...] staging buffers (`depth` sets per distinct shape signature).
@@ -54,8 +125,11 @@ class BatchGatherer:
     shapes; consumers read it before that (the collectives themselves are serialised on the RCCL
     stream, so a reuse never races with an earlier gather into the same set)."""
 
-    def __init__(self, dist, world, depth=2):
+    def __init__(self, dist, world, depth=2, comm=None):
+        """`comm`: a SlhipComm -- the collectives then go through the C-ABI (slhip_allgather_group, RCCL owned by
+        libslhip.so); without it torch.distributed moves the bytes (gloo in the CPU tests)."""
         self.dist, self.world, self.depth = dist, world, max(1, int(depth))
+        self.comm = comm
         self.rings = {}
 
     def _staging(self, tensors):
@@ -71,6 +145,14 @@ class BatchGatherer:
         return bufs
 
     def __call__(self, tensors, async_op=False):
+        if self.comm is not None:
+            bufs = self._staging(tensors)
+            work = self.comm.all_gather([t.contiguous() for t in tensors], bufs)
+            views = [g.view((self.world, -1) + tuple(g.shape[1:])) for g in bufs]
+            if async_op:
+                return views, [work]
+            work.wait()
+            return views
         if self.dist is None or self.world == 1:
             views = [t.unsqueeze(0) for t in tensors]
             return (views, []) if async_op else views

@@ -50,8 +50,21 @@ class SettleEngine:
     def run(self, srec, bodies, params):
         """Runs slhip_settle on numpy records; returns the updated bodies (numpy)."""
         d_bodies = self.run_device(srec, bodies, params)
+        self.check_status(len(srec))
         out = np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy()
         return out
+
+    def check_status(self, n_scenes, stream=None):
+        """Raises if the last launch on `stream` left scenes untouched (sizing hints too small): the
+        kernel refuses such scenes instead of corrupting LDS, and that must not pass silently."""
+        eng = self.eng
+        if stream is None:
+            stream = torch.cuda.current_stream(eng.device).cuda_stream
+        scratch = self._scratch[stream]
+        bad = C.c_uint32()
+        with torch.cuda.device(eng.device):
+            st = eng.L.slhip_settle_status(_abi_ptr(scratch), n_scenes, None, C.byref(bad), C.c_void_p(stream))
+        _abi.check(st, "slhip_settle")
 
     def run_device(self, srec, bodies, params, d_bodies=None):
         eng = self.eng
@@ -93,6 +106,36 @@ def settle_engine():
     if getattr(eng, "_settle", None) is None:
         eng._settle = SettleEngine(eng)
     return eng._settle
+
+
+def smoke_check(sl, checker):
+    """Used by __graft_entry__.smoke() only: a 4-object tabletop settle (25 frames) through the C-ABI,
+    compared bit for bit with `checker.settle` (the CPU oracle the caller hands in -- this module never
+    imports it)."""
+    import os
+
+    cube = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "fixtures", "cube.glb")
+    m = sl.Mesh(cube)
+    m.center_bbox()
+    m.scale_to_bbox_diagonal(0.2)
+    scene = sl.Scene((160, 120), seed=11)
+    for _ in range(4):
+        scene.add_object(sl.Object(m))
+    has_plane = prepare_tabletop(scene)
+    se = settle_engine()
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(has_plane, PLANE_HALF_Z)])
+    prm = SB.default_params(tabletop=True, frames=25)
+    gpu = se.run(srec, bodies.copy(), prm)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    checker.settle(srec, ref, hulls, verts, SB.sizing_hints(prm, srec, bodies, hulls))
+    for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "stuck_counter"):
+        a, b = np.ascontiguousarray(gpu[name]), np.ascontiguousarray(ref[name])
+        if not np.array_equal(a.view(np.uint8), b.view(np.uint8)):
+            raise AssertionError("settle smoke: body field '%s' differs from the oracle" % name)
+    if not (gpu["pose"].reshape(-1, 4, 4)[:, 2, 3] > 0.0).all():
+        raise AssertionError("settle smoke: an object fell through the table")
+    return len(gpu)
 
 
 # ------------------------------------------------------------------------------------------

@@ -228,8 +228,11 @@ def test_d6_on_a_rendered_scene_and_soft_forward(sl):
     # the gradients are in the units Mesh.update_positions expects
     m = seen[0].mesh
     before = m.points.clone()
-    m.update_positions(vi[0][:3], before[(vi[0][:3] - 1).long()] + 1e-4 * gv[0][:3])
+    # (the reference ADDS the update, mesh.cpp:836: a gradient step is update_positions(ids, lr * grad))
+    m.update_positions(vi[0][:3].contiguous(), (1e-4 * gv[0][:3]).contiguous())
     assert not torch.equal(m.points, before)
+    moved = (m.points - before).abs().max()
+    assert 0 < float(moved) <= 1e-4 * float(gv[0][:3].abs().sum()) + 1e-7
     peel = rp.render(scene, depth_peel=res)
 
     def loss_fn(pred, obs):
