@@ -3,10 +3,11 @@
 6-channel ground-truth render} (BASELINE.json metric, config C2), one process per GPU.
 
 A "step" = one batch of `--batch` freshly seeded scenes per GPU going through the whole hot
-path: slhip_settle (400 physics steps per scene) -> camera / light / draw-list assembly ->
-slhip_render (shadow pass, visibility raster, deferred shade, SSAO, tone map) -> for N > 1 an
-RCCL all-gather of the rendered batches.  Inputs (mesh pool, hull pool, the initial body
-states of every timed batch) are resident in HBM before the timed region starts.
+path ON THE DEVICE: slhip_synth_stage (object choice, random stack) -> slhip_settle (400 physics
+steps per scene) -> slhip_synth_place (camera, light, shadow matrix, draw records) -> slhip_render
+(shadow pass, visibility raster, deferred shade, SSAO, tone map) -> for N > 1 an RCCL all-gather of
+the step's exchange shard.  Resident in HBM before the timed region: the asset table (mesh pool,
+textures, hulls of the 21 classes).  Everything per scene happens inside the timed region.
 
 Prints ONE JSON line (rank 0) -- see the repository brief for the contract."""
 import argparse
@@ -38,13 +39,13 @@ def parse():
                     help="scenes per GPU per step (one settle launch: two rounds of the 2048 resident scenes = 256 CUs x 8; the second round back-fills the tail of the first)")
     ap.add_argument("--render-chunk", type=int, default=None,
                     help="scenes per render launch sequence (fewer, larger sequences: every kernel boundary is a chance for "
-                         "queued settle workgroups to take the freed SIMDs); default 512, 256 when the rendered chunks are "
-                         "all-gathered (N > 1: the [world, chunk, ...] staging ring grows with it)")
+                         "queued settle workgroups to take the freed SIMDs); default 512")
     ap.add_argument("--settle-streams", type=int, default=3,
                     help="settle launches kept in flight: scenes settle in very different times, and a second "
                          "launch on its own stream back-fills the CUs the tail of the first one leaves idle")
-    ap.add_argument("--settle-cus", type=int, default=0,
-                    help="compute units reserved for the settle streams; the render stream gets the rest (0 = share all CUs)")
+    ap.add_argument("--gather-scenes", type=int, default=64,
+                    help="N > 1: scenes per rank and step whose ground truth is all-gathered to every rank (BASELINE config C3: "
+                         "512 scenes = 64 per GPU x 8); 0 = no exchange")
     ap.add_argument("--no-ssao", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes per host thread of the bounded CPU-baseline sample")
@@ -68,179 +69,153 @@ def make_scene(sl, meshes, seed):
 
 
 class Pipeline:
-    def __init__(self, sl, batch, ssao, settle_cus=0, settle_streams=1):
-        from stillleben_amd import _abi, physics
+    """The whole hot path of one GPU, device-resident: per step ONE slhip_synth_stage (initial stacks of 4096 scenes),
+    ONE slhip_settle, ONE slhip_synth_place (cameras, lights, shadow matrices, draw records) on a settle stream, then
+    the slhip_render launch sequences of the step's chunks on the render stream; `ring` SceneBatch record sets are
+    recycled.  The host only enqueues: nothing is read back, no host thread sits between settle and render."""
+
+    def __init__(self, sl, table, batch, render_chunk, ssao, settle_streams, seed, rank):
+        from stillleben_amd import _abi
         from stillleben_amd._context import engine
 
-        self.sl, self._abi, self.physics = sl, _abi, physics
+        self.sl, self._abi = sl, _abi
         self.eng = engine()
-        self.se = physics.settle_engine()
-        self.batch = batch
-        self.ssao = ssao
+        self.batch, self.render_chunk, self.ssao = batch, render_chunk, ssao
         self.mask = _abi.OUT_GT6
-        self.buffers = []
-        if settle_cus > 0:
-            # the two halves get disjoint CU ranges: settle workgroups hold their CU slots for ~100 ms, and
-            # short render workgroups sharing those CUs fragment both
-            from stillleben_amd.parallel import cu_partition_streams
+        dev = self.eng.device
+        self.ring = settle_streams + 1
+        self.sets = []
+        for _ in range(self.ring):
+            b = sl.SceneBatch(table, batch, N_OBJECTS, resolution=RESOLUTION, seed=seed, render_chunk=render_chunk,
+                              shadows=not os.environ.get("SLHIP_BENCH_NO_SHADOWS"))
+            b.set_camera_intrinsics(*INTRINSICS)
+            self.sets.append(b)
+        self.s_settle = [torch.cuda.Stream(device=dev) for _ in range(settle_streams)]
+        self.s_render = torch.cuda.Stream(device=dev)
+        self.free = [None] * self.ring        # event: the set's previous render finished (its records may be rewritten)
+        self.buffers = []                     # render targets per chunk index, reused step after step
+        self.gatherer = None
+        self.gather_scenes = 0
+        self.pending = []
+        self.rank = rank
+        self.steps_launched = 0
 
-            self.s_settle, self.s_render = cu_partition_streams(settle_cus, settle_streams, self.eng.device)
-        else:
-            self.s_settle = [torch.cuda.Stream(device=self.eng.device)]
-            self.s_render = torch.cuda.Stream(device=self.eng.device)
-        self.render_chunk = 128
-        self.gatherer = None      # N > 1: BatchGatherer, one asynchronous RCCL all-gather per rendered chunk
-        self.pending = {}         # chunk slot -> outstanding collectives reading that slot's render buffers
-        self.t_step_host = []
-        self.t_settle = []
-        self.t_host = []
-        self.t_render = []
-        self.phase_ms = []
-
-    def prepare(self, scenes, seed):
-        """Host-side set-up of one batch BEFORE the timed region: initial stacks, static draw
-        records, the random draws of the batch, and the upload of the initial body states."""
-        import math
-
-        from stillleben_amd import _fast_batch as FB
-        from stillleben_amd import _settle_batch as SB
-
-        planes = [(self.physics.prepare_tabletop(s), self.physics.PLANE_HALF_Z) for s in scenes]
-        srec, bodies = SB.build_settle_batch(scenes, self.se.pool, planes)
-        chunks = []
-        for c0 in range(0, len(scenes), self.render_chunk):
-            chunks.append(FB.prepare(scenes[c0:c0 + self.render_chunk], self.eng.pool))
-        rng = np.random.default_rng(seed)
-        item = {
-            "params": SB.sizing_hints(self.params, srec, bodies, self.se.pool.arrays()[0]),
-            "scenes": scenes, "srec": srec, "chunks": chunks,
-            "d_bodies": self.eng.upload_records(bodies),
-            # the random draws of chooseRandomCameraPose / chooseRandomLightDirection
-            "az": rng.uniform(-math.pi, math.pi, len(scenes)).astype(np.float32),
-            "el": rng.uniform(math.radians(30.0), math.radians(60.0), len(scenes)).astype(np.float32),
-            "nrm": rng.standard_normal((len(scenes), 3)).astype(np.float32),
-            "plane_pose": np.stack([s._background_plane_pose for s in scenes]),
-            "obj_off": np.cumsum([0] + [len(s._objects) for s in scenes]),
-        }
-        self.se.hulls_dev()
-        self.eng.pool_abi()
-        return item
-
-    def launch_settle(self, item, slot=0):
-        """Asynchronous: slhip_settle on one of the settle streams, then the 288 B/object read-back
-        into pinned host memory; returns immediately."""
-        while len(self.s_settle) <= slot:
-            self.s_settle.append(torch.cuda.Stream(device=self.eng.device))
-        with torch.cuda.stream(self.s_settle[slot]):
-            item["ev0"] = torch.cuda.Event(enable_timing=True)
-            item["ev1"] = torch.cuda.Event(enable_timing=True)
-            item["ev0"].record()
-            d_bodies = self.se.run_device(item["srec"], None, item["params"], d_bodies=item["d_bodies"])
-            item["ev1"].record()
-            if "h_bodies" not in item:
-                item["h_bodies"] = torch.empty(d_bodies.shape, dtype=d_bodies.dtype, pin_memory=True)
-            item["h_bodies"].copy_(d_bodies, non_blocking=True)
-            item["ev_copy"] = torch.cuda.Event()
-            item["ev_copy"].record()
-
-    def finish(self, item, timed=True):
-        """Host assembly (camera, light, draw records) + slhip_render of every chunk on the
-        render stream; overlaps with the settle of the next batch."""
-        from stillleben_amd import _fast_batch as FB
-        from stillleben_amd import _settle_batch as SB
-
-        W, H = RESOLUTION
-        item["ev_copy"].synchronize()
-        t0 = time.perf_counter()
-        bodies = np.frombuffer(item["h_bodies"].numpy().tobytes(), dtype=SB.BODY_DTYPE)
-        poses = bodies["pose"].reshape(-1, 4, 4)
-        outs, revs = [], []
+    def launch_step(self, k, scene_id_base):
+        """Enqueues step k completely (returns at once): stage + settle + place on a settle stream, the render of
+        every chunk on the render stream, for N > 1 the all-gather of the step's exchange shard."""
+        b = self.sets[k % self.ring]
+        st = self.s_settle[k % len(self.s_settle)]
+        rec = {"batch": b}
+        with torch.cuda.stream(st):
+            if self.free[k % self.ring] is not None:
+                st.wait_event(self.free[k % self.ring])
+            rec["t_stage0"] = torch.cuda.Event(enable_timing=True)
+            rec["t_stage0"].record()
+            b.stage(scene_id_base=scene_id_base)
+            rec["ev0"] = torch.cuda.Event(enable_timing=True)
+            rec["ev0"].record()
+            b.settle()
+            rec["ev1"] = torch.cuda.Event(enable_timing=True)
+            rec["ev1"].record()
+            b.place()
+            rec["placed"] = torch.cuda.Event(enable_timing=True)
+            rec["placed"].record()
+        revs = []
         with torch.cuda.stream(self.s_render):
-            for ci, t in enumerate(item["chunks"]):
-                s0 = ci * self.render_chunk
-                s1 = s0 + t.n_scenes
-                o0, o1 = item["obj_off"][s0], item["obj_off"][s1]
-                for w in self.pending.pop(ci, []):
-                    w.wait()      # stream-level: this slot's previous gather must finish before it is re-rendered
-                th0 = time.perf_counter()
-                cam = FB.camera_poses(t, poses[o0:o1], item["az"][s0:s1], item["el"][s0:s1])
-                ld = FB.light_directions(cam, item["nrm"][s0:s1])
-                srec, drec = FB.update(t, poses[o0:o1], cam, ld, item["plane_pose"][s0:s1])
-                th1 = time.perf_counter()
+            self.s_render.wait_event(rec["placed"])
+            for ci in range(b.n_render_chunks()):
+                if ci == 0:
+                    for w in self.pending:
+                        w.wait()      # the previous step's gather reads chunk 0's targets: order the re-render after it
+                    self.pending = []
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                buf = self.eng.render_records(srec, drec, t.crec, W, H, self.mask, ssao=self.ssao, shadows=not os.environ.get("SLHIP_BENCH_NO_SHADOWS"),
-                                              buffers=self.buffers[ci] if ci < len(self.buffers) else None)
+                buf = b.render(ci, self.mask, ssao=self.ssao, buffers=self.buffers[ci] if ci < len(self.buffers) else None)
                 e1.record()
-                if self.gatherer is not None:
-                    # ordered after the chunk's kernels, runs on RCCL's stream while the next chunks render
-                    _, works = self.gatherer([t for t in (buf.rgb, buf.coord, buf.cls, buf.instance, buf.normals)
-                                              if t is not None], async_op=True)
-                    self.pending[ci] = works
                 if ci >= len(self.buffers):
                     self.buffers.append(buf)
-                outs.append(buf)
                 revs.append((e0, e1))
-                if timed:
-                    self.t_host.append((th1 - th0) * 1e3)
-        item["render_events"] = revs
-        item["t_post"] = (time.perf_counter() - t0) * 1e3
-        return outs
+                if ci == 0 and self.gatherer is not None and self.gather_scenes > 0:
+                    g = min(self.gather_scenes, buf.B)
+                    _, works = self.gatherer([t[:g] for t in (buf.rgb, buf.coord, buf.cls, buf.instance, buf.normals)],
+                                             async_op=True)
+                    self.pending = works
+            done = torch.cuda.Event()
+            done.record()
+            self.free[k % self.ring] = done
+        rec["render_events"] = revs
+        return rec
+
+    def drain(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        torch.cuda.synchronize()
 
 
-def cpu_baseline(sl, meshes, scenes_per_thread, ssao, max_threads=32):
-    """The oracle (scalar C restatement) timed on the host cores on a bounded sample of the same
-    workload: every thread takes `scenes_per_thread` scenes through {400-step settle + 640x480
-    render}.  Scenes are independent, so the threads mirror the reference's JobQueue workers
+def cpu_baseline(table_meshes, scenes_per_thread, ssao, max_threads=32):
+    """The oracle (scalar C restatement) timed on the host cores on a bounded sample of the same workload: every
+    thread takes `scenes_per_thread` scenes through {tabletop set-up + 400-step settle + camera / light placement +
+    640x480 render}.  Scenes are independent, so the threads mirror the reference's JobQueue workers
     (job_queue.cpp:35-40); the C calls release the GIL and share no state."""
     from concurrent.futures import ThreadPoolExecutor
 
     import oracle
-    from stillleben_amd import _abi, physics
+    import stillleben_amd as sl
+    from stillleben_amd import _abi
     from stillleben_amd import _settle_batch as SB
-    from stillleben_amd._batch import HostPool, build_batch
+    from stillleben_amd._batch import HostPool
 
     threads = max(1, min(os.cpu_count() or 1, max_threads))
     flags = _abi.OUT_GT6 | _abi.RENDER_SHADOWS | (_abi.RENDER_SSAO if ssao else 0) | _abi.OUT_CAM_COORD
-    prm = SB.default_params(tabletop=True)
-    jobs = []
-    for t in range(threads):   # untimed set-up, as for the GPU path
-        scenes = [make_scene(sl, meshes, 900000 + t * scenes_per_thread + i) for i in range(scenes_per_thread)]
-        pool_h = SB.HullPool()
-        planes = [(physics.prepare_tabletop(s), physics.PLANE_HALF_Z) for s in scenes]
-        srec, bodies = SB.build_settle_batch(scenes, pool_h, planes)
-        jobs.append((scenes, srec, bodies, pool_h.arrays()))
+    pool, hulls = HostPool(), SB.HullPool()
+    table = sl.AssetTable(table_meshes, mesh_pool=pool, hull_pool=hulls)   # host records only (untimed set-up, as on the GPU)
+    pool_arrays = pool.arrays()
+    hull_recs, hull_verts = hulls.arrays()
+    W, H = RESOLUTION
+    proto = sl.Scene(RESOLUTION)
+    proto.set_camera_intrinsics(*INTRINSICS)
+    sp = SB.default_params(tabletop=True)
 
-    def settle(job):
-        scenes, srec, bodies, (hulls, verts) = job
-        t0 = time.perf_counter()
-        oracle.settle(srec, bodies, hulls, verts, prm)
-        return time.perf_counter() - t0
+    def params(t):
+        p = np.zeros((), dtype=_abi.SYNTH_PARAMS_DTYPE)
+        p["n_scenes"], p["n_objects"], p["n_assets"] = scenes_per_thread, N_OBJECTS, len(table)
+        p["flags"] = _abi.SYNTH_SAMPLE_DISTINCT | _abi.SYNTH_RANDOM_PBR | _abi.SYNTH_SHADOWS
+        p["seed_lo"], p["scene_id_base"], p["render_chunk"] = 900000, t * scenes_per_thread, scenes_per_thread
+        p["max_draws_per_scene"] = table.bound(table.n_draws, N_OBJECTS, True) + 1
+        p["max_chunks_per_scene"] = table.bound(table.n_chunks, N_OBJECTS, True) + 1
+        p["max_clip_verts_per_scene"] = table.bound(table.n_clip, N_OBJECTS, True) + 4
+        p["plane_z"] = 0.04
+        p["proj"] = proto._projection.reshape(-1)
+        p["proj_inv"] = np.linalg.inv(proto._projection.astype(np.float64)).astype(np.float32).reshape(-1)
+        p["plane_size"] = (3.0, 3.0)
+        p["manual_exposure"] = -1.0
+        p["light_color"][:3] = 300.0
+        p["ambient"][:3] = 0.05
+        return p
 
-    def render(job):
-        pool, rs, rd = job
+    def job(t):
+        p = params(t)
         t0 = time.perf_counter()
-        oracle.render(pool.arrays(), rs, rd, RESOLUTION[0], RESOLUTION[1], flags)
-        return time.perf_counter() - t0
+        bodies, ss, objs, scs = oracle.synth_stage(p, table.records)
+        oracle.settle(ss, bodies, hull_recs, hull_verts, sp)
+        t1 = time.perf_counter()
+        srec, drec, _ = oracle.synth_place(p, table.records, table.templates, bodies, objs, scs)
+        md = int(p["max_draws_per_scene"])
+        for s in range(scenes_per_thread):       # the oracle renderer takes tightly packed draw lists
+            nd = int(srec[s]["draw_end"] - srec[s]["draw_begin"])
+            rs, rd = srec[s:s + 1].copy(), drec[s * md:s * md + nd].copy()
+            rs["draw_begin"], rs["draw_end"] = 0, nd
+            rd["scene"] = 0
+            oracle.render(pool_arrays, rs, rd, W, H, flags)
+        return t1 - t0, time.perf_counter() - t1
 
     with ThreadPoolExecutor(threads) as ex:
         w0 = time.perf_counter()
-        t_settle = list(ex.map(settle, jobs))
-        w1 = time.perf_counter()
-        rjobs = []
-        for scenes, srec, bodies, _ in jobs:   # camera / light placement + draw records: untimed host glue
-            SB.write_back(scenes, bodies)
-            for s in scenes:
-                s.choose_random_camera_pose()
-                s.choose_random_light_direction()
-            pool = HostPool()
-            rs, rd, _c = build_batch(scenes, pool, with_shadows=True)
-            rjobs.append((pool, rs, rd))
-        w2 = time.perf_counter()
-        t_render = list(ex.map(render, rjobs))
-        w3 = time.perf_counter()
+        times = list(ex.map(job, range(threads)))
+        wall = time.perf_counter() - w0
     n = threads * scenes_per_thread
-    wall = (w1 - w0) + (w3 - w2)
+    t_settle, t_render = sum(t[0] for t in times), sum(t[1] for t in times)
     cpu_model = "?"
     try:
         with open("/proc/cpuinfo") as f:
@@ -249,10 +224,9 @@ def cpu_baseline(sl, meshes, scenes_per_thread, ssao, max_threads=32):
         pass
     return {
         "value": n / wall, "unit": "scenes/s", "cores": threads, "kind": "port",
-        "sample": "%d scenes on %d threads (host: %d x %s): settle %.2f s + render %.2f s wall; per scene on one "
-                  "thread: settle %.3f s, render %.3f s, i.e. %.2f scenes/s single-threaded (oracle/, same C2 workload)"
-                  % (n, threads, os.cpu_count() or 0, cpu_model, w1 - w0, w3 - w2, sum(t_settle) / n, sum(t_render) / n,
-                     n / (sum(t_settle) + sum(t_render))),
+        "sample": "%d scenes on %d threads (host: %d x %s), %.1f s wall; per scene on one thread: set-up + settle %.3f s, "
+                  "placement + render %.3f s, i.e. %.2f scenes/s single-threaded (oracle/, same C2 workload and seeds scheme)"
+                  % (n, threads, os.cpu_count() or 0, cpu_model, wall, t_settle / n, t_render / n, n / (t_settle + t_render)),
     }
 
 
@@ -298,63 +272,53 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import stillleben_amd as sl
-    from stillleben_amd import _settle_batch as SB
     from stillleben_amd import synthetic
+    from stillleben_amd.parallel import BatchGatherer, SlhipComm
 
     sl.init_cuda(local_rank)
-    meshes = synthetic.ycb_like_meshes(seed=0)
-    pipe = Pipeline(sl, args.batch, not args.no_ssao, args.settle_cus, max(1, args.settle_streams))
-    pipe.params = SB.default_params(tabletop=True)
-    if args.render_chunk is None:
-        args.render_chunk = 512 if world == 1 else 256
-    pipe.render_chunk = args.render_chunk
-    pipe.eng.L.slhip_timing_enable(1)
-
-    n_items = args.warmup + args.steps
-    items = []
     t_prep = time.perf_counter()
-    for k in range(n_items):
-        base = (rank * n_items + k) * args.batch
-        items.append(pipe.prepare([make_scene(sl, meshes, base + i) for i in range(args.batch)], seed=base))
+    meshes = synthetic.ycb_like_meshes(seed=0)
+    table = sl.AssetTable(meshes)                 # once per process: the 21 classes' vertices, textures, hulls -> HBM
+    if args.render_chunk is None:
+        args.render_chunk = 512
+    args.render_chunk = min(args.render_chunk, args.batch)
+    pipe = Pipeline(sl, table, args.batch, args.render_chunk, not args.no_ssao, max(1, args.settle_streams), seed=20260929, rank=rank)
+    pipe.eng.L.slhip_timing_enable(1)
+    table.device()
+    pipe.eng.pool_abi()
     torch.cuda.synchronize()
     if rank == 0:
-        print("[bench] prepared %d batches of %d scenes in %.1f s (untimed set-up)" % (n_items, args.batch, time.perf_counter() - t_prep),
-              file=sys.stderr)
+        print("[bench] asset table of %d classes + %d record sets of %d scenes ready in %.1f s (once per process; per-scene "
+              "staging is inside the timed region)" % (len(table), pipe.ring, args.batch, time.perf_counter() - t_prep), file=sys.stderr)
 
-    from stillleben_amd.parallel import BatchGatherer
-
+    comm = None
     if dist is not None:
-        # every rank receives every rendered chunk: RCCL all-gather per dtype buffer into a ring of
-        # [world, chunk, ...] staging buffers, overlapped with the rendering of the following chunks
-        pipe.gatherer = BatchGatherer(dist, world, depth=2)
+        # the exchange step: every rank receives the step's C3 shard (64 scenes) of every other rank -- all-gather per
+        # dtype buffer in one RCCL group through the C-ABI (slhip_allgather_group), on its own stream
+        pipe.gather_scenes = max(0, min(args.gather_scenes, args.render_chunk))
+        if pipe.gather_scenes:
+            if os.environ.get("SLHIP_BENCH_ONE_DEVICE") or os.environ.get("SLHIP_BENCH_GATHER") == "torch":
+                pipe.gatherer = BatchGatherer(dist, world, depth=2)
+            else:
+                comm = SlhipComm(rank, world, dist=dist)
+                pipe.gatherer = BatchGatherer(dist, world, depth=2, comm=comm)
 
-    def run(seq, timed):
-        """Software pipeline over a sequence of batches: while the GPU settles batch k+1 (settle
-        stream) the host assembles and the GPU renders batch k (render stream).  Every batch's
-        settle AND render (and gather) complete inside the call."""
-        if not seq:
-            return
-        ahead = max(1, args.settle_streams)
-        for k in range(min(ahead, len(seq))):
-            pipe.launch_settle(seq[k], k % ahead)
-        for k in range(len(seq)):
-            if k + ahead < len(seq):
-                pipe.launch_settle(seq[k + ahead], (k + ahead) % ahead)
-            pipe.finish(seq[k], timed)
-        for works in pipe.pending.values():
-            for w in works:
-                w.wait()
-        pipe.pending.clear()
-        torch.cuda.synchronize()
+    def scene_base(k):      # disjoint random streams per rank and step
+        return (rank * 4096 + k) * args.batch
 
-    run(items[:args.warmup], False)
+    def run(first, count):
+        recs = [pipe.launch_step(k, scene_base(k)) for k in range(first, first + count)]
+        pipe.drain()
+        return recs
+
+    run(0, args.warmup)
     pipe.eng.L.slhip_render_timings(C.byref((C.c_float * 8)()))   # drop warm-up phase timings
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(items[args.warmup:], True)
+    recs = run(args.warmup, args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -364,118 +328,169 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    for r in recs:
+        r["batch"].check_settled()     # a scene the kernel refused (sizing hints) must fail the run, not pass silently
 
-    # phase timings: the render events of all timed batches accumulate in the library
+    # phase timings: the render events of all timed steps accumulate in the library
     ms_all = (C.c_float * 8)()
     pipe.eng.L.slhip_render_timings(C.byref(ms_all))
-    for it in items[args.warmup:]:
-        pipe.t_render.append(sum(a.elapsed_time(b) for a, b in it["render_events"]))
-        pipe.t_settle.append(it["ev0"].elapsed_time(it["ev1"]))
-        pipe.t_step_host.append(it["t_post"])
+    t_settle = float(np.mean([r["ev0"].elapsed_time(r["ev1"]) for r in recs]))
+    t_stage = float(np.mean([r["t_stage0"].elapsed_time(r["ev0"]) for r in recs]))
+    t_place = float(np.mean([r["ev1"].elapsed_time(r["placed"]) for r in recs]))
+    t_render = float(np.mean([sum(a.elapsed_time(b) for a, b in r["render_events"]) for r in recs]))
     if rank == 0 and os.environ.get("SLHIP_BENCH_TRACE"):
-        ref = items[args.warmup]["ev0"]
-        for k, it in enumerate(items[args.warmup:]):
-            print("[trace] step %d: settle %.0f..%.0f ms, render %.0f..%.0f ms" % (
-                k, ref.elapsed_time(it["ev0"]), ref.elapsed_time(it["ev1"]),
-                ref.elapsed_time(it["render_events"][0][0]), ref.elapsed_time(it["render_events"][-1][1])), file=sys.stderr)
-    pipe.phase_ms.append(np.array(list(ms_all)) / max(1, args.steps))
-    # the render kernels overlap with the next batch's settle inside the timed region, which
-    # stretches their event-to-event times; one extra NON-overlapped render pass of the last
-    # batch (outside the timed region) gives the per-kernel durations the roofline is priced on
-    pipe.finish(items[-1], timed=False)
+        ref = recs[0]["t_stage0"]
+        for k, r in enumerate(recs):
+            print("[trace] step %d: stage %.1f, settle %.0f..%.0f ms, render %.0f..%.0f ms" % (
+                k, ref.elapsed_time(r["t_stage0"]), ref.elapsed_time(r["ev0"]), ref.elapsed_time(r["ev1"]),
+                ref.elapsed_time(r["render_events"][0][0]), ref.elapsed_time(r["render_events"][-1][1])), file=sys.stderr)
+    phases = np.array(list(ms_all)) / max(1, args.steps)
+    # inside the timed region the render overlaps the next steps' settles, which stretches its event-to-event times;
+    # ONE extra non-overlapped render of the last step's chunks (outside the timed region) gives the isolated
+    # per-kernel durations the render roofline is priced on
+    b_last = recs[-1]["batch"]
+    iso_wall = []
+    with torch.cuda.stream(pipe.s_render):
+        for ci in range(b_last.n_render_chunks()):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b_last.render(ci, pipe.mask, ssao=pipe.ssao, buffers=pipe.buffers[ci])
+            e1.record()
+            iso_wall.append((e0, e1))
     torch.cuda.synchronize()
     ms_iso = (C.c_float * 8)()
     pipe.eng.L.slhip_render_timings(C.byref(ms_iso))
     iso = np.array(list(ms_iso))
+    t_render_iso = float(sum(a.elapsed_time(b) for a, b in iso_wall))
+    # ... and ONE settle launch alone on the idle GPU (same shape: the whole step's scenes)
+    with torch.cuda.stream(pipe.s_settle[0]):
+        b_last.stage(scene_id_base=scene_base(args.warmup + args.steps))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b_last.settle()
+        e1.record()
+    torch.cuda.synchronize()
+    t_settle_alone = e0.elapsed_time(e1)
     if rank == 0:
-        total_scenes = args.batch * world * args.steps
-        value = total_scenes / elapsed
-        ms_step = elapsed / args.steps * 1e3
-        # ---- roofline of the dominant kernels ----
-        W, H = RESOLUTION
-        P = W * H
-        t_settle = float(np.mean(pipe.t_settle))
-        t_render = float(np.mean(pipe.t_render))
-        phases = np.mean(np.array(pipe.phase_ms), axis=0) if pipe.phase_ms else np.zeros(8)
-        names = ["shadow_raster", "shadow_large", "vis_raster", "vis_large", "shade", "ssao", "ssao_apply", "tonemap"]
-        # algorithmic bytes of the deferred shade pass per launch (DESIGN.md "roofline"):
-        #   read the 8 B visibility key, write the selected targets + HDR colour, per pixel,
-        #   plus the winning triangle's 3 vertices (pos 16 B, normal 16 B, uv 8 B) + 12 B indices
-        out_bytes = 16 + 2 + 2 + 16 + 16 + 16  # coord, class, instance, normals, cam_coord(SSAO input), hdr
-        n_chunks = (args.batch + args.render_chunk - 1) // args.render_chunk
-        shade_bytes = args.batch * P * (8 + out_bytes + 3 * 40 + 12)  # all chunks of one step
-        k_dom = int(np.argmax(phases)) if phases.sum() > 0 else 4
-        settle_dominant = t_settle > t_render
-        roof_render = {
-            "bound": "hbm", "kernel": "k_shade",
-            "achieved": shade_bytes / (iso[4] * 1e-3) / 1e9 if iso[4] > 0 else None,
-            "peak": 8000.0, "unit": "GB/s", "traffic": None,
-            "measured": "HIP events, non-overlapped render pass of the last timed batch (inside the timed region "
-                        "the render overlaps the next batch's settle: see breakdown_ms)",
-            "achieved_overlapped": shade_bytes / (phases[4] * 1e-3) / 1e9 if phases[4] > 0 else None,
-        }
-        if roof_render["achieved"]:
-            roof_render["frac"] = roof_render["achieved"] / roof_render["peak"]
-        # HBM traffic from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes on
-        # the same workload, committed under profiles/): bytes per scene x scenes per launch
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-        pmc_k = {}
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                pmc_k = json.load(f)["kernels"]
-        if "k_shade" in pmc_k:
-            roof_render["traffic"] = pmc_k["k_shade"]["hbm_bytes_per_scene"] * args.render_chunk
-            roof_render["traffic_source"] = "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-            roof_render["algorithmic_bytes_per_launch"] = shade_bytes / n_chunks
-        # settle: hull vertices + body state are read once and written once per scene (HBM),
-        # everything else lives in LDS/L2: an HBM fraction is reported for completeness only
-        # per scene: body records in + out (288 B each), hull records (64 B) and hull vertices (16 B) once
-        hulls_per_scene, verts_per_scene = 68, 1456   # C2 maxima (sizing hints of the batches)
-        settle_bytes = args.batch * (N_OBJECTS * 288 * 2 + hulls_per_scene * 64 + verts_per_scene * 16)
-        roof_settle = {
-            "bound": "hbm", "kernel": "k_settle", "achieved": settle_bytes / (t_settle * 1e-3) / 1e9, "peak": 8000.0,
-            "unit": "GB/s", "traffic": pmc_k["k_settle"]["hbm_bytes_per_scene"] * args.batch if "k_settle" in pmc_k else None,
-            "algorithmic_bytes_per_launch": settle_bytes,
-            "measured": "HIP events around each slhip_settle launch; up to --settle-streams launches share the GPU, "
-                        "so a launch's duration is longer than when it runs alone",
-            "note": "VALU-issue-bound persistent kernel (400 dependent steps per scene in LDS): neither HBM nor MFMA "
-                    "bounds it, the HBM fraction is reported because the schema asks for one -- see valu_frac "
-                    "(SQ_INSTS_VALU per scene from profiles/r01/settle_sq_counters_v32.txt x scenes / launch time, "
-                    "against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction) and steps_scenes_per_s",
-            "valu_insts_per_scene": VALU_INSTS_PER_SCENE,
-            "valu_frac": VALU_INSTS_PER_SCENE * args.batch / (t_settle * 1e-3) / (1024 * 2.4e9 / 4),
-            "steps_scenes_per_s": args.batch * 400 / (t_settle * 1e-3),
-        }
-        roof_settle["frac"] = roof_settle["achieved"] / roof_settle["peak"]
-        roofline = dict(roof_settle if settle_dominant else roof_render)
-        out = {
-            "metric": "scenes/sec (settle + 640x480 6-ch GT render), 20-obj YCB-like",
-            "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": "C2: 20 procedural YCB-like objects (8k verts/16k tris, 1024^2 texture each), tabletop "
-                            "settle 100 frames x 4 substeps + 640x480 render of rgb/coord+depth/class/instance/normals, "
-                            "shadows on, SSAO %s" % ("off" if args.no_ssao else "on"),
-                "scenes_per_gpu_per_step": args.batch, "resolution": list(RESOLUTION), "objects": N_OBJECTS,
-                "parallelism": "scenes sharded 1 batch/GPU, RCCL all-gather of rendered batches" if world > 1 else "1 GPU",
-            },
-            "roofline": roofline,
-            "roofline_render": roof_render,
-            "roofline_settle": roof_settle,
-            "breakdown_ms": {
-                "settle": t_settle, "host_assembly_per_chunk": float(np.mean(pipe.t_host)),
-                "post_settle_wall": float(np.mean(pipe.t_step_host)), "render_total": t_render, "render_chunks": n_chunks,
-                **{n: float(v) for n, v in zip(names, phases)},
-            },
-            "breakdown_isolated_ms": {n: float(v) for n, v in zip(names, iso)},
-            "dominant_render_phase": names[k_dom],
-        }
+        out = report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso,
+                     phases, iso)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sl, meshes, args.cpu_scenes, not args.no_ssao)
+            out["cpu_baseline"] = cpu_baseline(meshes, args.cpu_scenes, not args.no_ssao)
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def load_counters():
+    """SQ / HBM counters of the dominant kernels, collected by tools/collect_counters.py from separate rocprofv3 --pmc
+    passes at the bench shape and committed under profiles/ (the latest round's file wins)."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "counters.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                c = json.load(f)
+            c["source"] = "profiles/%s/counters.json" % rnd
+            return c
+    return {}
+
+
+def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso, phases, iso):
+    W, H = RESOLUTION
+    P = W * H
+    total_scenes = args.batch * world * args.steps
+    n_chunks = (args.batch + args.render_chunk - 1) // args.render_chunk
+    names = ["shadow_raster", "shadow_large", "vis_raster", "vis_large", "shade", "ssao", "ssao_apply", "tonemap"]
+    cnt = load_counters()
+    ck = cnt.get("kernels", {})
+    # ---- algorithmic bytes, SURVEY.md 8d (per scene) ----
+    verts = float(np.mean(table.n_clip)) * N_OBJECTS + 4            # V_inst: vertices of the drawn instances
+    tris = float(np.mean([sum(int(t["n_tris"]) for t in table.templates[int(r["draw_begin"]):int(r["draw_begin"] + r["draw_count"])])
+                          for r in table.records])) * N_OBJECTS + 2    # T_inst
+    S = 2048
+    b_gt6 = verts * 68 + tris * 12 + P * 40                         # scan the geometry once, write the 6-channel GT
+    b_shadow = verts * 12 + tris * 12 + S * S * 4                   # one active light
+    b_post = P * (16 + 16 + 4 + 16 + 16 + 4)                        # SSAO + blur + tone map
+    b_scene = b_gt6 + (0 if os.environ.get("SLHIP_BENCH_NO_SHADOWS") else b_shadow) + (b_post if not args.no_ssao else P * 20)
+    # per-kernel byte models (DESIGN.md section 4): what each kernel must move when every byte is touched once
+    per_kernel_bytes = {
+        "k_shade": P * (8 + 40 + 16 + 16 + 4) + verts * 40,         # key in; GT6 + cam coords + HDR + z plane out; vertex attributes once
+        "k_ssao": P * (16 + 16 + 4 + 4),
+        "k_ssao_apply": P * (16 + 4 + 4 + 16),
+        "k_tonemap": P * (16 + 4),
+        "k_raster": tris * (12 + 48) + P * 8,
+        "k_shadow_raster": tris * (12 + 48) + S * S * 4,
+    }
+    iso_by_kernel = {"k_shade": iso[4], "k_ssao": iso[5], "k_ssao_apply": iso[6], "k_tonemap": iso[7],
+                     "k_raster": iso[2] + iso[3], "k_shadow_raster": iso[0] + iso[1]}
+    per_kernel = {}
+    for k, bts in per_kernel_bytes.items():
+        ms = float(iso_by_kernel[k]) / n_chunks                      # one launch = one render chunk
+        if ms > 0:
+            per_kernel[k] = {"algorithmic_bytes_per_launch": bts * args.render_chunk, "ms_per_launch": ms,
+                             "achieved_GBps": bts * args.render_chunk / (ms * 1e-3) / 1e9,
+                             "frac": bts * args.render_chunk / (ms * 1e-3) / 8e12,
+                             "traffic": ck[k]["hbm_bytes_per_scene"] * args.render_chunk if k in ck else None}
+    ms_seq = t_render_iso / n_chunks
+    roof_render = {
+        "bound": "hbm", "kernel": "slhip_render launch sequence (%d scenes: vertex transform, shadow pass, visibility, shade, SSAO, tone map)" % args.render_chunk,
+        "achieved": b_scene * args.render_chunk / (ms_seq * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+        "algorithmic_bytes_per_scene": b_scene, "algorithmic_bytes_per_launch": b_scene * args.render_chunk,
+        "ms_per_launch": ms_seq,
+        "traffic": sum(v["hbm_bytes_per_scene"] for k, v in ck.items() if k != "k_settle" and not k.startswith("k_synth")) * args.render_chunk if ck else None,
+        "measured": "HIP events on the render stream around one non-overlapped pass over the last step's chunks",
+        "byte_model": "SURVEY.md 8d: V_inst*68 + T_inst*12 + P*40 (GT6) + V_inst*12 + T_inst*12 + 2048^2*4 (one shadow light) + P*72 (SSAO, blur, tone map)",
+        "per_kernel": per_kernel,
+    }
+    roof_render["frac"] = roof_render["achieved"] / roof_render["peak"]
+    # settle: per scene body records in + out (288 B each), hull records (64 B) and hull vertices (16 B) once
+    hulls_per_scene = float(np.mean(table.n_hulls)) * N_OBJECTS
+    hverts_per_scene = float(np.mean(table.n_hull_verts)) * N_OBJECTS
+    settle_bytes = args.batch * (N_OBJECTS * 288 * 2 + hulls_per_scene * 64 + hverts_per_scene * 16)
+    sq = ck.get("k_settle", {})
+    valu_per_scene = sq.get("valu_insts_per_scene")
+    roofline = {
+        "bound": "hbm", "kernel": "k_settle", "achieved": settle_bytes / (t_settle * 1e-3) / 1e9, "peak": 8000.0,
+        "unit": "GB/s", "traffic": sq["hbm_bytes_per_scene"] * args.batch if "hbm_bytes_per_scene" in sq else None,
+        "algorithmic_bytes_per_launch": settle_bytes, "ms_per_launch": t_settle, "ms_per_launch_alone": t_settle_alone,
+        "measured": "HIP events on the launch's stream around every slhip_settle of the timed region (%d launches in flight "
+                    "share the GPU with the render stream); ms_per_launch_alone: one launch on the idle GPU" % len(pipe.s_settle),
+        "note": "the time-dominant kernel is NOT HBM-bound: 400 dependent steps per scene run out of LDS, the limiter is VALU "
+                "issue x lane occupancy (valu_frac, active_lanes); the HBM fraction is reported because the schema asks for one",
+        "valu_insts_per_scene": valu_per_scene,
+        "valu_frac": (valu_per_scene * args.batch / (t_settle_alone * 1e-3) / (1024 * 2.4e9 / 4)) if valu_per_scene else None,
+        "active_lanes": sq.get("active_lanes"),
+        "steps_scenes_per_s": args.batch * 400 / (t_settle * 1e-3),
+        "counters_source": cnt.get("source"),
+    }
+    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    k_dom = int(np.argmax(phases)) if phases.sum() > 0 else 4
+    return {
+        "metric": "scenes/sec (settle + 640x480 6-ch GT render), 20-obj YCB-like",
+        "value": total_scenes / elapsed, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "C2: 20 of 21 procedural YCB-like objects (8k verts/16k tris, 1024^2 texture each) per scene; per step and GPU "
+                        "%d scenes are staged (random stack), settled (100 frames x 4 substeps), framed (camera, light, shadow "
+                        "matrix) and rendered at 640x480 (rgb, coord+depth, class, instance, normals; shadows on, SSAO %s) -- "
+                        "all four stages inside the timed region" % (args.batch, "off" if args.no_ssao else "on"),
+            "scenes_per_gpu_per_step": args.batch, "render_chunk": args.render_chunk, "resolution": list(RESOLUTION),
+            "objects": N_OBJECTS,
+            "parallelism": ("scenes sharded by rank, no data-path collective; exchange: RCCL all-gather of a %d-scene C3 shard per "
+                            "rank and step (%.0f MB per rank)" % (pipe.gather_scenes, pipe.gather_scenes * P * 40 / 1e6)) if world > 1 else "1 GPU",
+        },
+        "roofline": roofline,
+        "roofline_render": roof_render,
+        "breakdown_ms": {
+            "stage": t_stage, "settle": t_settle, "settle_alone": t_settle_alone, "place": t_place,
+            "render_total_overlapped": t_render, "render_total_isolated": t_render_iso, "render_chunks": n_chunks,
+            **{n: float(v) for n, v in zip(names, phases)},
+        },
+        "breakdown_isolated_ms": {n: float(v) for n, v in zip(names, iso)},
+        "dominant_render_phase": names[k_dom],
+    }
 
 
 if __name__ == "__main__":
