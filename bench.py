@@ -26,7 +26,6 @@ sys.path.insert(0, ROOT)
 
 RESOLUTION = (640, 480)
 INTRINSICS = (1066.778, 1067.487, 312.9869, 241.3109)  # reference examples/ycb.py:32
-VALU_INSTS_PER_SCENE = 52762516188 / 2048   # rocprofv3 --pmc SQ_INSTS_VALU, tools/profile_settle.py 2048 100 (profiles/r01/settle_sq_counters_v32.txt)
 N_OBJECTS = 20
 
 
@@ -459,7 +458,8 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
         "note": "the time-dominant kernel is NOT HBM-bound: 400 dependent steps per scene run out of LDS, the limiter is VALU "
                 "issue x lane occupancy (valu_frac, active_lanes); the HBM fraction is reported because the schema asks for one",
         "valu_insts_per_scene": valu_per_scene,
-        "valu_frac": (valu_per_scene * args.batch / (t_settle_alone * 1e-3) / (1024 * 2.4e9 / 4)) if valu_per_scene else None,
+        "valu_frac": (valu_per_scene * args.batch / (t_settle_alone * 1e-3) / (1024 * 2.4e9 / 2)) if valu_per_scene else None,
+        "valu_peak": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md, per-instruction cycle table)",
         "active_lanes": sq.get("active_lanes"),
         "steps_scenes_per_s": args.batch * 400 / (t_settle * 1e-3),
         "counters_source": cnt.get("source"),

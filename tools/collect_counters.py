@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Collects, ON THE GPU BOX, everything bench.py's roofline objects quote, at the bench shape
+(4096 scenes per step, 512-scene render sequences), and writes it under gpurun_out/<round>/:
+
+  kernel_stats.csv          rocprofv3 --kernel-trace --stats of the default `python bench.py`
+  bench_under_rocprof.json  the JSON line printed by that very run (its HIP-event durations must agree with the CSV)
+  counters.json             per kernel: HBM bytes per launch / per scene (FETCH_SIZE and WRITE_SIZE from two separate
+                            --pmc passes, KiB units, corrected by the factors measured on a known-byte kernel in the
+                            same passes), and for k_settle the SQ counters: VALU instructions per scene, active lanes
+                            (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), VALU duty of a wave
+
+usage (through gpurun):  python tools/collect_counters.py gpurun_out/r02
+Every rocprofv3 call combines --pmc only with --kernel-trace (the pool refuses / crashes on other mixes)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = ["python", os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"]
+PMC_SHAPE = ["--steps", "1", "--warmup", "0", "--settle-streams", "1"]   # one step: every kernel of the path once, serialised
+N_CAL = 1 << 31
+
+
+def kname(n):
+    m = re.search(r"(k_\w+)", n)
+    return m.group(1) if m else None
+
+
+def run(cmd, **kw):
+    print("+ " + " ".join(cmd), flush=True)
+    return subprocess.run(cmd, **kw)
+
+
+def pmc(out, tag, counters, cmd):
+    d = os.path.join(out, "raw_" + tag)
+    shutil.rmtree(d, ignore_errors=True)
+    run(["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--"] + cmd,
+        stdout=subprocess.DEVNULL, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+    f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    ids = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = kname(r["Kernel_Name"]) or ("cal" if "elementwise" in r["Kernel_Name"] else None)
+        if not k:
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        ids[k].add(r["Dispatch_Id"])
+    return {k: {c: v / len(ids[k]) for c, v in cs.items()} for k, cs in acc.items()}, {k: len(v) for k, v in ids.items()}
+
+
+def main():
+    out = os.path.abspath(sys.argv[1])
+    os.makedirs(out, exist_ok=True)
+    batch, chunk = 4096, 512
+    # 1. per-kernel durations of the default command + the bench line under the profiler
+    d = os.path.join(out, "raw_stats")
+    shutil.rmtree(d, ignore_errors=True)
+    r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + BENCH,
+            stdout=subprocess.PIPE, text=True, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    open(os.path.join(out, "bench_under_rocprof.json"), "w").write(line + "\n")
+    st = glob.glob(d + "/**/*_kernel_stats.csv", recursive=True)[0]
+    shutil.copy(st, os.path.join(out, "kernel_stats.csv"))
+    stats = {kname(r_["Name"]) or r_["Name"][:40]: r_ for r_ in csv.DictReader(open(st))}
+    # 2. HBM traffic: two passes, each also over the calibration kernel
+    cal_cmd = ["python", os.path.join(ROOT, "tools", "pmc_calibrate.py")]
+    fetch, n_f = pmc(out, "fetch", ["FETCH_SIZE"], BENCH + PMC_SHAPE)
+    write, _ = pmc(out, "write", ["WRITE_SIZE"], BENCH + PMC_SHAPE)
+    cal_f, _ = pmc(out, "cal_fetch", ["FETCH_SIZE"], cal_cmd)
+    cal_w, _ = pmc(out, "cal_write", ["WRITE_SIZE"], cal_cmd)
+    f_fac = N_CAL / (cal_f["cal"]["FETCH_SIZE"] * 1024.0)
+    w_fac = N_CAL / (cal_w["cal"]["WRITE_SIZE"] * 1024.0)
+    # 3. SQ counters of the settle kernel (8 SQ slots per pass)
+    sq, _ = pmc(out, "sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
+                            "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM"], BENCH + PMC_SHAPE)
+    sq_cal, _ = pmc(out, "sq_cal", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES"], cal_cmd)
+    full = sq_cal["cal"]["SQ_THREAD_CYCLES_VALU"] / sq_cal["cal"]["SQ_ACTIVE_INST_VALU"]   # the ratio of a kernel with all 64 lanes on
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        if k == "cal":
+            continue
+        n = batch if k in ("k_settle", "k_synth_stage", "k_synth_place") else chunk
+        fb = fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
+        wb = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
+        kernels[k] = {"scenes_per_launch": n, "dispatches_in_pass": n_f.get(k, 0),
+                      "fetch_bytes_raw": fb, "write_bytes_raw": wb,
+                      "fetch_bytes": fb * f_fac, "write_bytes": wb * w_fac,
+                      "hbm_bytes_per_launch": fb * f_fac + wb * w_fac,
+                      "hbm_bytes_per_scene": (fb * f_fac + wb * w_fac) / n}
+        if k in stats:
+            kernels[k]["avg_ms_default_run"] = float(stats[k]["AverageNs"]) / 1e6
+            kernels[k]["calls_default_run"] = int(stats[k]["Calls"])
+            kernels[k]["pct_gpu_time_default_run"] = float(stats[k]["Percentage"])
+    s = sq.get("k_settle", {})
+    if s:
+        kernels.setdefault("k_settle", {})
+        kernels["k_settle"].update({
+            "sq": s,
+            "valu_insts_per_scene": s["SQ_INSTS_VALU"] / batch,
+            "active_lanes": 64.0 * (s["SQ_THREAD_CYCLES_VALU"] / s["SQ_ACTIVE_INST_VALU"]) / full if s.get("SQ_ACTIVE_INST_VALU") else None,
+            "thread_cycles_per_active_inst": s["SQ_THREAD_CYCLES_VALU"] / s["SQ_ACTIVE_INST_VALU"] if s.get("SQ_ACTIVE_INST_VALU") else None,
+            "thread_cycles_per_active_inst_full_wave": full,
+            "active_lanes_note": "64 x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of k_settle) / (the same ratio of an elementwise kernel with all "
+                                 "64 lanes on, measured in the same session): the counters' units cancel",
+            "valu_duty_of_a_wave": s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"] if s.get("SQ_WAVE_CYCLES") else None,
+        })
+    res = {
+        "commands": {
+            "stats": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline",
+            "pmc": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_...> --kernel-trace --output-format csv -- python bench.py --no-cpu-baseline " + " ".join(PMC_SHAPE),
+            "calibration": "same two --pmc passes over python tools/pmc_calibrate.py (2 GiB read + 2 GiB written per dispatch, 16 B per lane)",
+        },
+        "shape": {"scenes_per_settle_launch": batch, "scenes_per_render_launch": chunk},
+        "units": "FETCH_SIZE / WRITE_SIZE are KiB; bytes = counter x 1024 x the factor measured on the known-byte kernel",
+        "calibration": {"fetch_factor": f_fac, "write_factor": w_fac,
+                        "expected": "fetch factor 2.0 for 16 B/lane streaming reads (MI355X_MICROARCH.md HBM section), write factor ~1.0"},
+        "kernels": kernels,
+    }
+    json.dump(res, open(os.path.join(out, "counters.json"), "w"), indent=1)
+    for k, v in kernels.items():
+        print("%-18s %8.2f MB/scene HBM  avg %s ms" % (k, v.get("hbm_bytes_per_scene", 0) / 1e6, v.get("avg_ms_default_run")))
+    print("calibration factors: fetch %.3f write %.3f" % (f_fac, w_fac))
+    for dname in glob.glob(os.path.join(out, "raw_*")):
+        shutil.rmtree(dname, ignore_errors=True)     # keep gpurun_out small: the summaries are what is committed
+
+
+if __name__ == "__main__":
+    main()
