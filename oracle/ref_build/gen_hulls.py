@@ -38,6 +38,9 @@ def run(mesh_path):
         v = np.frombuffer(raw, np.float32, 3 * nv, off).reshape(nv, 3); off += 12 * nv
         t = np.frombuffer(raw, np.uint32, 3 * nt, off).reshape(nt, 3); off += 12 * nt
         out["v%d" % i], out["t%d" % i] = v.copy(), t.astype(np.int32)
+    from stillleben_amd import hulls as H
+
+    out["digests"] = np.array(H._mesh_digests(cm), dtype=np.uint64)   # the fixture is valid for THIS geometry only
     dst = mesh_path + ".hulls.npz"
     np.savez_compressed(dst, **out)
     print(mesh_path, "->", n, "hulls,", sum(len(out["v%d" % i]) for i in range(n)), "vertices,", os.path.getsize(dst) // 1024, "KiB")

@@ -1,14 +1,16 @@
 """Convex collision shapes for a mesh (reference Mesh::loadPhysics, src/mesh.cpp:304-533).
 
 The reference runs V-HACD twice (single hull, then concavity 0.002) and uses the decomposition
-only when its volume is < 75 % of the hull's (mesh.cpp:426-429).  V-HACD is a vendored
-third-party library of the reference and is not shipped here; this module provides
-  * the single convex hull (exact, scipy/Qhull) -- what PHYSICS_FORCE_CONVEX_HULL and every
-    mesh with convexity >= 0.75 uses, and
-  * pre-computed decompositions: `<mesh>.hulls.npz` next to the mesh file (generated with the
-    reference's V-HACD parameters by oracle/ref_build/gen_hulls.py) is picked up when present,
-  * a built-in approximate decomposition (recursive plane splits of the surface along the
-    longest axis while the hull volume ratio is < 0.75) for concave meshes without a cache.
+only when its volume is < 75 % of the hull's (mesh.cpp:426-429).  Here:
+  * `lib/libslvhacd.so` -- the SAME library (the reference's vendored third-party V-HACD, built by
+    `__graft_entry__.build()` from the sources where they lie, behind our C shim
+    csrc/host/slvhacd.cpp) run with the same two parameter sets and the same selection rule: this
+    is the decomposition behind `hulls_for_mesh` whenever the library is present;
+  * `<mesh>.sl_hulls` caches the result with the reference's invalidation keys (below);
+  * `<mesh>.hulls.npz` fixtures (tests/fixtures: cube, bunny) carry hulls made by the same library
+    for boxes without it; they are validated against the mesh's geometry digests;
+  * without the library: the exact single hull (scipy/Qhull) and, for concave meshes, a built-in
+    approximate splitter -- with a RuntimeWarning, because those parts are NOT V-HACD's.
 Hull vertices are limited to 64 (VHACD.h:235)."""
 import os
 
@@ -214,17 +216,92 @@ def write_cache(cache_file, data, flags, hulls):
         pass                              # read-only asset directory: the cache is an optimisation
 
 
+_VHACD = None
+VHACD_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libslvhacd.so")
+
+
+def vhacd_lib():
+    """ctypes handle of lib/libslvhacd.so, or None when it was not built (no /root/reference at build time)."""
+    global _VHACD
+    if _VHACD is None:
+        import ctypes as C
+
+        if not os.path.exists(VHACD_LIB):
+            _VHACD = False
+        else:
+            L = C.CDLL(VHACD_LIB)
+            L.slvhacd_decompose.restype = C.c_void_p
+            L.slvhacd_decompose.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]
+            L.slvhacd_free.argtypes = [C.c_void_p]
+            L.slvhacd_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            L.slvhacd_hull_size.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.slvhacd_hull_copy.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+            _VHACD = L
+    return _VHACD or None
+
+
+def vhacd_hulls(positions, indices, force_single=False):
+    """Mesh::loadPhysics' two V-HACD passes + selection rule (mesh.cpp:335-470) through lib/libslvhacd.so.
+    Returns (hulls, info) with info = dict(volume_single, volume_decomposition, used_decomposition), or None
+    when V-HACD could not build a hull with volume (the reference then hands the raw vertices to PhysX,
+    mesh.cpp:373-378 -- the caller falls back to the Qhull hull of the vertices)."""
+    import ctypes as C
+
+    L = vhacd_lib()
+    if L is None:
+        raise RuntimeError("lib/libslvhacd.so is not built")
+    v = np.ascontiguousarray(positions, dtype=np.float32)
+    t = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+    r = L.slvhacd_decompose(v.ctypes.data, len(v), t.ctypes.data, len(t) // 3, 1 if force_single else 0)   # releases the GIL
+    if not r:
+        raise RuntimeError("V-HACD failed")
+    try:
+        info = (C.c_uint32 * 3)()
+        vol = (C.c_double * 2)()
+        L.slvhacd_info(r, info, vol)
+        if info[2]:
+            return None
+        hulls = []
+        for i in range(info[0]):
+            nv, nt, hv = C.c_uint32(), C.c_uint32(), C.c_double()
+            L.slvhacd_hull_size(r, i, C.byref(nv), C.byref(nt), C.byref(hv))
+            hv_ = np.empty((nv.value, 3), np.float32)
+            ht_ = np.empty((nt.value, 3), np.uint32)
+            L.slvhacd_hull_copy(r, i, hv_.ctypes.data, ht_.ctypes.data)
+            hulls.append(Hull(hv_, ht_.astype(np.int32)))
+        return hulls, {"volume_single": vol[0], "volume_decomposition": vol[1], "used_decomposition": bool(info[1])}
+    finally:
+        L.slvhacd_free(r)
+
+
+_warned_no_vhacd = False
+
+
 def _compute_hulls(data, force):
+    global _warned_no_vhacd
+    if vhacd_lib() is not None:
+        res = vhacd_hulls(data.positions, data.indices, force_single=force)
+        if res is None:
+            return [_reduce(data.positions)]      # mesh.cpp:373-378: raw vertices -> the cooker's own hull
+        return res[0]
     single = _reduce(data.positions)
     if force:
         return [single]
     tris = data.indices.reshape(-1, 3).astype(np.int64)
-    mv = _mesh_volume(data.positions, data.indices)
     hv = single.volume()
-    if hv < 1e-9 or mv / max(hv, 1e-30) >= 0.75:  # mesh.cpp:373-378, :426-429
+    if hv < 1e-9:
         return [single]
     parts = _decompose(data.positions, tris, 0)
-    return parts if len(parts) > 1 else [single]
+    # the reference's criterion on what we have: sum of the parts' hull volumes against the single hull (mesh.cpp:426-429)
+    if len(parts) <= 1 or sum(p.volume() for p in parts) / hv >= 0.75:
+        return [single]
+    if not _warned_no_vhacd:
+        import warnings
+
+        warnings.warn("lib/libslvhacd.so is not built (run __graft_entry__.build() where /root/reference is present): concave "
+                      "meshes are split by the built-in approximate splitter, NOT by V-HACD as the reference does", RuntimeWarning)
+        _warned_no_vhacd = True
+    return parts
 
 
 def hulls_for_mesh(mesh, use_cache=True):
@@ -235,8 +312,10 @@ def hulls_for_mesh(mesh, use_cache=True):
     fixture = mesh._filename + ".hulls.npz"   # decompositions made with the reference's V-HACD (oracle/ref_build/gen_hulls.py)
     if not force and os.path.exists(fixture):
         z = np.load(fixture)
-        n = int(z["n_hulls"])
-        return [Hull(z["v%d" % i], z["t%d" % i]) for i in range(n)]
+        # a fixture belongs to ONE geometry: stale after an asset edit (files without digests predate the check)
+        if "digests" not in z.files or tuple(int(x) for x in z["digests"]) == _mesh_digests(data):
+            n = int(z["n_hulls"])
+            return [Hull(z["v%d" % i], z["t%d" % i]) for i in range(n)]
     on_disk = use_cache and "://" not in mesh._filename and os.path.exists(mesh._filename)   # primitive:// etc.: no cache (mesh.cpp:323)
     cache_file = mesh._filename + CACHE_SUFFIX
     if on_disk:

@@ -3,9 +3,13 @@ YCB-Video models are not redistributable/available offline, so each of the 21 cl
 reference examples/ycb.py:21-30 is approximated by a compound of convex primitives
 (cans = cylinders, boxes, bowl/mug = rings of wall segments, banana = bent chain, drill/clamps =
 box compounds), tessellated to ~8192 vertices / ~16384 triangles with a seeded 1024^2 noise
-texture.  Because every part is convex, the collision hulls are known by construction (one hull
-per part, <= 64 vertices), so no convex decomposition is needed."""
+texture.  Collision hulls: like every mesh of the reference these go through Mesh::loadPhysics' V-HACD
+procedure (hulls.vhacd_hulls: lib/libslvhacd.so, mesh.cpp:335-470); the result for the default set
+(seed 0, 8192 vertices) is shipped as data/ycb_like_hulls_seed0.npz, keyed by the meshes' geometry
+digests, so that a box without the library (or without minutes to spare) loads the very same hulls.
+`hulls="parts"` gives the by-construction hulls instead (one convex hull per primitive part)."""
 import math
+import os
 
 import numpy as np
 
@@ -218,15 +222,73 @@ def make_class_mesh(name, seed=0, target_verts=8192, tex_size=1024):
     return cm, hulls
 
 
-def ycb_like_meshes(seed=0, target_verts=8192, tex_size=1024):
+HULL_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "ycb_like_hulls_seed%d.npz")
+
+
+def _shipped_hulls(seed, cms):
+    """The V-HACD hulls shipped for this seed, if every mesh's geometry digests match; else None."""
+    from . import hulls as H
+
+    path = HULL_DATA % seed
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    out = []
+    for name, cm in zip(YCB_CLASSES, cms):
+        key = name + "/"
+        if key + "digests" not in z.files or tuple(int(x) for x in z[key + "digests"]) != H._mesh_digests(cm):
+            return None
+        out.append([H.Hull(z["%sv%d" % (key, i)], z["%st%d" % (key, i)]) for i in range(int(z[key + "n"]))])
+    return out
+
+
+def write_hull_data(seed=0, target_verts=8192):
+    """Developer step (needs lib/libslvhacd.so): runs V-HACD on the set and writes data/ycb_like_hulls_seed<seed>.npz."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import hulls as H
+
+    cms = [make_class_mesh(name, seed, target_verts, 64)[0] for name in YCB_CLASSES]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:      # the C call releases the GIL
+        res = list(ex.map(lambda cm: H._compute_hulls(cm, False), cms))
+    out = {}
+    for name, cm, hs in zip(YCB_CLASSES, cms, res):
+        key = name + "/"
+        out[key + "digests"] = np.array(H._mesh_digests(cm), dtype=np.uint64)
+        out[key + "n"] = np.int32(len(hs))
+        for i, h in enumerate(hs):
+            out["%sv%d" % (key, i)], out["%st%d" % (key, i)] = h.vertices, h.triangles
+    os.makedirs(os.path.dirname(HULL_DATA), exist_ok=True)
+    np.savez_compressed(HULL_DATA % seed, **out)
+    return {n: len(h) for n, h in zip(YCB_CLASSES, res)}
+
+
+def ycb_like_meshes(seed=0, target_verts=8192, tex_size=1024, hulls="vhacd"):
     """21 sl.Mesh objects named after the YCB-Video classes, class_index = i + 1
-    (reference examples/ycb.py:46-48)."""
+    (reference examples/ycb.py:46-48).  hulls: "vhacd" (the reference's procedure: shipped data when it
+    matches the geometry, else computed with lib/libslvhacd.so) or "parts" (by construction)."""
+    from . import hulls as H
     from .mesh import Mesh
 
+    made = [make_class_mesh(name, seed, target_verts, tex_size) for name in YCB_CLASSES]
+    sets = [h for _, h in made]
+    if hulls == "vhacd":
+        shipped = _shipped_hulls(seed, [cm for cm, _ in made]) if target_verts == 8192 else None
+        if shipped is not None:
+            sets = shipped
+        elif H.vhacd_lib() is not None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+                sets = list(ex.map(lambda m: H._compute_hulls(m[0], False), made))
+        else:
+            raise RuntimeError("ycb_like_meshes(hulls='vhacd'): neither shipped hull data for this seed / size nor "
+                               "lib/libslvhacd.so is available; pass hulls='parts' for the by-construction hulls")
+    elif hulls != "parts":
+        raise ValueError("hulls must be 'vhacd' or 'parts'")
     out = []
-    for i, name in enumerate(YCB_CLASSES):
-        cm, hulls = make_class_mesh(name, seed, target_verts, tex_size)
-        m = Mesh.from_data(cm, hulls, "synthetic://ycb/%s" % name)
+    for i, (name, (cm, _), hs) in enumerate(zip(YCB_CLASSES, made, sets)):
+        m = Mesh.from_data(cm, hs, "synthetic://ycb/%s" % name)
         m.class_index = i + 1
         out.append(m)
     return out

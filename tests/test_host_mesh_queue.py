@@ -111,3 +111,54 @@ def test_job_queue_returns_scenes_in_submission_order(sl, monkeypatch):
     with pytest.raises(RuntimeError):
         q.retrieve_scene()
     q.stop()
+
+
+def test_vhacd_is_the_decomposition_behind_hulls_for_mesh(sl):
+    """Mesh::loadPhysics (reference src/mesh.cpp:335-470): with lib/libslvhacd.so (the reference's vendored V-HACD
+    behind our C shim) the bunny decomposes into the reference's 121 hulls / 1 428 vertices WITHOUT the fixture, the
+    cube stays one 8-vertex hull, PHYSICS_FORCE_CONVEX_HULL gives one hull; SURVEY.md 8a row S1."""
+    from stillleben_amd import _loaders, hulls
+
+    if hulls.vhacd_lib() is None:
+        pytest.skip("lib/libslvhacd.so not built on this box (needs /root/reference at build time)")
+    cm = _loaders.load_any(S.BUNNY)
+    hs, info = hulls.vhacd_hulls(cm.positions, cm.indices)
+    assert len(hs) == 121 and sum(len(h.vertices) for h in hs) == 1428 and info["used_decomposition"]
+    assert info["volume_decomposition"] / info["volume_single"] < 0.75
+    assert max(len(h.vertices) for h in hs) <= 64            # VHACD.h:235
+    fx = np.load(S.BUNNY + ".hulls.npz")                      # the committed fixture is this very output
+    assert int(fx["n_hulls"]) == 121 and all(np.array_equal(fx["v%d" % i], hs[i].vertices) for i in range(121))
+    single, info1 = hulls.vhacd_hulls(cm.positions, cm.indices, force_single=True)
+    assert len(single) == 1 and not info1["used_decomposition"]
+    cube = _loaders.load_any(S.CUBE)
+    hc, ic = hulls.vhacd_hulls(cube.positions, cube.indices)
+    assert len(hc) == 1 and len(hc[0].vertices) == 8 and ic["volume_single"] == pytest.approx(8.0)
+    # and hulls_for_mesh routes through it: a copy of the cube WITHOUT fixture / cache next to it
+    assert len(hulls._compute_hulls(cube, False)) == 1
+
+
+def test_hull_fixture_is_rejected_after_a_geometry_edit(sl, tmp_path):
+    import shutil
+
+    from stillleben_amd import hulls
+
+    dst = tmp_path / "cube.glb"
+    shutil.copy(S.CUBE, dst)
+    shutil.copy(S.CUBE + ".hulls.npz", str(dst) + ".hulls.npz")
+    m = sl.Mesh(str(dst), physics=False)
+    good = hulls.hulls_for_mesh(m, use_cache=False)
+    assert len(good) == 1 and np.abs(good[0].vertices).max() == pytest.approx(1.0)
+    m._data.positions = (m._data.positions * 2.0).astype(np.float32)       # the asset changed, the fixture did not
+    after = hulls.hulls_for_mesh(m, use_cache=False)
+    assert np.abs(after[0].vertices).max() == pytest.approx(2.0)           # recomputed, not the stale fixture
+
+
+def test_synthetic_set_ships_the_vhacd_hulls(sl):
+    from stillleben_amd import synthetic
+
+    meshes = synthetic.ycb_like_meshes(seed=0, tex_size=64)
+    n = {m.filename.split("/")[-1]: len(m._hulls) for m in meshes}
+    assert n["011_banana"] == 44 and n["024_bowl"] == 28 and n["025_mug"] == 28 and n["003_cracker_box"] == 1
+    assert all(len(h.vertices) <= 64 for m in meshes for h in m._hulls)
+    parts = synthetic.ycb_like_meshes(seed=0, tex_size=64, hulls="parts")
+    assert len(parts[9]._hulls) != 44
