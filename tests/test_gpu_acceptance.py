@@ -1,0 +1,106 @@
+"""Acceptance tests through `import stillleben as sl`: the call sequence of the reference's examples/ycb.py:36-80
+on committed synthetic stand-ins for <YCB-Video>/models/*/textured.obj (tests/fixtures/ycb_mini), sl.JobQueue's
+submission-order contract with the real settle (src/job_queue.cpp:55-82) and Mesh.load_threaded (mesh.cpp:923-999)."""
+import pathlib
+import random
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MODELS = pathlib.Path(__file__).parent / "fixtures" / "ycb_mini" / "models"
+CLASSES = ('__background__',) + tuple(sorted(p.name for p in MODELS.iterdir()))
+RESOLUTION = (640, 480)
+INTRINSICS = (1066.778, 1067.487, 312.9869, 241.3109)
+
+
+@pytest.fixture(scope="module")
+def slx():
+    import stillleben as sl      # the alias package: a user of the reference changes nothing but the install
+
+    sl.init()
+    return sl
+
+
+def test_examples_ycb_call_sequence(slx):
+    sl = slx
+    random.seed(3)
+    # --- examples/ycb.py:40-47
+    meshes = sl.Mesh.load_threaded([MODELS / c / 'textured.obj' for c in CLASSES[1:]])
+    for i, mesh in enumerate(meshes):
+        mesh.class_index = i + 1
+    # --- :49-58 (the example samples 10 of 21 models; the fixture has 4 classes, two instances of each)
+    scene = sl.Scene(RESOLUTION)
+    scene.set_camera_intrinsics(*INTRINSICS)
+    for mesh in random.sample(meshes * 2, 6):
+        obj = sl.Object(mesh)
+        obj.metallic = random.random()
+        obj.roughness = random.random()
+        scene.add_object(obj)
+    # --- :60-61
+    scene.simulate_tabletop_scene()
+    # --- :63-67: without --ibl the example calls the deprecated no-op (quirk q3, py_scene.cpp:350-352)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        scene.choose_random_light_position()
+    assert len(w) == 1
+    # --- :69-74
+    scene.background_plane_size = torch.tensor([3.0, 3.0])
+    scene.background_color = torch.tensor([0.1, 0.1, 0.1, 1.0])
+    # sl.view(scene) (:77) is the interactive viewer: out of scope; headless shim that warns so that the script goes on
+    with pytest.warns(UserWarning):
+        sl.view(scene)
+    # --- :79-84
+    renderer = sl.RenderPass()
+    result = renderer.render(scene)
+    rgb = result.rgb()[:, :, :3].cpu().numpy()
+    assert rgb.shape == (480, 640, 3) and rgb.dtype == np.uint8
+    # what the reference's own tests check on such a frame (tests/test_python.py:44-60, tests/basic.cpp:173-260)
+    inst = result.instance_index()
+    assert inst.dtype == torch.int16 and tuple(inst.shape) == (480, 640, 1)
+    ids = set(torch.unique(inst).tolist())
+    assert ids <= set(range(0, 7)) and len(ids - {0}) >= 4          # the heap is in view (chooseRandomCameraPose)
+    cls = result.class_index()
+    assert set(torch.unique(cls).tolist()) <= set(range(0, len(CLASSES)))
+    for o in scene.objects:                                          # class of every visible instance = its mesh's
+        m = inst == o.instance_index
+        if bool(m.any()):
+            assert set(torch.unique(cls[m]).tolist()) == {o.mesh.class_index}
+    depth = result.depth()
+    assert tuple(depth.shape) == (480, 640) and float(depth[inst[..., 0] > 0].min()) > 0.1
+    assert float(depth.max()) <= 3000.0
+    # quirk q3: no light direction was chosen and there is no ambient light -> objects render black, like the reference
+    assert int(rgb[inst[..., 0].cpu().numpy() > 0].max()) == 0
+    # settled: nothing below the table, nothing moving
+    for o in scene.objects:
+        assert float(o.pose()[2, 3]) > 0.0 and float(o.linear_velocity.abs().max()) < 0.2
+    # with a light the same frame shows the objects
+    scene.choose_random_light_direction()
+    lit = renderer.render(scene).rgb()[:, :, :3].cpu().numpy()
+    assert int(lit[inst[..., 0].cpu().numpy() > 0].max()) > 30
+
+
+def test_job_queue_settles_and_returns_in_submission_order(slx):
+    """examples-style use of sl.JobQueue (python/src/py_job_queue.cpp:18-48): scenes come back first-in first-out, each
+    one settled (its camera placed by simulateTableTopScene's last step, scene.cpp:758)."""
+    sl = slx
+    meshes = sl.Mesh.load_threaded([MODELS / c / 'textured.obj' for c in CLASSES[1:]])
+    q = sl.JobQueue()
+    scenes = []
+    for k in range(5):
+        s = sl.Scene(RESOLUTION)
+        for mesh in meshes[:3]:
+            s.add_object(sl.Object(mesh))
+        scenes.append(s)
+        q.add_scene(s)
+    out = [q.retrieve_scene() for _ in range(5)]
+    assert all(a is b for a, b in zip(out, scenes))
+    for s in out:
+        z = [float(o.pose()[2, 3]) for o in s.objects]
+        assert min(z) > 0.0 and max(z) < 0.5                      # dropped from the stack onto the table
+        assert not torch.equal(s.camera_pose(), torch.eye(4))       # chooseRandomCameraPose ran
+    with pytest.raises(RuntimeError, match="No scenes in work queue"):
+        q.retrieve_scene()

@@ -211,7 +211,7 @@ def test_fragment_at_the_far_plane_loses(sl, oracle, eng):
     import bench
     from stillleben_amd import physics, synthetic
 
-    meshes = synthetic.ycb_like_meshes(seed=0, tex_size=64)
+    meshes = synthetic.ycb_like_meshes(seed=0, tex_size=64, hulls="parts")   # the hull set the soak found this scene with
     scene = bench.make_scene(sl, meshes, 610184)
     physics.settle_batch([scene])
     scene.choose_random_camera_pose()
