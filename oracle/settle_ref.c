@@ -162,6 +162,7 @@ typedef struct {
     int body_lh[SLHIP_MAX_BODIES + 1]; /* first hull ordinal of every body */
 } scene_ws;
 
+
 /* ------------------------------------------------------------------------------------------ */
 /* support mapping + GJK distance                                                              */
 /* ------------------------------------------------------------------------------------------ */
@@ -1106,6 +1107,11 @@ static void redrop(const slhip_settle_scene* sc, slhip_body* bodies, int me, con
     }
 }
 
+/* optional per-frame trace for the tests: trace[(s * frames + f) * 4 + {0,1,2,3}] = bodies asleep, redrops so far,
+   active contacts of the frame's last step, max |v| */
+static float* g_trace = NULL;
+void slref_settle_set_trace(float* t) { g_trace = t; }
+
 int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body* bodies,
                  const slhip_hull* hulls, const float* hull_verts, const slhip_settle_params* prm)
 {
@@ -1127,12 +1133,26 @@ int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body
         for (uint32_t f = 0; f < prm->frames; ++f) {
             for (uint32_t ss = 0; ss < prm->substeps; ++ss) step_scene(sc, bodies, hulls, hull_verts, prm, ws);
             if (!prm->tabletop) continue;
+            int moved = 0;
             for (int i = 0; i < nb; ++i) { /* scene.cpp:742-755 */
                 if (b[i].flags & SLHIP_BODY_STATIC) continue;
-                if (b[i].pose[11] < prm->redrop_z) redrop(sc, b, i, prm);
+                if (b[i].pose[11] < prm->redrop_z) { redrop(sc, b, i, prm); moved = 1; }
                 else if (b[i].separation < prm->stuck_separation) {
-                    if (++b[i].stuck_counter > prm->stuck_frames) redrop(sc, b, i, prm);
+                    if (++b[i].stuck_counter > prm->stuck_frames) { redrop(sc, b, i, prm); moved = 1; }
                 } else if (b[i].stuck_counter > 0) b[i].stuck_counter--;
+            }
+            if (g_trace) {
+                float* t = g_trace + ((size_t)s * prm->frames + f) * 4;
+                int asleep = 0, active = 0;
+                float vmax = 0.0f;
+                for (int i = 0; i < nb; ++i) {
+                    if (b[i].flags & SLHIP_BODY_ASLEEP) ++asleep;
+                    const float v = sqrtf(dot(V(b[i].lin_vel[0], b[i].lin_vel[1], b[i].lin_vel[2]), V(b[i].lin_vel[0], b[i].lin_vel[1], b[i].lin_vel[2])));
+                    if (v > vmax) vmax = v;
+                }
+                for (int g = 0; g < ws->n_groups; ++g)
+                    for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) active += ws->c[i].valid ? 1 : 0;
+                t[0] = (float)asleep; t[1] = (f ? t[1 - 4] : 0.0f) + (moved ? 1.0f : 0.0f); t[2] = (float)active; t[3] = vmax;
             }
         }
         free(ws->cache);

@@ -793,6 +793,10 @@ __device__ __forceinline__ int sg16_walk_band(const WBody& w, const HullRef* lh,
     int ord = 0;
     for (int h = lh_begin; h < lh_end; ++h) {
         const HullRef H = lh[h];
+        // a hull whose bounding sphere clears the contact band has no in-band vertex: skipping it leaves the
+        // ordinals (they count in-band vertices only) and every selection untouched.  The slack (0.1 mm) is
+        // orders of magnitude above the rounding of the sphere and vertex transforms.
+        if (fmaf(w.R.m[8], H.sc.z, fmaf(w.R.m[7], H.sc.y, w.R.m[6] * H.sc.x)) + w.t.z - H.sr - plane_z > margin + 1.0e-4f) continue;
         for (int i0 = 0; i0 < H.count; i0 += 16) {
             const int i = i0 + sl;
             bool in = false;

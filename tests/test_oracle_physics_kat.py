@@ -1,0 +1,158 @@
+"""Physics known answers for the settle ORACLE that do not depend on any choice of this repository: they follow
+from the constants the reference configures (materials 0.3/0.2/0.1 and plane 0.5/0.5/0
+averaged, bounce threshold 2 m/s, angular damping 0.05 1/s, max angular velocity 100 rad/s, gravity 9.81) and
+Newtonian mechanics.  `oracle/settle_ref.c` is "parity unpinned" against PhysX output (the library cannot be built
+here); these tests bound how far it can be from ANY correct rigid-body solver configured that way."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import scenes as S
+from stillleben_amd import _settle_batch as SB
+
+TABLE = 0.04
+G = 9.81
+
+
+def cube_mesh(sl, diag=0.2):
+    m = sl.Mesh(S.CUBE)
+    m.center_bbox()
+    m.scale_to_bbox_diagonal(diag)
+    return m
+
+
+def half_edge(diag=0.2):
+    return diag / math.sqrt(3.0) / 2.0
+
+
+def build(sl, poses, plane=True, diag=0.2, vel=None, ang=None):
+    cube = cube_mesh(sl, diag)
+    scene = sl.Scene((64, 48))
+    for i, p in enumerate(poses):
+        o = sl.Object(cube)
+        scene.add_object(o)
+        o.set_pose(torch.from_numpy(np.asarray(p, np.float32)))
+        if vel is not None:
+            o.linear_velocity = torch.tensor(vel[i], dtype=torch.float32)
+        if ang is not None:
+            o.angular_velocity = torch.tensor(ang[i], dtype=torch.float32)
+    pool = SB.HullPool()
+    srec, bodies = SB.build_settle_batch([scene], pool, [(plane, TABLE)])
+    hulls, verts = pool.arrays()
+    return srec, bodies, hulls, verts
+
+
+def at(x, y, z):
+    p = np.eye(4, dtype=np.float32)
+    p[:3, 3] = (x, y, z)
+    return p
+
+
+def step(oracle, state, n, dt=0.01, gravity=(0.0, 0.0, -G)):
+    """n steps in ONE settle call (the solver's warm-start cache lives for the duration of a call)."""
+    srec, bodies, hulls, verts = state
+    prm = SB.default_params(tabletop=False, dt=dt, frames=n, substeps=1)
+    prm["gravity"] = gravity
+    bodies["flags"] &= ~np.uint32(SB.BODY_ASLEEP)
+    bodies["wake_counter"] = 0.4
+    oracle.settle(srec, bodies, hulls, verts, prm)
+    return bodies
+
+
+@pytest.mark.parametrize("tan_theta,slides", [(0.25, False), (0.34, False), (0.50, True), (0.70, True)])
+def test_friction_cone_threshold_on_an_incline(sl, oracle, tan_theta, slides):
+    """A block on an incline of angle theta (gravity tilted instead of the plane) stays put iff tan(theta) <= mu_s and
+    otherwise accelerates at g (sin - mu_d cos).  Cube vs table: mu_s = (0.3 + 0.5) / 2 = 0.4, mu_d = (0.2 + 0.5) / 2 = 0.35
+    (context.cpp:250-252, scene.cpp:645, PhysX average combine mode)."""
+    th = math.atan(tan_theta)
+    g = (G * math.sin(th), 0.0, -G * math.cos(th))
+    h = half_edge()
+    state = build(sl, [at(0, 0, TABLE + h + 0.0015)])
+    step(oracle, state, 30, gravity=(0.0, 0.0, -G * math.cos(th)))        # settle into the resting contact first
+    x0 = float(state[1][0]["pose"][3])
+    T = 1.0
+    b = step(oracle, state, int(T / 0.01), gravity=g)
+    dx = float(b[0]["pose"][3]) - x0
+    if not slides:
+        assert abs(dx) < 2e-3, "block crept %.4f m on a slope below the friction cone" % dx
+        assert abs(float(b[0]["lin_vel"][0])) < 5e-3
+    else:
+        a = G * (math.sin(th) - 0.35 * math.cos(th))
+        assert dx == pytest.approx(0.5 * a * T * T, rel=0.2), "slid %.3f m, Coulomb predicts %.3f" % (dx, 0.5 * a * T * T)
+        assert float(b[0]["lin_vel"][0]) == pytest.approx(a * T, rel=0.2)
+    assert abs(float(b[0]["pose"][7])) < 1e-3                                   # no sideways drift
+    assert float(b[0]["pose"][11]) == pytest.approx(TABLE + h + 0.0015, abs=2e-3)   # stays on the table
+
+
+@pytest.mark.parametrize("v_impact,bounces", [(4.0, True), (1.0, False)])
+def test_restitution_only_above_the_bounce_threshold(sl, oracle, v_impact, bounces):
+    """Cube falling flat on the table: restitution e = (0.1 + 0) / 2 = 0.05 applies only when the approach speed exceeds
+    the bounce threshold 0.2 * tolerance speed = 2 m/s: rebound speed e * v above it, ~0 below."""
+    h = half_edge()
+    gap = 0.05
+    v0 = -math.sqrt(max(0.0, v_impact ** 2 - 2 * G * gap))
+    state = build(sl, [at(0, 0, TABLE + h + gap)], vel=[(0, 0, v0)])
+    vmax_up, vmin = 0.0, 0.0
+    for _ in range(60):
+        b = step(oracle, state, 1, dt=0.0025)      # impact: no resting contact whose impulses would need carrying over
+        vz = float(b[0]["lin_vel"][2])
+        vmin = min(vmin, vz)
+        vmax_up = max(vmax_up, vz)
+    assert vmin == pytest.approx(-v_impact, rel=0.03)                          # it did reach the impact speed
+    # (the speculative contact reverses the body within one step's travel of the surface, as PhysX's does)
+    assert float(b[0]["pose"][11]) > TABLE + h - 1e-3                          # no tunnelling
+    if bounces:
+        assert vmax_up == pytest.approx(0.05 * v_impact, rel=0.35, abs=0.03)
+    else:
+        assert vmax_up < 0.03
+
+
+def test_angular_damping_decay_and_no_linear_damping(sl, oracle):
+    """Free body, no gravity: omega decays by (1 - 0.05 dt) per step (PhysX angular damping 0.05), the linear
+    velocity is untouched (linear damping 0)."""
+    state = build(sl, [at(0, 0, 1.0)], plane=False, vel=[(0.3, -0.2, 0.1)], ang=[(0.0, 0.0, 2.0)])
+    b = step(oracle, state, 100, gravity=(0.0, 0.0, 0.0))
+    assert float(b[0]["ang_vel"][2]) == pytest.approx(2.0 * (1.0 - 0.05 * 0.01) ** 100, rel=2e-3)
+    assert np.allclose(b[0]["lin_vel"][:3], (0.3, -0.2, 0.1), atol=1e-6)
+    assert np.allclose(b[0]["pose"].reshape(4, 4)[:3, 3], (0.3, -0.2, 1.1), atol=1e-4)
+
+
+def test_angular_velocity_is_clamped_at_100_rad_s(sl, oracle):
+    state = build(sl, [at(0, 0, 1.0)], plane=False, ang=[(300.0, 0.0, 400.0)])
+    b = step(oracle, state, 1, gravity=(0.0, 0.0, 0.0))
+    w = b[0]["ang_vel"][:3]
+    assert float(np.linalg.norm(w)) == pytest.approx(100.0, rel=1e-3)
+    assert np.allclose(w / np.linalg.norm(w), (0.6, 0.0, 0.8), atol=1e-4)      # direction kept
+
+
+@pytest.mark.parametrize("n", [3, pytest.param(5, marks=pytest.mark.xfail(strict=True, reason=(
+    "KNOWN MODEL LIMIT (DESIGN.md section 2): the solver starts every step from zero impulses (PhysX warm-starts its "
+    "persistent manifolds) and rebuilds the manifold from GJK + tilt runs, so 4 + 4 Gauss-Seidel sweeps carry a column of "
+    "three cubes but a column of five jitters (|v| ~ 0.05 m/s, never sleeps) and topples after ~2 s; in the tabletop "
+    "settle such interpenetrations are caught by the reference's own redrop rule (scene.cpp:742-755)")))])
+def test_cube_stack_stands_for_four_seconds(sl, oracle, n):
+    h = half_edge()
+    zs = [TABLE + h + 0.0015 + k * (2 * h + 0.003) for k in range(n)]
+    state = build(sl, [at(0, 0, z) for z in zs])
+    b = step(oracle, state, 400)
+    assert np.allclose(b["pose"][:, 11], zs, atol=4e-3), b["pose"][:, 11]
+    assert np.abs(b["pose"][:, [3, 7]]).max() < 5e-3                             # no lateral creep
+    for k in range(n):
+        R = b[k]["pose"].reshape(4, 4)[:3, :3]
+        assert math.degrees(math.acos(min(1.0, float(R[2, 2])))) < 0.5            # stays upright ...
+        assert math.degrees(math.acos(min(1.0, (np.trace(R) - 1.0) / 2.0))) < 3.0  # ... a little yaw creep is tolerated
+    assert np.abs(b["lin_vel"]).max() < 0.02 and np.abs(b["ang_vel"]).max() < 0.2
+
+
+def test_head_on_collision_conserves_momentum(sl, oracle):
+    """Two equal cubes, no gravity, closing at 3 m/s (> bounce threshold): total momentum is conserved exactly by
+    equal-and-opposite impulses; the separation speed is e * 3 with e = 0.1 (both default materials)."""
+    h = half_edge()
+    state = build(sl, [at(-h - 0.02, 0, 1.0), at(h + 0.02, 0, 1.0)], plane=False, vel=[(1.5, 0, 0), (-1.5, 0, 0)])
+    b = step(oracle, state, 30, dt=0.002, gravity=(0.0, 0.0, 0.0))
+    v = b["lin_vel"][:, 0]
+    assert float(v[0] + v[1]) == pytest.approx(0.0, abs=1e-4)
+    assert float(v[1] - v[0]) == pytest.approx(0.1 * 3.0, rel=0.35, abs=0.05)       # now separating
+    assert np.abs(b["lin_vel"][:, 1:3]).max() < 1e-3 and np.abs(b["ang_vel"]).max() < 0.05
