@@ -27,19 +27,20 @@ sys.path.insert(0, ROOT)
 RESOLUTION = (640, 480)
 INTRINSICS = (1066.778, 1067.487, 312.9869, 241.3109)  # reference examples/ycb.py:32
 N_OBJECTS = 20
+TARGET_RING = 8     # render-target sets kept alive (chunks of --render-chunk scenes)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096,
                     help="scenes per GPU per step (one settle launch: two rounds of the 2048 resident scenes = 256 CUs x 8; the second round back-fills the tail of the first)")
     ap.add_argument("--render-chunk", type=int, default=None,
                     help="scenes per render launch sequence (fewer, larger sequences: every kernel boundary is a chance for "
-                         "queued settle workgroups to take the freed SIMDs); default 512")
-    ap.add_argument("--settle-streams", type=int, default=3,
+                         "queued settle workgroups to take the freed SIMDs); default 1024")
+    ap.add_argument("--settle-streams", type=int, default=2,
                     help="settle launches kept in flight: scenes settle in very different times, and a second "
                          "launch on its own stream back-fills the CUs the tail of the first one leaves idle")
     ap.add_argument("--gather-scenes", type=int, default=64,
@@ -92,7 +93,8 @@ class Pipeline:
         self.s_settle = [torch.cuda.Stream(device=dev) for _ in range(settle_streams)]
         self.s_render = torch.cuda.Stream(device=dev)
         self.free = [None] * self.ring        # event: the set's previous render finished (its records may be rewritten)
-        self.buffers = []                     # render targets per chunk index, reused step after step
+        self.buffers = []                     # ring of render-target sets: a chunk's ground truth stays in HBM until TARGET_RING
+                                              # further chunks have been rendered (50 GB of the last 4096 scenes at the defaults)
         self.gatherer = None
         self.gather_scenes = 0
         self.pending = []
@@ -123,15 +125,16 @@ class Pipeline:
         with torch.cuda.stream(self.s_render):
             self.s_render.wait_event(rec["placed"])
             for ci in range(b.n_render_chunks()):
-                if ci == 0:
+                slot = ci % TARGET_RING
+                if slot == 0:
                     for w in self.pending:
-                        w.wait()      # the previous step's gather reads chunk 0's targets: order the re-render after it
+                        w.wait()      # a gather still reads slot 0's targets: order the re-render after it
                     self.pending = []
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                buf = b.render(ci, self.mask, ssao=self.ssao, buffers=self.buffers[ci] if ci < len(self.buffers) else None)
+                buf = b.render(ci, self.mask, ssao=self.ssao, buffers=self.buffers[slot] if slot < len(self.buffers) else None)
                 e1.record()
-                if ci >= len(self.buffers):
+                if slot >= len(self.buffers):
                     self.buffers.append(buf)
                 revs.append((e0, e1))
                 if ci == 0 and self.gatherer is not None and self.gather_scenes > 0:
@@ -279,7 +282,7 @@ def main():
     meshes = synthetic.ycb_like_meshes(seed=0)
     table = sl.AssetTable(meshes)                 # once per process: the 21 classes' vertices, textures, hulls -> HBM
     if args.render_chunk is None:
-        args.render_chunk = 512
+        args.render_chunk = 1024
     args.render_chunk = min(args.render_chunk, args.batch)
     pipe = Pipeline(sl, table, args.batch, args.render_chunk, not args.no_ssao, max(1, args.settle_streams), seed=20260929, rank=rank)
     pipe.eng.L.slhip_timing_enable(1)
@@ -353,7 +356,7 @@ def main():
         for ci in range(b_last.n_render_chunks()):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            b_last.render(ci, pipe.mask, ssao=pipe.ssao, buffers=pipe.buffers[ci])
+            b_last.render(ci, pipe.mask, ssao=pipe.ssao, buffers=pipe.buffers[ci % TARGET_RING])
             e1.record()
             iso_wall.append((e0, e1))
     torch.cuda.synchronize()

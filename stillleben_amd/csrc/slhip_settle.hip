@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                const slhip_hull* __restrict__ hulls,
                                                const float* __restrict__ hull_verts, slhip_settle_params prm,
                                                LdsLayout L, ProfScratch* prof_all, DriveAcc* drive_all,
-                                               GjkSeed* cache_all, unsigned cache_stride)
+                                               GjkSeed* cache_all, unsigned cache_stride, int continued)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WBody* wb = reinterpret_cast<WBody*>(smem + L.off_wb);
@@ -1336,7 +1336,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (n_hulls > 0 && n_hulls <= SLHIP_PAIR_CACHE_MAX_HULLS && (unsigned)(n_hulls * n_hulls) <= cache_stride) {
         cache = cache_all + (size_t)blockIdx.x * cache_stride;
         int4* z = reinterpret_cast<int4*>(cache);
-        for (int k = lane; k < n_hulls * n_hulls; k += 64) z[k] = make_int4(0, 0, 0, 0);
+        // a settle may be launched in segments of frames (slhip_settle): everything a scene carries from step to step
+        // lives in global memory (bodies, pair cache, drive accumulators), so a continuation only keeps the cache
+        if (!continued)
+            for (int k = lane; k < n_hulls * n_hulls; k += 64) z[k] = make_int4(0, 0, 0, 0);
     }
     __syncthreads();
 
@@ -1881,6 +1884,8 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
     }
 }
 
+#include "slhip_settle_wide.inc"
+
 }  // namespace
 
 // entries of one scene's pair cache: (hulls per scene)^2, from the hint (0 or beyond the cap: the cap)
@@ -1897,9 +1902,36 @@ static uint64_t settle_fixed_bytes(uint32_t n_scenes)
     const uint64_t b = (uint64_t)n_scenes * (sizeof(ProfScratch) + SLHIP_MAX_BODIES * sizeof(DriveAcc));
     return (b + 255u) & ~(uint64_t)255u;
 }
+static int hint_nb_cap(const slhip_settle_params* params)
+{
+    return params && params->max_bodies_per_scene ? (int)params->max_bodies_per_scene : SLHIP_MAX_BODIES;
+}
+static int hint_lh_cap(const slhip_settle_params* params)
+{
+    return params && params->max_hulls_per_scene ? (int)params->max_hulls_per_scene : 1024;
+}
+static uint64_t settle_cache_bytes(uint32_t n_scenes, const slhip_settle_params* params)
+{
+    const uint64_t b = (uint64_t)n_scenes * pair_cache_stride(params) * sizeof(GjkSeed);
+    return (b + 255u) & ~(uint64_t)255u;
+}
+// [fixed][pair cache][state of the lockstep pipeline (slhip_settle_wide.inc)]
 static uint64_t settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params)
 {
-    return settle_fixed_bytes(n_scenes) + (uint64_t)n_scenes * pair_cache_stride(params) * sizeof(GjkSeed) + 256;
+    return settle_fixed_bytes(n_scenes) + settle_cache_bytes(n_scenes, params) +
+           wide_bytes(n_scenes, hint_nb_cap(params), hint_lh_cap(params)) + 256;
+}
+
+// Two implementations of the same step (same device functions, bit-identical results, both parity-tested):
+//   persistent (default)  k_settle: one wave per scene for the whole settle, scene state in LDS
+//   lockstep              slhip_settle_wide.inc: five launches per step over the whole batch, state in HBM / L2
+// Measured on the C2 workload (profiles/r02): the lockstep narrowphase kernels fill their waves
+// (lane = hull pair), but every launch waits for its slowest scene and the per-scene solver chain is as long as before, so at
+// 4096 scenes it needs 677 ms against 659 ms and loses 10 % in the pipelined benchmark; SLHIP_SETTLE_IMPL=lockstep selects it.
+static bool use_persistent_settle()
+{
+    const char* e = getenv("SLHIP_SETTLE_IMPL");
+    return !(e && e[0] == 'l');
 }
 
 extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out)
@@ -1931,6 +1963,42 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         slhip::set_error("slhip_settle: at most %d bodies per scene", SLHIP_MAX_BODIES);
         return -1;
     }
+    if (!use_persistent_settle()) {
+        const int lhc = hint_lh_cap(params);
+        if (n_scenes > 65535u) {
+            slhip::set_error("slhip_settle: at most 65535 scenes per launch");
+            return -1;
+        }
+        ProfScratch* prof_w = reinterpret_cast<ProfScratch*>(d_scratch);
+        DriveAcc* drive_w = reinterpret_cast<DriveAcc*>(prof_w + n_scenes);
+        char* base = reinterpret_cast<char*>(d_scratch) + settle_fixed_bytes(n_scenes);
+        GjkSeed* cache_w = reinterpret_cast<GjkSeed*>(base);
+        const WideBufs W = wide_carve(base + settle_cache_bytes(n_scenes, params), n_scenes, nb_cap, lhc);
+        const BeginLds BL = begin_layout(nb_cap, lhc);
+        const FinishLds FL = finish_layout(nb_cap);
+        const SolveLds SL = solve_layout(nb_cap);
+        if (BL.total > 64 * 1024) {
+            slhip::set_error("slhip_settle: scene too large for LDS (%d bytes)", BL.total);
+            return -1;
+        }
+        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_begin), hipFuncAttributeMaxDynamicSharedMemorySize, BL.total));
+        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_finish), hipFuncAttributeMaxDynamicSharedMemorySize, FL.total));
+        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve), hipFuncAttributeMaxDynamicSharedMemorySize, SL.total));
+        const unsigned cstride = pair_cache_stride(params);
+        k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, cache_w, cstride);
+        const dim3 pair_grid(n_scenes, SLHIP_MAX_HULL_PAIRS / 64);
+        for (uint32_t f = 0; f < params->frames; ++f)
+            for (uint32_t sub = 0; sub < params->substeps; ++sub) {
+                k_w_begin<<<n_scenes, 64, BL.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, W, BL, drive_w);
+                k_w_gjk_main<<<pair_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride);
+                k_w_gjk_tilt<<<pair_grid, 64, 0, stream>>>(d_hull_verts, *params, W);
+                k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL);
+                k_w_solve<<<n_scenes, 64, SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
+                                                              sub + 1 == params->substeps ? 1 : 0);
+            }
+        SLHIP_LAUNCH_CHECK();
+        return 0;
+    }
     // LDS layout from the batch maxima.  The kernel is bound by the latency of its dependent
     // instruction chains, so residency comes first: 8 single-wave workgroups per CU (two per
     // SIMD, the VGPR limit) when the fixed part of the layout fits 160 KiB / 8, fewer otherwise.
@@ -1959,8 +2027,21 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
     ProfScratch* prof = reinterpret_cast<ProfScratch*>(d_scratch);
     DriveAcc* drive = reinterpret_cast<DriveAcc*>(prof + n_scenes);
     GjkSeed* cache = reinterpret_cast<GjkSeed*>(reinterpret_cast<char*>(d_scratch) + settle_fixed_bytes(n_scenes));
-    k_settle<<<n_scenes, 64, L.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, L, prof, drive, cache,
-                                                pair_cache_stride(params));
+    // Segments: the 100 frames of a settle are launched as `segments` kernels of frames / segments frames each (bit-identical
+    // to one launch: the scene state lives in global memory between steps anyway).  A workgroup then holds its CU slot for a
+    // fraction of the ~150 ms a whole settle takes, so the launches of other streams -- the render of the previous batch above
+    // all -- get their turn sooner, and a launch's tail (its slowest scene) is shorter.
+    uint32_t segments = 1;   // measured (profiles/r02): 2 / 4 / 8 segments raise the settle-only rate by 4-7 % but cost the pipelined benchmark 2-9 %
+    if (const char* e = getenv("SLHIP_SETTLE_SEGMENTS")) segments = (uint32_t)atoi(e);
+    if (segments < 1 || params->frames < 2 * segments) segments = 1;
+    slhip_settle_params seg = *params;
+    uint32_t done = 0;
+    for (uint32_t k = 0; k < segments; ++k) {
+        seg.frames = (params->frames - done) / (segments - k);
+        k_settle<<<n_scenes, 64, L.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, seg, L, prof, drive, cache,
+                                                    pair_cache_stride(params), k > 0 ? 1 : 0);
+        done += seg.frames;
+    }
     SLHIP_LAUNCH_CHECK();
     return 0;
 }

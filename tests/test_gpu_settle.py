@@ -280,3 +280,18 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
         for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "wake_counter"):
             a, b = np.ascontiguousarray(gpu[name]), np.ascontiguousarray(ref[name])
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
+
+
+def test_lockstep_pipeline_is_bit_identical(sl, oracle, monkeypatch):
+    """The second implementation of the step (SLHIP_SETTLE_IMPL=lockstep: five launches per step over the whole batch,
+    csrc/slhip_settle_wide.inc) gives the oracle's bits as well: a C2-like batch of mixed scenes, full tabletop settle."""
+    monkeypatch.setenv("SLHIP_SETTLE_IMPL", "lockstep")
+    cube = scaled(sl, S.CUBE, 0.15)
+    bunny = scaled(sl, S.BUNNY, 0.2)
+    scs = [heap(sl, 300 + i, 4 + 3 * i, cube, bunny) for i in range(6)]
+    gpu, ref = run_both(oracle, scs, frames=60)
+    assert_bodies_equal(gpu, ref)
+    monkeypatch.setenv("SLHIP_SETTLE_SEGMENTS", "4")
+    monkeypatch.setenv("SLHIP_SETTLE_IMPL", "persistent")
+    gpu4, _ = run_both(oracle, scs, frames=60)       # the persistent kernel launched in 4 segments of 15 frames
+    assert_bodies_equal(gpu4, ref)
