@@ -35,8 +35,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096,
-                    help="scenes per GPU per step (one settle launch: two rounds of the 2048 resident scenes = 256 CUs x 8; the second round back-fills the tail of the first)")
+    ap.add_argument("--batch", type=int, default=16384,
+                    help="scenes per GPU per step = one settle launch.  Scenes settle in very different times (60 .. 410 ms against a "
+                         "145 ms mean) and 2048 are resident at once, so a launch ends with a tail of idle CUs; the more rounds of "
+                         "workgroups a launch has, the smaller the share of that tail: 4096 -> 4 490, 8192 -> 5 110, 16384 -> 5 550, "
+                         "24576 -> 5 660 scenes/s (profiles/r02)")
     ap.add_argument("--render-chunk", type=int, default=None,
                     help="scenes per render launch sequence (fewer, larger sequences: every kernel boundary is a chance for "
                          "queued settle workgroups to take the freed SIMDs); default 1024")

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SLHIP_ABI_VERSION 1
+#define SLHIP_ABI_VERSION 2   /* 2: slhip_render_scratch.d_shadow_tiles, slhip_render_scratch_bytes fills 7 sizes */
 #define SLHIP_NUM_LIGHTS 3 /* reference include/stillleben/common.h:17 */
 
 /* ---------------------------------------------------------------------------------------------
@@ -185,6 +185,12 @@ typedef struct {
 
 #define SLHIP_RENDER_SSAO     0x100u /* RenderPass::ssaoEnabled (render_pass.h:150)          */
 #define SLHIP_RENDER_SHADOWS  0x200u /* shadow pass + PCF (render_pass.cpp:408-460)          */
+#define SLHIP_RENDER_SHADOW_RESET 0x400u /* d_shadow / d_shadow_tiles hold garbage (first use of the buffers, or a
+                                            previous call failed half way): clear all of it first.  Without the flag
+                                            the call RELIES on the invariant it maintains: on entry and on exit every
+                                            shadow texel is 1.0 and every tile bit 0 -- a render marks the 64x64-texel
+                                            tiles its casters may touch and resets exactly those after shading, instead
+                                            of clearing 16.8 MB per scene and light on every call                     */
 
 /* Result buffers, batch-major [B][H][W][C] -- the 8 colour attachments of
  * RenderPass::Result (reference include/stillleben/render_pass.h:48-78, formats
@@ -210,6 +216,8 @@ typedef struct {
     float*    d_lum;          /* f32 [B,4] HDR sums for auto exposure                        */
     float*    d_clip;         /* f32 [1 + NUM_LIGHTS][n_clip_verts][4]: clip positions written by the
                                  MFMA vertex-transform kernel (plane 0: camera, 1..3: lights)  */
+    uint32_t* d_shadow_tiles; /* u32 [B][NUM_LIGHTS][ceil(ceil(S/64)^2 / 32)]: touched-tile bits (see
+                                 SLHIP_RENDER_SHADOW_RESET)                                     */
     uint32_t  queue_capacity; /* number of (prim,tile) pairs that fit                        */
     uint32_t  shadow_res;     /* S (reference: 2048, render_pass.cpp:271)                    */
     uint32_t  n_clip_verts;   /* sum of n_verts over the draws of the batch                  */
@@ -237,7 +245,7 @@ int slhip_render_timings(float* ms_out);
 /* Bytes of each scratch buffer for a batch (host helper, no GPU needed).                    */
 int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uint32_t height,
                                uint32_t shadow_res, uint32_t queue_capacity,
-                               uint64_t bytes_out[6]);
+                               uint64_t bytes_out[7]);   /* vis, hdr, ao, shadow, queue, lum, shadow_tiles */
 
 /* ---------------------------------------------------------------------------------------------
  * Settle half (replaces PhysX as driven by Scene::simulateTableTopScene, scene.cpp:612-759)

@@ -37,6 +37,8 @@ OUT_ALL = 0xFF
 OUT_GT6 = 0x1F
 RENDER_SSAO = 0x100
 RENDER_SHADOWS = 0x200
+RENDER_SHADOW_RESET = 0x400
+ABI_VERSION = 2
 COMM_ID_BYTES = 128
 
 
@@ -159,6 +161,7 @@ class RenderScratch(C.Structure):
         ("d_queue", C.c_void_p),
         ("d_lum", C.c_void_p),
         ("d_clip", C.c_void_p),
+        ("d_shadow_tiles", C.c_void_p),
         ("queue_capacity", C.c_uint32),
         ("shadow_res", C.c_uint32),
         ("n_clip_verts", C.c_uint32),
@@ -233,7 +236,7 @@ def lib():
         C.c_void_p, C.POINTER(RenderOut), C.POINTER(RenderScratch), C.c_void_p,
     ]
     L.slhip_render_scratch_bytes.argtypes = [
-        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64 * 6)
+        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64 * 7)
     ]
     L.slhip_timing_enable.argtypes = [C.c_int]
     L.slhip_render_timings.argtypes = [C.POINTER(C.c_float * 8)]

@@ -44,7 +44,7 @@ class RenderBuffers:
 class Engine:
     def __init__(self, device_index):
         L = _abi.lib()
-        if L.slhip_abi_version() != 1:
+        if L.slhip_abi_version() != _abi.ABI_VERSION:
             raise _abi.SlhipError("libslhip.so ABI version mismatch")
         if not torch.cuda.is_available():
             raise _abi.SlhipError(
@@ -89,7 +89,7 @@ class Engine:
         key = (B, H, W, want_rgb, ssao, shadows, stream)   # per stream: launches on different streams may overlap
         s = self._scratch.get(key)
         if s is None:
-            sizes = (C.c_uint64 * 6)()
+            sizes = (C.c_uint64 * 7)()
             qcap = max(1 << 20, B * QUEUE_ITEMS_PER_SCENE)
             self.L.slhip_render_scratch_bytes(B, W, H, SHADOW_RES if shadows else 0, qcap, C.byref(sizes))
 
@@ -99,7 +99,8 @@ class Engine:
             s = {
                 "vis": buf(sizes[0]), "hdr": buf(sizes[1], want_rgb), "ao": buf(sizes[2], ssao),
                 "shadow": buf(sizes[3], shadows), "queue": buf(sizes[4]), "lum": buf(sizes[5], want_rgb),
-                "qcap": qcap,
+                "tiles": buf(sizes[6], shadows), "qcap": qcap,
+                "shadow_ready": False,    # the shadow maps / tile bits are garbage until the first call has reset them
             }
             if len(self._scratch) > 6:
                 self._scratch.clear()
@@ -107,6 +108,7 @@ class Engine:
         a = _abi.RenderScratch()
         a.d_vis, a.d_hdr, a.d_ao, a.d_shadow, a.d_queue, a.d_lum = (
             _ptr(s["vis"]), _ptr(s["hdr"]), _ptr(s["ao"]), _ptr(s["shadow"]), _ptr(s["queue"]), _ptr(s["lum"]))
+        a.d_shadow_tiles = _ptr(s["tiles"])
         a.queue_capacity = s["qcap"]
         a.shadow_res = SHADOW_RES
         return a, s
@@ -159,6 +161,9 @@ class Engine:
         scratch.d_clip = _ptr(clips[stream])
         scratch.n_clip_verts = n_clip
         flags = mask | (_abi.RENDER_SSAO if ssao else 0) | (_abi.RENDER_SHADOWS if shadows else 0)
+        if shadows and not keep["shadow_ready"]:
+            flags |= _abi.RENDER_SHADOW_RESET
+        keep["shadow_ready"] = False      # stays False if the call below raises: the next one resets again
 
         def addr(t):
             return C.c_void_p(t) if isinstance(t, int) else _ptr(t)
@@ -167,5 +172,6 @@ class Engine:
             st = self.L.slhip_render(C.byref(pool), addr(d_s), addr(d_d), addr(d_c), B, n_draws, n_chunks, W, H, flags,
                                      _ptr(depth_peel), C.byref(out), C.byref(scratch), C.c_void_p(stream))
         _abi.check(st, "slhip_render")
+        keep["shadow_ready"] = bool(shadows)
         buffers._keepalive = (keep,)
         return buffers

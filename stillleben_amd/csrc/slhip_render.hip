@@ -852,36 +852,96 @@ __device__ __forceinline__ void shadow_clip(const slhip_mesh_pool& pool, const f
     }
 }
 
+// Shadow maps are kept CLEAN BETWEEN CALLS (all texels 1.0): a render marks the 64x64-texel tiles its casters touch
+// (one bit per tile, per scene and light: every triangle marks the tiles of its pixel box -- which also covers the 8x8 tiles
+// k_shadow_large resolves for the large ones), and after the shading pass k_shadow_restore resets exactly those tiles.  The
+// per-call clear of the whole 2048^2 map (16.8 MB per scene and light, more than the whole G-buffer of the scene) is gone;
+// what is written back is proportional to what was drawn.
+constexpr int kShadowTile = 64;
+constexpr int kShadowMaxWords = 32;   // LDS bitmap of k_shadow_raster: 1024 tiles = a 2048^2 map
+__host__ __device__ inline int shadow_tiles_x(int S) { return (S + kShadowTile - 1) / kShadowTile; }
+__host__ __device__ inline int shadow_tile_words(int S) { return (shadow_tiles_x(S) * shadow_tiles_x(S) + 31) / 32; }
+
 __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                        const slhip_draw* __restrict__ draws,
                                                        const slhip_chunk* __restrict__ chunks, int S,
                                                        unsigned* __restrict__ shadow, unsigned* queue,
                                                        unsigned capacity, const float4* __restrict__ clipbuf,
-                                                       unsigned n_clip_verts)
+                                                       unsigned n_clip_verts, unsigned* __restrict__ tile_bits)
 {
+    __shared__ unsigned bm[SLHIP_NUM_LIGHTS][kShadowMaxWords];   // the chunk's touched tiles, ORed into the scene's bits at the end
     const slhip_chunk ch = chunks[blockIdx.x];
-    if (threadIdx.x >= ch.count) return;
+    if (ch.count == 0) return;
     const slhip_scene* sc = scenes + ch.scene;
     const slhip_draw* dr = draws + ch.draw;
-    if (!(dr->flags & SLHIP_DRAW_CASTS_SHADOW)) return;
-    const unsigned tri = ch.first_tri + threadIdx.x;
+    if (!(dr->flags & SLHIP_DRAW_CASTS_SHADOW)) return;      // block-uniform
+    const int tx_n = shadow_tiles_x(S), words = shadow_tile_words(S);
+    for (int k = (int)threadIdx.x; k < SLHIP_NUM_LIGHTS * kShadowMaxWords; k += 256) bm[k / kShadowMaxWords][k % kShadowMaxWords] = 0u;
+    __syncthreads();
+    const bool have_tri = threadIdx.x < ch.count;
+    const unsigned tri = ch.first_tri + (have_tri ? threadIdx.x : 0u);
     const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
     const unsigned i0 = ip[0], i1 = ip[1], i2 = ip[2];
     // one block per chunk, the (few) active lights in a loop: the index fetch is shared and no
     // workgroups are launched for lights that are off
     for (int light = 0; light < SLHIP_NUM_LIGHTS; ++light) {
         if (!light_active(sc, light)) continue;
+        if (!have_tri) continue;
         const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
         const float4 a4 = plane[i0], b4 = plane[i1], c4 = plane[i2];
         const float c0[4] = {a4.x, a4.y, a4.z, a4.w}, c1[4] = {b4.x, b4.y, b4.z, b4.w}, c2[4] = {c4.x, c4.y, c4.z, c4.w};
         Setup t;
         if (!setup_tri(c0, c1, c2, S, S, t)) continue;
         if (t.flipped) continue;  // front face culled
+        // tiles of the triangle's pixel box (a 16k-triangle object: almost always one tile, at most a handful)
+        if (words <= kShadowMaxWords) {
+            const int tx0 = t.xmin / kShadowTile, tx1 = t.xmax / kShadowTile, ty0 = t.ymin / kShadowTile, ty1 = t.ymax / kShadowTile;
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) {
+                    const int tile = ty * tx_n + tx;
+                    atomicOr(&bm[light][tile >> 5], 1u << (tile & 31));
+                }
+        }
         ShadowTarget tgt;
         tgt.sm = shadow + ((size_t)ch.scene * SLHIP_NUM_LIGHTS + light) * S * S;
         tgt.W = S;
         raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene | ((unsigned)light << 24));
     }
+    __syncthreads();
+    for (int k = (int)threadIdx.x; k < SLHIP_NUM_LIGHTS * words; k += 256) {
+        const int light = k / words, w = k % words;
+        if (!light_active(sc, light)) continue;
+        // maps with more tiles than the LDS bitmap holds (shadow_res > 2048) are marked wholesale
+        const unsigned m = words <= kShadowMaxWords ? bm[light][w] : 0xFFFFFFFFu;
+        if (m) atomicOr(tile_bits + ((size_t)ch.scene * SLHIP_NUM_LIGHTS + light) * words + w, m);
+    }
+}
+
+// after the shading pass: every marked tile back to 1.0, its bit cleared (one block per 32-tile word)
+__global__ __launch_bounds__(256) void k_shadow_restore(unsigned* __restrict__ shadow, unsigned* __restrict__ tile_bits, int S,
+                                                        unsigned n_words_total)
+{
+    const unsigned wi = blockIdx.x;
+    if (wi >= n_words_total) return;
+    unsigned m = tile_bits[wi];
+    if (m == 0u) return;
+    const int words = shadow_tile_words(S), tx_n = shadow_tiles_x(S);
+    const unsigned map = wi / (unsigned)words, w = wi % (unsigned)words;
+    unsigned* base = shadow + (size_t)map * S * S;
+    const uint4 one = make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u);
+    while (m) {
+        const int b = __ffs((int)m) - 1;
+        m &= m - 1;
+        const int tile = (int)w * 32 + b;
+        const int x0 = (tile % tx_n) * kShadowTile, y0 = (tile / tx_n) * kShadowTile;
+        // 64 x 64 texels = 16 uint4 per row; S is a multiple of 4 (checked by slhip_render), tiles at the right / bottom edge are cut
+        for (int k = (int)threadIdx.x; k < kShadowTile * (kShadowTile / 4); k += 256) {
+            const int y = y0 + k / (kShadowTile / 4), x = x0 + 4 * (k % (kShadowTile / 4));
+            if (y < S && x < S) *reinterpret_cast<uint4*>(base + (size_t)y * S + x) = one;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tile_bits[wi] = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
@@ -1632,15 +1692,11 @@ __global__ __launch_bounds__(256) void k_tonemap(const slhip_scene* __restrict__
 }
 
 // clears the shadow maps of the ACTIVE lights only (blockIdx.y = scene * NUM_LIGHTS + light)
-__global__ __launch_bounds__(256) void k_clear_shadow(const slhip_scene* __restrict__ scenes, unsigned* __restrict__ shadow,
-                                                      int S)
+__global__ __launch_bounds__(256) void k_clear_shadow(unsigned* __restrict__ shadow, size_t n4)
 {
-    const unsigned scene = blockIdx.x / SLHIP_NUM_LIGHTS, light = blockIdx.x % SLHIP_NUM_LIGHTS;
-    if (!light_active(scenes + scene, (int)light)) return;
-    uint4* p = reinterpret_cast<uint4*>(shadow + (size_t)blockIdx.x * S * S);
-    const size_t n4 = (size_t)S * S / 4;
+    uint4* p = reinterpret_cast<uint4*>(shadow);
     const uint4 v = make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u);
-    for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.y * 256) p[i] = v;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 
 bool g_ssao_tables_uploaded[16] = {};
@@ -1708,7 +1764,7 @@ extern "C" int slhip_render_timings(float* ms_out)
 #include "ssao_tables.inc"
 
 extern "C" int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uint32_t height,
-                                          uint32_t shadow_res, uint32_t queue_capacity, uint64_t bytes_out[6])
+                                          uint32_t shadow_res, uint32_t queue_capacity, uint64_t bytes_out[7])
 {
     const uint64_t P = (uint64_t)width * height, B = n_scenes;
     const uint64_t blocks = (P + 255) / 256;
@@ -1718,6 +1774,7 @@ extern "C" int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uin
     bytes_out[3] = B * SLHIP_NUM_LIGHTS * (uint64_t)shadow_res * shadow_res * 4;  // d_shadow
     bytes_out[4] = 16 + (uint64_t)queue_capacity * 16;                     // d_queue
     bytes_out[5] = B * blocks * 16;                                        // d_lum
+    bytes_out[6] = B * SLHIP_NUM_LIGHTS * (uint64_t)shadow_tile_words((int)shadow_res) * 4;   // d_shadow_tiles
     return 0;
 }
 
@@ -1740,6 +1797,10 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     const bool want_rgb = out->d_rgb != nullptr;
     const bool ssao = (flags & SLHIP_RENDER_SSAO) && want_rgb;
     const bool shadows = (flags & SLHIP_RENDER_SHADOWS) && want_rgb && scratch->d_shadow != nullptr;
+    if (shadows && (!scratch->d_shadow_tiles || (scratch->shadow_res & 3u))) {
+        slhip::set_error("slhip_render: shadows need the d_shadow_tiles scratch and a shadow_res that is a multiple of 4");
+        return -1;
+    }
     if (ssao && (!out->d_cam_coord || !out->d_normals || !scratch->d_ao)) {
         slhip::set_error("slhip_render: SSAO needs the cam_coord and normals outputs and d_ao scratch");
         return -1;
@@ -1783,15 +1844,19 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
                                                                       scratch->n_clip_verts, shadows ? 1 : 0);
         SLHIP_LAUNCH_CHECK();
     }
-    // shadow pass
+    // shadow pass (maps clean on entry, see k_shadow_raster)
+    const unsigned n_tile_words = shadows ? n_scenes * SLHIP_NUM_LIGHTS * (unsigned)shadow_tile_words(S) : 0u;
+    if (shadows && (flags & SLHIP_RENDER_SHADOW_RESET)) {
+        k_clear_shadow<<<4096, 256, 0, stream>>>(reinterpret_cast<unsigned*>(scratch->d_shadow),
+                                                 (size_t)n_scenes * SLHIP_NUM_LIGHTS * S * S / 4);
+        SLHIP_CHECK(hipMemsetAsync(scratch->d_shadow_tiles, 0, (size_t)n_tile_words * 4, stream));
+    }
     if (shadows && n_chunks > 0) {
         mark(0, stream);
-        k_clear_shadow<<<dim3(n_scenes * SLHIP_NUM_LIGHTS, 64), 256, 0, stream>>>(
-            d_scenes, reinterpret_cast<unsigned*>(scratch->d_shadow), S);
         SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
         k_shadow_raster<<<n_chunks, 256, 0, stream>>>(
             *pool, d_scenes, d_draws, d_chunks, S, reinterpret_cast<unsigned*>(scratch->d_shadow),
-            scratch->d_queue, scratch->queue_capacity, clipbuf, scratch->n_clip_verts);
+            scratch->d_queue, scratch->queue_capacity, clipbuf, scratch->n_clip_verts, scratch->d_shadow_tiles);
         mark(1, stream);
         k_shadow_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, S,
                                                  reinterpret_cast<unsigned*>(scratch->d_shadow), scratch->d_queue,
@@ -1829,6 +1894,11 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
                                             shadows ? scratch->d_shadow : nullptr, scratch->d_lum, clipbuf,
                                             ssao ? scratch->d_ao + (size_t)n_scenes * P : nullptr);
     SLHIP_LAUNCH_CHECK();
+    if (shadows && n_chunks > 0) {   // the maps were read for the last time: marked tiles back to 1.0
+        k_shadow_restore<<<n_tile_words, 256, 0, stream>>>(reinterpret_cast<unsigned*>(scratch->d_shadow), scratch->d_shadow_tiles,
+                                                          S, n_tile_words);
+        SLHIP_LAUNCH_CHECK();
+    }
 
     if (want_rgb) {
         const float* tm_in = hdr0;
