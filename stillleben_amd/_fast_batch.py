@@ -59,6 +59,42 @@ def prepare(scenes, pool):
     return t
 
 
+def replicate(t1, B):
+    """A B-scene template whose scenes are all copies of the ONE scene of template `t1` (same objects, materials, camera
+    intrinsics; poses, camera pose and lights are filled in by `update`): the records are tiled with numpy instead of being
+    rebuilt scene by scene -- used for batches of pose hypotheses of one scene (sl.diff)."""
+    if t1.n_scenes != 1:
+        raise ValueError("replicate() needs a single-scene template")
+    t = BatchTemplate()
+    nd, nc, no = len(t1.drec), len(t1.crec), t1.n_obj
+    t.n_scenes, t.n_obj, t.max_objs = B, no * B, t1.max_objs
+    t.srec = np.tile(t1.srec, B)
+    t.srec["draw_begin"] = np.arange(B, dtype=np.uint32) * nd
+    t.srec["draw_end"] = t.srec["draw_begin"] + nd
+    t.drec = np.tile(t1.drec, B)
+    t.drec["scene"] = np.repeat(np.arange(B, dtype=np.uint32), nd)
+    per_scene_clip = int(t1.drec["n_verts"].sum())
+    t.drec["clip_base"] = (np.tile(t1.drec["clip_base"].astype(np.uint64), B) + np.repeat(np.arange(B, dtype=np.uint64) * per_scene_clip, nd)).astype(np.uint32)
+    t.crec = np.tile(t1.crec, B)
+    t.crec["scene"] = np.repeat(np.arange(B, dtype=np.uint32), nc)
+    t.crec["draw"] = np.tile(t1.crec["draw"], B) + np.repeat(np.arange(B, dtype=np.uint32) * nd, nc)
+    t.draw_scene = np.repeat(np.arange(B, dtype=np.int64), nd)
+    obj = np.tile(t1.draw_obj, B)
+    shift = np.repeat(np.arange(B, dtype=np.int64) * no, nd)
+    t.draw_obj = np.where(obj >= 0, obj + shift, -1)
+    t.obj_scene = np.repeat(np.arange(B, dtype=np.int64), no)
+    t.obj_base = np.arange(B + 1, dtype=np.int64) * no
+    t.m2o = np.tile(t1.m2o, (B, 1, 1))
+    t.bbox_corners = np.tile(t1.bbox_corners, (B, 1, 1))
+    t.bbox_center = np.tile(t1.bbox_center, (B, 1))
+    t.bbox_radius = np.tile(t1.bbox_radius, B)
+    t.proj = np.tile(t1.proj, (B, 1, 1))
+    t.proj_inv = np.tile(t1.proj_inv, (B, 1, 1))
+    t.plane_size = np.tile(t1.plane_size, (B, 1))
+    t.light_colors = np.tile(t1.light_colors, (B, 1, 1))
+    return t
+
+
 def _pad_by_scene(t, arr, fill):
     """[O,...] -> [B,maxN,...] with `fill` in the unused slots."""
     out = np.full((t.n_scenes, t.max_objs) + arr.shape[1:], fill, dtype=arr.dtype)

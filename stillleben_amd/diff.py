@@ -18,6 +18,7 @@ from .profiling import Timer
 __all__ = [
     'compute_image_space_gradients', 'backpropagate_gradient_to_poses', 'apply_pose_delta',
     'generate_sobel_valid_mask', 'dilate_object_mask', 'bp_to_vertices_and_colors', 'soft_forward',
+    'backpropagate_gradient_to_poses_batch',
 ]
 
 DIFF_AVAILABLE = True
@@ -120,6 +121,56 @@ def backpropagate_gradient_to_poses(scene, render_result, grad_objective_wrt_rnd
                                             _p(ids), n, H, W, _p(valid), _p(acc), _p(res), _stream(eng))
     _abi.check(st, "slhip_diff_pose_backward")
     return res.cpu()
+
+
+def backpropagate_gradient_to_poses_batch(scene, pose_hypotheses, grad_objective_wrt_rnd_img, ssao=True, return_results=False):
+    r"""Additive batch form of render-and-compare (BASELINE config C5: 64 objects x 32 pose hypotheses): renders the scene
+    under every pose hypothesis -- `pose_hypotheses` float[K, N, 4, 4], object poses in `scene.objects` order -- in ONE
+    slhip_render launch sequence (K scenes in a batch) and backpropagates `grad_objective_wrt_rnd_img` (float[3,H,W], or
+    float[K,3,H,W] for one gradient image per hypothesis) through each of them.  Returns float[K, N, 6]: row k equals
+    `backpropagate_gradient_to_poses` after `set_pose(pose_hypotheses[k, i])` on every object and `RenderPass().render`.
+    The reference has no batch form: it loops hypothesis by hypothesis through the GL renderer (diff.py:355-523)."""
+    from . import _fast_batch as FB
+
+    eng = engine()
+    objs = scene.objects
+    n = len(objs)
+    hyp = pose_hypotheses.detach().cpu().numpy() if hasattr(pose_hypotheses, "detach") else np.asarray(pose_hypotheses)
+    hyp = np.ascontiguousarray(hyp, dtype=np.float32)
+    if hyp.ndim != 4 or hyp.shape[1:] != (n, 4, 4):
+        raise ValueError("pose_hypotheses must be K x %d x 4 x 4" % n)
+    K = hyp.shape[0]
+    W, H = scene.viewport
+    g = grad_objective_wrt_rnd_img.to(eng.device, torch.float32).contiguous()
+    per_hyp_grad = g.dim() == 4
+    if tuple(g.shape[-3:]) != (3, H, W) or (per_hyp_grad and g.shape[0] != K):
+        raise ValueError("grad_objective_wrt_rnd_img must be 3xHxW or Kx3xHxW")
+    if K == 0 or n == 0:
+        return torch.zeros(K, n, 6)
+    t = FB.replicate(FB.prepare([scene], eng.pool), K)
+    poses = hyp.reshape(K * n, 4, 4)
+    cam = np.tile(scene._camera_pose[None], (K, 1, 1)).astype(np.float32)
+    ld = np.tile(scene._light_directions.numpy()[0][None].astype(np.float32), (K, 1))
+    lit = bool(np.any(ld)) and bool(scene._light_colors[0].any())
+    srec, drec = FB.update(t, poses, cam, ld, np.tile(scene._background_plane_pose[None], (K, 1, 1)).astype(np.float32), with_shadows=lit)
+    srec["ambient"][:, :3] = np.asarray(scene._ambient_light, np.float32)
+    srec["manual_exposure"] = scene._manual_exposure
+    mask = _abi.OUT_RGB | _abi.OUT_COORD | _abi.OUT_INSTANCE
+    buf = eng.render_records(srec, drec, t.crec, W, H, mask, ssao=ssao, shadows=lit)
+    d_poses = torch.from_numpy(hyp).to(eng.device)
+    ids = torch.tensor([o.instance_index for o in objs], dtype=torch.int32, device=eng.device)
+    P = np.ascontiguousarray(scene.projection_matrix().numpy(), dtype=np.float32)
+    valid = torch.empty((H, W), dtype=torch.uint8, device=eng.device)
+    acc = torch.empty(6 * n, dtype=torch.float64, device=eng.device)
+    res = torch.empty((K, n, 6), dtype=torch.float32, device=eng.device)
+    with torch.cuda.device(eng.device):
+        for k in range(K):
+            st = eng.L.slhip_diff_pose_backward(_p(buf.rgb[k]), _p(buf.coord[k]), _p(buf.instance[k]), _p(g[k] if per_hyp_grad else g),
+                                                C.c_void_p(P.ctypes.data), _p(d_poses[k]), _p(ids), n, H, W, _p(valid), _p(acc),
+                                                _p(res[k]), _stream(eng))
+            _abi.check(st, "slhip_diff_pose_backward")
+    out = res.cpu()
+    return (out, buf) if return_results else out
 
 
 def bp_to_vertices_and_colors(scene, render_result, grad_objective_wrt_rnd_img, visualize_grad=False):

@@ -242,3 +242,30 @@ def test_d6_on_a_rendered_scene_and_soft_forward(sl):
     obs = torch.rand(3, 120, 160)
     soft, layers, loss_img, loss, svi, sgv, sgc = sl.diff.soft_forward(scene, [res, peel], obs, loss_fn)
     assert soft.shape == (3, 120, 160) and len(layers) == 2 and loss > 0 and len(svi) == len(sgv) == len(sgc) >= len(seen)
+
+
+def test_pose_hypothesis_batch_equals_the_loop(sl):
+    """sl.diff.backpropagate_gradient_to_poses_batch (BASELINE config C5's shape: K pose hypotheses of one scene in one
+    render launch sequence) == set_pose + RenderPass().render + backpropagate_gradient_to_poses hypothesis by hypothesis."""
+    scene = S.clutter_scene(sl, 5, n_objects=5, size=(160, 120))
+    scene.manual_exposure = 1.0
+    rng = np.random.default_rng(2)
+    base = [o.pose() for o in scene.objects]
+    K = 4
+    hyps = torch.stack([torch.stack([sl.diff.apply_pose_delta(b, torch.from_numpy(rng.normal(0, 0.02, 6).astype(np.float32))) for b in base])
+                        for _ in range(K)])
+    g = torch.from_numpy(pattern_grad(120, 160))
+    got, buf = sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps, g, return_results=True)
+    assert tuple(got.shape) == (K, 5, 6)
+    rp = sl.RenderPass()
+    for k in range(K):
+        for o, p in zip(scene.objects, hyps[k]):
+            o.set_pose(p)
+        res = rp.render(scene)
+        assert torch.equal(res.instance_index().squeeze(-1).cpu(), buf.instance[k].squeeze(-1).cpu())
+        assert torch.equal(res.coordDepth().cpu(), buf.coord[k].cpu())
+        ref = sl.diff.backpropagate_gradient_to_poses(scene, res, g)
+        scale = max(1e-9, float(ref.abs().max()))
+        assert float((got[k] - ref).abs().max()) <= 1e-4 * scale
+    with pytest.raises(ValueError):
+        sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps[:, :3], g)

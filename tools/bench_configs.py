@@ -161,10 +161,22 @@ def c5():
         d = hypothesis(h)
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
+    # the batch form: all 32 hypotheses in one render launch sequence + 32 backward launches
+    hyps = torch.stack([torch.stack([sl.diff.apply_pose_delta(base[k], deltas[h, k]) for k in range(64)]) for h in range(32)])
+    db = sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps, grad)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        db = sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps, grad)
+    torch.cuda.synchronize()
+    total_batch = (time.perf_counter() - t0) / 3
+    agree = float((db[31] - d).abs().max() / max(1e-12, float(d.abs().max())))
     res = rp.render(scene)
     ms_b = timed(lambda: sl.diff.backpropagate_gradient_to_poses(scene, res, grad), reps=10)
     alg = 307200 * 35 + 64 * 88
     emit("C5 sl.diff 64 objects x 32 hypotheses", s_total_32_hypotheses=total, ms_per_hypothesis_render_plus_backward=total / 32 * 1e3,
+         s_total_32_hypotheses_batch_api=total_batch, ms_per_hypothesis_batch_api=total_batch / 32 * 1e3,
+         batch_vs_loop_max_rel_diff=agree,
          backward_ms=ms_b, grad_shape=list(d.shape),
          roofline={"bound": "hbm", "kernel": "diff backward (4 launches)", "algorithmic_bytes": alg, "achieved": alg / (ms_b * 1e-3) / 1e9,
                    "peak": PEAK, "unit": "GB/s", "frac": alg / (ms_b * 1e-3) / 1e9 / PEAK,
