@@ -1977,12 +1977,6 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         const BeginLds BL = begin_layout(nb_cap, lhc);
         const FinishLds FL = finish_layout(nb_cap);
         const SolveLds SL = solve_layout(nb_cap);
-        if (BL.total > 64 * 1024) {
-            slhip::set_error("slhip_settle: scene too large for LDS (%d bytes)", BL.total);
-            return -1;
-        }
-        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_begin), hipFuncAttributeMaxDynamicSharedMemorySize, BL.total));
-        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_finish), hipFuncAttributeMaxDynamicSharedMemorySize, FL.total));
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve), hipFuncAttributeMaxDynamicSharedMemorySize, SL.total));
         const unsigned cstride = pair_cache_stride(params);
         k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, cache_w, cstride);
