@@ -1923,15 +1923,15 @@ static uint64_t settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_param
 }
 
 // Two implementations of the same step (same device functions, bit-identical results, both parity-tested):
-//   persistent (default)  k_settle: one wave per scene for the whole settle, scene state in LDS
-//   lockstep              slhip_settle_wide.inc: five launches per step over the whole batch, state in HBM / L2
-// Measured on the C2 workload (profiles/r02): the lockstep narrowphase kernels fill their waves
-// (lane = hull pair), but every launch waits for its slowest scene and the per-scene solver chain is as long as before, so at
-// 4096 scenes it needs 677 ms against 659 ms and loses 10 % in the pipelined benchmark; SLHIP_SETTLE_IMPL=lockstep selects it.
+//   lockstep (default)    slhip_settle_wide.inc: five launches per step over the whole batch, state in HBM / L2
+//   persistent            k_settle: one wave per scene for the whole settle, scene state in LDS (SLHIP_SETTLE_IMPL=persistent)
+// Measured on the C2 workload (profiles/r02): alone, a settle of 16384 scenes takes 1.54 s either way; in the
+// pipelined benchmark the lockstep kernels leave the render stream alone (its launch sequences run at their isolated speed, where
+// the persistent workgroups -- 256 VGPRs, ~150 ms lifetime -- make them wait for SIMDs): 5 800 against 5 590 scenes/s.
 static bool use_persistent_settle()
 {
     const char* e = getenv("SLHIP_SETTLE_IMPL");
-    return !(e && e[0] == 'l');
+    return e && e[0] == 'p';
 }
 
 extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out)

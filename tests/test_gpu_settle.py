@@ -282,16 +282,19 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
 
 
-def test_lockstep_pipeline_is_bit_identical(sl, oracle, monkeypatch):
-    """The second implementation of the step (SLHIP_SETTLE_IMPL=lockstep: five launches per step over the whole batch,
-    csrc/slhip_settle_wide.inc) gives the oracle's bits as well: a C2-like batch of mixed scenes, full tabletop settle."""
-    monkeypatch.setenv("SLHIP_SETTLE_IMPL", "lockstep")
+def test_both_settle_implementations_are_bit_identical(sl, oracle, monkeypatch):
+    """The two implementations of the step -- the lockstep pipeline (default: five launches per step over the whole batch,
+    csrc/slhip_settle_wide.inc) and the persistent kernel (SLHIP_SETTLE_IMPL=persistent: one wave per scene for the whole
+    settle, optionally launched in segments of frames) -- give the oracle's bits: a batch of mixed scenes, tabletop settle."""
     cube = scaled(sl, S.CUBE, 0.15)
     bunny = scaled(sl, S.BUNNY, 0.2)
     scs = [heap(sl, 300 + i, 4 + 3 * i, cube, bunny) for i in range(6)]
+    monkeypatch.setenv("SLHIP_SETTLE_IMPL", "lockstep")
     gpu, ref = run_both(oracle, scs, frames=60)
     assert_bodies_equal(gpu, ref)
-    monkeypatch.setenv("SLHIP_SETTLE_SEGMENTS", "4")
     monkeypatch.setenv("SLHIP_SETTLE_IMPL", "persistent")
+    gpu1, _ = run_both(oracle, scs, frames=60)
+    assert_bodies_equal(gpu1, ref)
+    monkeypatch.setenv("SLHIP_SETTLE_SEGMENTS", "4")
     gpu4, _ = run_both(oracle, scs, frames=60)       # the persistent kernel launched in 4 segments of 15 frames
     assert_bodies_equal(gpu4, ref)
