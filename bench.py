@@ -289,6 +289,7 @@ def main():
     args.render_chunk = min(args.render_chunk, args.batch)
     pipe = Pipeline(sl, table, args.batch, args.render_chunk, not args.no_ssao, max(1, args.settle_streams), seed=20260929, rank=rank)
     pipe.eng.L.slhip_timing_enable(1)
+    pipe.eng.L.slhip_settle_timing_enable(1)
     table.device()
     pipe.eng.pool_abi()
     torch.cuda.synchronize()
@@ -318,6 +319,7 @@ def main():
 
     run(0, args.warmup)
     pipe.eng.L.slhip_render_timings(C.byref((C.c_float * 8)()))   # drop warm-up phase timings
+    pipe.eng.L.slhip_settle_timings(C.byref((C.c_float * 5)()), C.byref((C.c_uint32 * 5)()))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -339,6 +341,11 @@ def main():
     # phase timings: the render events of all timed steps accumulate in the library
     ms_all = (C.c_float * 8)()
     pipe.eng.L.slhip_render_timings(C.byref(ms_all))
+    st_ms, st_n = (C.c_float * 5)(), (C.c_uint32 * 5)()
+    pipe.eng.L.slhip_settle_timings(C.byref(st_ms), C.byref(st_n))     # lockstep kernels: average launch duration inside the timed region
+    pipe.eng.L.slhip_settle_timing_enable(0)
+    settle_kernels = {n: {"avg_ms_per_launch": float(st_ms[i]), "timed_launches": int(st_n[i])}
+                      for i, n in enumerate(("k_w_begin", "k_w_gjk_main", "k_w_gjk_tilt", "k_w_finish", "k_w_solve"))}
     t_settle = float(np.mean([r["ev0"].elapsed_time(r["ev1"]) for r in recs]))
     t_stage = float(np.mean([r["t_stage0"].elapsed_time(r["ev0"]) for r in recs]))
     t_place = float(np.mean([r["ev1"].elapsed_time(r["placed"]) for r in recs]))
@@ -378,7 +385,7 @@ def main():
     t_settle_alone = e0.elapsed_time(e1)
     if rank == 0:
         out = report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso,
-                     phases, iso)
+                     phases, iso, settle_kernels)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(meshes, args.cpu_scenes, not args.no_ssao)
         print(json.dumps(out))
@@ -401,7 +408,8 @@ def load_counters():
     return {}
 
 
-def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso, phases, iso):
+def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso, phases, iso,
+           settle_kernels):
     W, H = RESOLUTION
     P = W * H
     total_scenes = args.batch * world * args.steps
@@ -449,28 +457,50 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
         "per_kernel": per_kernel,
     }
     roof_render["frac"] = roof_render["achieved"] / roof_render["peak"]
-    # settle: per scene body records in + out (288 B each), hull records (64 B) and hull vertices (16 B) once
+    # ---- the time-dominant kernel of the whole path: the solver of the settle ----
+    lockstep = settle_kernels["k_w_solve"]["timed_launches"] > 0          # SLHIP_SETTLE_IMPL=persistent runs k_settle instead
     hulls_per_scene = float(np.mean(table.n_hulls)) * N_OBJECTS
     hverts_per_scene = float(np.mean(table.n_hull_verts)) * N_OBJECTS
-    settle_bytes = args.batch * (N_OBJECTS * 288 * 2 + hulls_per_scene * 64 + hverts_per_scene * 16)
-    sq = ck.get("k_settle", {})
-    valu_per_scene = sq.get("valu_insts_per_scene")
+    if lockstep:
+        kname = "k_w_solve"
+        sq = ck.get(kname, {})
+        contacts = sq.get("contacts_per_scene_step", 63.0)
+        # per launch (= one step of every scene): the scene's working bodies (152 B) and prepared contacts (72 B) in, group /
+        # colour lists in, the body records (288 B) out -- DESIGN.md section 4
+        per_scene = N_OBJECTS * 152 + contacts * 72 + 1500 + N_OBJECTS * 288
+        ms_launch = settle_kernels[kname]["avg_ms_per_launch"]
+        launches_per_settle = 400
+        measured = ("HIP events on the settle streams around every k_w_solve launch of every 8th step of the timed region "
+                    "(slhip_settle_timings); %d launches timed" % settle_kernels[kname]["timed_launches"])
+    else:
+        kname = "k_settle"
+        sq = ck.get(kname, {})
+        per_scene = N_OBJECTS * 288 * 2 + hulls_per_scene * 64 + hverts_per_scene * 16
+        ms_launch = t_settle
+        launches_per_settle = 1
+        measured = "HIP events on the launch's stream around every slhip_settle of the timed region"
+    alg = per_scene * args.batch
+    valu_per_launch = sq.get("valu_insts_per_scene_launch")
     roofline = {
-        "bound": "hbm", "kernel": "k_settle", "achieved": settle_bytes / (t_settle * 1e-3) / 1e9, "peak": 8000.0,
+        "bound": "hbm", "kernel": kname, "achieved": alg / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else None, "peak": 8000.0,
         "unit": "GB/s", "traffic": sq["hbm_bytes_per_scene"] * args.batch if "hbm_bytes_per_scene" in sq else None,
-        "algorithmic_bytes_per_launch": settle_bytes, "ms_per_launch": t_settle, "ms_per_launch_alone": t_settle_alone,
-        "measured": "HIP events on the launch's stream around every slhip_settle of the timed region (%d launches in flight "
-                    "share the GPU with the render stream); ms_per_launch_alone: one launch on the idle GPU" % len(pipe.s_settle),
-        "note": "the time-dominant kernel is NOT HBM-bound: 400 dependent steps per scene run out of LDS, the limiter is VALU "
-                "issue x lane occupancy (valu_frac, active_lanes); the HBM fraction is reported because the schema asks for one",
-        "valu_insts_per_scene": valu_per_scene,
-        "valu_frac": (valu_per_scene * args.batch / (t_settle_alone * 1e-3) / (1024 * 2.4e9 / 2)) if valu_per_scene else None,
-        "valu_peak": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md, per-instruction cycle table)",
+        "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms_launch, "launches_per_settle": launches_per_settle,
+        "measured": measured,
+        "note": "the time-dominant kernel is NOT HBM-bound: a step's Gauss-Seidel sweeps are chains of dependent contact solves "
+                "(4 + 4 sweeps x the longest contact chain of the scene), the limiter is the latency of that chain x the scenes "
+                "resident per CU; the HBM fraction is reported because the schema asks for one -- see valu_frac / active_lanes",
+        "valu_insts_per_scene_launch": valu_per_launch,
+        "valu_frac": (valu_per_launch * args.batch / (ms_launch * 1e-3) / (1024 * 2.4e9 / 4)) if valu_per_launch and ms_launch > 0 else None,
+        "valu_peak": "1024 SIMDs x 2.4 GHz / 4 cycles: SQ_ACTIVE_INST_VALU (quad-cycles) per SQ_INSTS_VALU is 1.0 for these kernels, "
+                     "i.e. a wave64 VALU instruction holds its SIMD for four cycles",
         "active_lanes": sq.get("active_lanes"),
-        "steps_scenes_per_s": args.batch * 400 / (t_settle * 1e-3),
         "counters_source": cnt.get("source"),
+        "settle_kernels_ms_per_launch": {k: v["avg_ms_per_launch"] for k, v in settle_kernels.items()} if lockstep else None,
+        "settle_ms_per_batch": t_settle, "settle_ms_per_batch_alone": t_settle_alone,
+        "steps_scenes_per_s": args.batch * 400 / (t_settle * 1e-3),
     }
-    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    if roofline["achieved"] is not None:
+        roofline["frac"] = roofline["achieved"] / roofline["peak"]
     k_dom = int(np.argmax(phases)) if phases.sum() > 0 else 4
     return {
         "metric": "scenes/sec (settle + 640x480 6-ch GT render), 20-obj YCB-like",

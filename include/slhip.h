@@ -350,6 +350,12 @@ int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
 #define SLHIP_SETTLE_REFUSED_HULLS  2u   /* more hulls than max_hulls_per_scene, or > 1024 in one body */
 int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_status, uint32_t* h_n_refused,
                         void* stream);
+/* Optional live timing of the five kernels of a lockstep step (bench.py's roofline leg): HIP events on the launch's stream
+ * around every kernel of every 8th step.  slhip_settle_timings synchronises the recorded events and returns, since the last
+ * call, the average launch duration [ms] and the number of timed launches of 0 k_w_begin (integrate, table contacts,
+ * broadphase), 1 k_w_gjk_main, 2 k_w_gjk_tilt, 3 k_w_finish (manifolds, groups, prep, colouring), 4 k_w_solve.          */
+int slhip_settle_timing_enable(int on);
+int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5]);
 /* scratch for n_scenes scenes: accumulators + the per-scene pair cache, sized from the hints in
  * `params` (NULL or zero hints: the worst case, SLHIP_PAIR_CACHE_MAX_HULLS^2 entries per scene)   */
 int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out);

@@ -1922,6 +1922,43 @@ static uint64_t settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_param
            wide_bytes(n_scenes, hint_nb_cap(params), hint_lh_cap(params)) + 256;
 }
 
+// Optional live timing of the lockstep kernels (bench.py's roofline leg): HIP events on the launch's stream around every
+// kernel of every 8th step; slhip_settle_timings() synchronises them and returns the average launch duration per kernel.
+struct SettleTiming {
+    bool on = false;
+    struct Rec { int kernel; hipEvent_t e0, e1; };
+    std::vector<Rec> pending;          // kernel k of a timed step ran between e0 and e1 (neighbours share an event)
+    std::vector<hipEvent_t> events;    // every event once, destroyed after the read-out
+};
+static SettleTiming g_settle_timing;
+
+extern "C" int slhip_settle_timing_enable(int on)
+{
+    g_settle_timing.on = on != 0;
+    return 0;
+}
+
+extern "C" int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5])
+{
+    double acc[5] = {0, 0, 0, 0, 0};
+    uint32_t n[5] = {0, 0, 0, 0, 0};
+    for (auto& r : g_settle_timing.pending) {
+        SLHIP_CHECK(hipEventSynchronize(r.e1));
+        float ms = 0.0f;
+        SLHIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        acc[r.kernel] += ms;
+        ++n[r.kernel];
+    }
+    for (hipEvent_t e : g_settle_timing.events) (void)hipEventDestroy(e);
+    g_settle_timing.events.clear();
+    g_settle_timing.pending.clear();
+    for (int k = 0; k < 5; ++k) {
+        if (avg_ms_out) avg_ms_out[k] = n[k] ? (float)(acc[k] / n[k]) : 0.0f;
+        if (launches_out) launches_out[k] = n[k];
+    }
+    return 0;
+}
+
 // Two implementations of the same step (same device functions, bit-identical results, both parity-tested):
 //   lockstep (default)    slhip_settle_wide.inc: five launches per step over the whole batch, state in HBM / L2
 //   persistent            k_settle: one wave per scene for the whole settle, scene state in LDS (SLHIP_SETTLE_IMPL=persistent)
@@ -1981,14 +2018,29 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         const unsigned cstride = pair_cache_stride(params);
         k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, cache_w, cstride);
         const dim3 pair_grid(n_scenes, SLHIP_MAX_HULL_PAIRS / 64);
+        uint32_t step = 0;
         for (uint32_t f = 0; f < params->frames; ++f)
-            for (uint32_t sub = 0; sub < params->substeps; ++sub) {
+            for (uint32_t sub = 0; sub < params->substeps; ++sub, ++step) {
+                const bool timed = g_settle_timing.on && step % 8u == 0u;
+                hipEvent_t ev[6];
+                if (timed)
+                    for (int k = 0; k < 6; ++k) SLHIP_CHECK(hipEventCreate(&ev[k]));
+                if (timed) (void)hipEventRecord(ev[0], stream);
                 k_w_begin<<<n_scenes, 64, BL.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, W, BL, drive_w);
+                if (timed) (void)hipEventRecord(ev[1], stream);
                 k_w_gjk_main<<<pair_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride);
+                if (timed) (void)hipEventRecord(ev[2], stream);
                 k_w_gjk_tilt<<<pair_grid, 64, 0, stream>>>(d_hull_verts, *params, W);
+                if (timed) (void)hipEventRecord(ev[3], stream);
                 k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL);
+                if (timed) (void)hipEventRecord(ev[4], stream);
                 k_w_solve<<<n_scenes, 64, SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
                                                               sub + 1 == params->substeps ? 1 : 0);
+                if (timed) {
+                    (void)hipEventRecord(ev[5], stream);
+                    for (int k = 0; k < 5; ++k) g_settle_timing.pending.push_back({k, ev[k], ev[k + 1]});
+                    for (int k = 0; k < 6; ++k) g_settle_timing.events.push_back(ev[k]);
+                }
             }
         SLHIP_LAUNCH_CHECK();
         return 0;

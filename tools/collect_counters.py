@@ -57,7 +57,7 @@ def pmc(out, tag, counters, cmd):
 def main():
     out = os.path.abspath(sys.argv[1])
     os.makedirs(out, exist_ok=True)
-    batch, chunk = 4096, 512
+    batch, chunk = 16384, 1024     # bench.py defaults
     # 1. per-kernel durations of the default command + the bench line under the profiler
     d = os.path.join(out, "raw_stats")
     shutil.rmtree(d, ignore_errors=True)
@@ -77,15 +77,15 @@ def main():
     f_fac = N_CAL / (cal_f["cal"]["FETCH_SIZE"] * 1024.0)
     w_fac = N_CAL / (cal_w["cal"]["WRITE_SIZE"] * 1024.0)
     # 3. SQ counters of the settle kernel (8 SQ slots per pass)
-    sq, _ = pmc(out, "sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
-                            "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM"], BENCH + PMC_SHAPE)
+    sq, n_sq = pmc(out, "sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
+                               "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"], BENCH + PMC_SHAPE)
     sq_cal, _ = pmc(out, "sq_cal", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES"], cal_cmd)
     full = sq_cal["cal"]["SQ_THREAD_CYCLES_VALU"] / sq_cal["cal"]["SQ_ACTIVE_INST_VALU"]   # the ratio of a kernel with all 64 lanes on
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         if k == "cal":
             continue
-        n = batch if k in ("k_settle", "k_synth_stage", "k_synth_place") else chunk
+        n = batch if (k in ("k_settle", "k_synth_stage", "k_synth_place") or k.startswith("k_w_")) else chunk
         fb = fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
         wb = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
         kernels[k] = {"scenes_per_launch": n, "dispatches_in_pass": n_f.get(k, 0),
@@ -97,19 +97,21 @@ def main():
             kernels[k]["avg_ms_default_run"] = float(stats[k]["AverageNs"]) / 1e6
             kernels[k]["calls_default_run"] = int(stats[k]["Calls"])
             kernels[k]["pct_gpu_time_default_run"] = float(stats[k]["Percentage"])
-    s = sq.get("k_settle", {})
-    if s:
-        kernels.setdefault("k_settle", {})
-        kernels["k_settle"].update({
-            "sq": s,
-            "valu_insts_per_scene": s["SQ_INSTS_VALU"] / batch,
-            "active_lanes": 64.0 * (s["SQ_THREAD_CYCLES_VALU"] / s["SQ_ACTIVE_INST_VALU"]) / full if s.get("SQ_ACTIVE_INST_VALU") else None,
-            "thread_cycles_per_active_inst": s["SQ_THREAD_CYCLES_VALU"] / s["SQ_ACTIVE_INST_VALU"] if s.get("SQ_ACTIVE_INST_VALU") else None,
-            "thread_cycles_per_active_inst_full_wave": full,
-            "active_lanes_note": "64 x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of k_settle) / (the same ratio of an elementwise kernel with all "
-                                 "64 lanes on, measured in the same session): the counters' units cancel",
-            "valu_duty_of_a_wave": s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"] if s.get("SQ_WAVE_CYCLES") else None,
+    for k, c in sq.items():      # SQ counters of every kernel (averages per launch)
+        if k == "cal" or not c.get("SQ_ACTIVE_INST_VALU"):
+            continue
+        n = batch if (k in ("k_settle", "k_synth_stage", "k_synth_place") or k.startswith("k_w_")) else chunk
+        kernels.setdefault(k, {})
+        kernels[k].update({
+            "sq": c,
+            "valu_insts_per_scene_launch": c["SQ_INSTS_VALU"] / n,
+            "active_lanes": 64.0 * (c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]) / full,
+            "valu_duty_of_a_wave": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+            "wait_any_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c else None,
+            "wait_inst_share": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in c else None,
         })
+    notes = {"active_lanes": "64 x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of the kernel) / (the same ratio of an elementwise kernel with all "
+                             "64 lanes on, measured in the same session: %.1f)" % full}
     res = {
         "commands": {
             "stats": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline",
@@ -120,6 +122,7 @@ def main():
         "units": "FETCH_SIZE / WRITE_SIZE are KiB; bytes = counter x 1024 x the factor measured on the known-byte kernel",
         "calibration": {"fetch_factor": f_fac, "write_factor": w_fac,
                         "expected": "fetch factor 2.0 for 16 B/lane streaming reads (MI355X_MICROARCH.md HBM section), write factor ~1.0"},
+        "notes": notes,
         "kernels": kernels,
     }
     json.dump(res, open(os.path.join(out, "counters.json"), "w"), indent=1)
