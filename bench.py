@@ -451,7 +451,7 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
         "achieved": b_scene * args.render_chunk / (ms_seq * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
         "algorithmic_bytes_per_scene": b_scene, "algorithmic_bytes_per_launch": b_scene * args.render_chunk,
         "ms_per_launch": ms_seq,
-        "traffic": sum(v["hbm_bytes_per_scene"] for k, v in ck.items() if k != "k_settle" and not k.startswith("k_synth")) * args.render_chunk if ck else None,
+        "traffic": sum(v["hbm_bytes_per_scene"] for k, v in ck.items() if k not in ("k_settle", "k_clear_shadow") and not k.startswith(("k_synth", "k_w_"))) * args.render_chunk if ck else None,
         "measured": "HIP events on the render stream around one non-overlapped pass over the last step's chunks",
         "byte_model": "SURVEY.md 8d: V_inst*68 + T_inst*12 + P*40 (GT6) + V_inst*12 + T_inst*12 + 2048^2*4 (one shadow light) + P*72 (SSAO, blur, tone map)",
         "per_kernel": per_kernel,
