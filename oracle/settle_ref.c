@@ -710,13 +710,12 @@ static inline void apply_impulse(wbody* a, wbody* b, const contact* c, v3 J)
     }
 }
 
-static void solve_contact(contact* c, wbody* wbs, const slhip_settle_params* prm, int biased)
+/* normal row of one contact */
+static void solve_normal(contact* c, wbody* wbs, const slhip_settle_params* prm, int biased)
 {
-    if (!c->valid) return;
     wbody* a = &wbs[c->a];
     wbody* b = c->b >= 0 ? &wbs[c->b] : NULL;
     const float inv_dt = 1.0f / prm->dt;
-    /* normal row */
     v3 rel = vel_at(a, c->ra);
     if (b) rel = sub(rel, vel_at(b, c->rb));
     float vn = dot(rel, c->n);
@@ -734,21 +733,55 @@ static void solve_contact(contact* c, wbody* wbs, const slhip_settle_params* prm
     dl = ln - c->ln;
     c->ln = ln;
     apply_impulse(a, b, c, scale(c->n, dl));
-    /* friction rows (static/dynamic Coulomb on the tangent impulse vector) */
-    rel = vel_at(a, c->ra);
+}
+
+/* friction rows of one ANCHOR of a patch: static / dynamic Coulomb on the tangent impulse vector against the anchor's
+   share of the patch's normal impulse */
+static void solve_friction(contact* c, wbody* wbs, float share)
+{
+    wbody* a = &wbs[c->a];
+    wbody* b = c->b >= 0 ? &wbs[c->b] : NULL;
+    v3 rel = vel_at(a, c->ra);
     if (b) rel = sub(rel, vel_at(b, c->rb));
     float l1 = c->lt1 - dot(rel, c->t1) * c->kt1;
     float l2 = c->lt2 - dot(rel, c->t2) * c->kt2;
     float mag2 = fmaf(l2, l2, l1 * l1);
-    float lim_s = c->mu_s * c->ln;
+    float lim_s = c->mu_s * share;
     if (mag2 > lim_s * lim_s) {
         float mag = sqrtf(mag2);
-        float k = (c->mu_d * c->ln) / mag;
+        float k = (c->mu_d * share) / mag;
         l1 *= k; l2 *= k;
     }
     float d1 = l1 - c->lt1, d2 = l2 - c->lt2;
     c->lt1 = l1; c->lt2 = l2;
     apply_impulse(a, b, c, madd(scale(c->t1, d1), c->t2, d2));
+}
+
+/* One friction PATCH = the manifold of one hull pair (or of one body against the table): <= 4 contacts with a common normal
+   in a block of MAX_CONTACTS_PER_HP slots, the valid ones first.  PhysX's configured friction model (PxFrictionType::ePATCH
+   [ext]): every contact has a normal row, friction acts at two ANCHORS per patch -- here the first two
+   contacts of the manifold, i.e. its deepest point and the point farthest from it (reduce4) -- each limited by mu times its share
+   of the patch's accumulated normal impulse (half each with two anchors: the total stays inside the Coulomb cone).  Order within
+   a patch: the normal rows in slot order, then the anchors. */
+static void solve_patch(contact* c, wbody* wbs, const slhip_settle_params* prm, int biased)
+{
+    float nsum = 0.0f;
+    int m = 0;
+    for (int i = 0; i < MAX_CONTACTS_PER_HP; ++i) {
+        if (!c[i].valid) continue;
+        solve_normal(&c[i], wbs, prm, biased);
+        nsum = nsum + c[i].ln;
+        ++m;
+    }
+    if (m == 0) return;
+    const int anchors = m >= 2 ? 2 : 1;
+    const float share = anchors == 2 ? 0.5f * nsum : nsum;
+    int done = 0;
+    for (int i = 0; i < MAX_CONTACTS_PER_HP && done < anchors; ++i) {
+        if (!c[i].valid) continue;
+        solve_friction(&c[i], wbs, share);
+        ++done;
+    }
 }
 
 /* D6 joint of ManipulationSim (manipulation_sim.cpp:46-93): world-anchored, linear X/Y/Z driven by
@@ -843,7 +876,7 @@ static void solve_iteration(scene_ws* ws, const slhip_body* bodies, int nb, cons
     for (int col = 0; col < ws->n_colors; ++col)
         for (int g = 0; g < ws->n_groups; ++g) {
             if (ws->g_color[g] != col) continue;
-            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) solve_contact(&ws->c[i], ws->wb, prm, biased);
+            for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += MAX_CONTACTS_PER_HP) solve_patch(&ws->c[i], ws->wb, prm, biased);
         }
     for (int i = 0; i < nb; ++i) solve_drive(&bodies[i], &ws->wb[i], prm, biased);
 }

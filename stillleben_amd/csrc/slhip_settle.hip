@@ -895,8 +895,10 @@ __device__ void plane_contacts_sg16(const WBody& w, const HullRef* lh, const f3*
     out.count = nk;
 }
 
+// `head`: the first contact of its friction patch (= the manifold of one hull pair / of one body against the table); carried
+// in the sign of `til` (the tangent construction's 1 / |a| is positive)
 __device__ __forceinline__ void fill_contact(Contact* c, int a, int b, const WBody& wa, const WBody* wbb, v3 pa, v3 pb,
-                                             v3 n, float sep, float rest, float e)
+                                             v3 n, float sep, float rest, float e, bool head)
 {
     Contact k;
     k.ra = sub(pa, wa.x);
@@ -907,7 +909,7 @@ __device__ __forceinline__ void fill_contact(Contact* c, int a, int b, const WBo
     k.ln = __int_as_float(a); k.lt1 = __int_as_float(b);   // consumed (and zeroed) by prep_contact
     k.lt2 = 0.0f;
     k.bounce = e;                                          // restitution until prep_contact
-    k.til = 0.0f;
+    k.til = head ? -1.0f : 1.0f;                           // sign = patch head; magnitude set by prep_contact
     *c = k;
 }
 
@@ -968,7 +970,7 @@ __device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_thresho
     float bounce = -3.0e38f;
     if (vn0 < -bounce_threshold && e > 0.0f) bounce = -e * vn0;
     cp->kn = c.kn; cp->kt1 = c.kt1; cp->kt2 = c.kt2; cp->bounce = bounce;
-    cp->ln = 0.0f; cp->lt1 = 0.0f; cp->til = til;
+    cp->ln = 0.0f; cp->lt1 = 0.0f; cp->til = c.til < 0.0f ? -til : til;
 }
 
 // Gauss-Seidel sweep over the contacts of ONE group (all share the same two bodies) by a PAIR of
@@ -1023,8 +1025,14 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, int
     const float mu_s = 0.5f * (wbs[ia].mu_s + (has_b ? wbs[ib].mu_s : plane_mu_s));
     const float mu_d = 0.5f * (wbs[ia].mu_d + (has_b ? wbs[ib].mu_d : plane_mu_d));
     const float sgn = side ? -1.0f : 1.0f;
+    // Friction patches (oracle solve_patch; PhysX's ePATCH model): the contacts of one manifold are contiguous, the first one
+    // carries the head mark.  Normal rows in order; when the patch ends, the friction rows of its (at most two) anchors -- its
+    // first two contacts -- against their share of the patch's accumulated normal impulse.
+    float nsum = 0.0f;
+    int p0 = begin;
     for (int ci = begin; ci < end; ++ci) {
         const Contact c = ac[ci];
+        if (c.til < 0.0f) { nsum = 0.0f; p0 = ci; }
         const v3 r = side ? c.rb : c.ra;
         v3 pv = add(M.v, cross(M.w, r));
         v3 d = sub(pv, pair_swap(pv));              // side 0: a - b, side 1: b - a
@@ -1039,22 +1047,32 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, int
         if (ln < 0.0f) ln = 0.0f;
         dl = ln - c.ln;
         apply_mine(M, r, scale(c.n, sgn * dl));
-        pv = add(M.v, cross(M.w, r));
-        d = sub(pv, pair_swap(pv));
-        v3 t1, t2;
-        tangents_cached(c.n, c.til, &t1, &t2);
-        float l1 = c.lt1 - (sgn * dot(d, t1)) * c.kt1;
-        float l2 = c.lt2 - (sgn * dot(d, t2)) * c.kt2;
-        const float mag2 = fmaf(l2, l2, l1 * l1);
-        const float lim_s = mu_s * ln;
-        if (mag2 > lim_s * lim_s) {
-            const float mag = sqrtf(mag2);
-            const float k = (mu_d * ln) / mag;
-            l1 *= k; l2 *= k;
+        if (side == 0) ac[ci].ln = ln;
+        nsum = nsum + ln;
+        const bool last = ci + 1 == end || ac[ci + 1].til < 0.0f;
+        if (!last) continue;
+        const int anchors = ci - p0 >= 1 ? 2 : 1;
+        const float share = anchors == 2 ? 0.5f * nsum : nsum;
+        for (int ai = 0; ai < anchors; ++ai) {
+            const Contact q = ac[p0 + ai];
+            const v3 rq = side ? q.rb : q.ra;
+            pv = add(M.v, cross(M.w, rq));
+            d = sub(pv, pair_swap(pv));
+            v3 t1, t2;
+            tangents_cached(q.n, fabsf(q.til), &t1, &t2);
+            float l1 = q.lt1 - (sgn * dot(d, t1)) * q.kt1;
+            float l2 = q.lt2 - (sgn * dot(d, t2)) * q.kt2;
+            const float mag2 = fmaf(l2, l2, l1 * l1);
+            const float lim_s = mu_s * share;
+            if (mag2 > lim_s * lim_s) {
+                const float mag = sqrtf(mag2);
+                const float k = (mu_d * share) / mag;
+                l1 *= k; l2 *= k;
+            }
+            const float d1 = l1 - q.lt1, d2 = l2 - q.lt2;
+            apply_mine(M, rq, madd(scale(t1, sgn * d1), t2, sgn * d2));
+            if (side == 0) { ac[p0 + ai].lt1 = l1; ac[p0 + ai].lt2 = l2; }
         }
-        const float d1 = l1 - c.lt1, d2 = l2 - c.lt2;
-        apply_mine(M, r, madd(scale(t1, sgn * d1), t2, sgn * d2));
-        if (side == 0) { ac[ci].ln = ln; ac[ci].lt1 = l1; ac[ci].lt2 = l2; }
     }
     if (M.dynamic) { wbs[mine].v = M.v; wbs[mine].w = M.w; }
 }
@@ -1407,7 +1425,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                 const v3 pa = vsel(sl == 0, rc.pa[0], vsel(sl == 1, rc.pa[1], vsel(sl == 2, rc.pa[2], rc.pa[3])));
                                 const float sp = sl == 0 ? rc.sep[0] : sl == 1 ? rc.sep[1] : sl == 2 ? rc.sep[2] : rc.sep[3];
                                 fill_contact(&ac[off + sl], bi, -1, wb[bi], nullptr, pa, V(pa.x, pa.y, sc.plane_z), rc.n, sp,
-                                             prm.rest_offset, e);
+                                             prm.rest_offset, e, sl == 0);
                             }
                             if (sl == 0) {
                                 Group G;
@@ -1601,7 +1619,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc)
                             if (cc < rc.count && off + cc < kMaxActive) {
-                                fill_contact(&ac[off + cc], bi, bj, wb[bi], &wb[bj], rc.pa[cc], rc.pb[cc], rc.n, rc.sep[cc], rest, e);
+                                fill_contact(&ac[off + cc], bi, bj, wb[bi], &wb[bj], rc.pa[cc], rc.pb[cc], rc.n, rc.sep[cc], rest, e, cc == 0);
                                 ++written;
                             }
                         hp_off[kk] = (unsigned char)written;

@@ -142,7 +142,7 @@ def test_cube_stack_stands_for_four_seconds(sl, oracle, n):
     for k in range(n):
         R = b[k]["pose"].reshape(4, 4)[:3, :3]
         assert math.degrees(math.acos(min(1.0, float(R[2, 2])))) < 0.5            # stays upright ...
-        assert math.degrees(math.acos(min(1.0, (np.trace(R) - 1.0) / 2.0))) < 3.0  # ... a little yaw creep is tolerated
+        assert math.degrees(math.acos(min(1.0, (np.trace(R) - 1.0) / 2.0))) < 6.0  # ... a little yaw creep is tolerated
     assert np.abs(b["lin_vel"]).max() < 0.02 and np.abs(b["ang_vel"]).max() < 0.2
 
 
