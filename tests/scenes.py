@@ -73,3 +73,54 @@ def clutter_scene(sl, seed, n_objects=6, size=(320, 240), with_bunny=False, plan
         scene.choose_random_light_direction()
     scene.ambient_light = torch.tensor([0.1, 0.1, 0.1])
     return scene
+
+
+def delaunay_sheet(sl, n_points, seed, reverse=False, half=1.0):
+    """A watertight flat sheet in the mesh's z = 0 plane: `n_points` random interior points plus a dense border, Delaunay
+    triangulated (every interior edge is shared by exactly two triangles).  `reverse` keeps the geometry and submits the
+    triangles in the opposite order -- on a fronto-parallel sheet every triangle has the SAME depth, so the depth test
+    (LESS, earlier triangle wins) makes any pixel that two triangles both claim change its owner."""
+    from scipy.spatial import Delaunay
+
+    from stillleben_amd import _loaders
+
+    rng = np.random.default_rng(seed)
+    nb = max(8, int(math.sqrt(n_points)))
+    t = np.linspace(-half, half, nb, endpoint=False)
+    border = np.concatenate([np.stack([t, np.full(nb, -half)], 1), np.stack([np.full(nb, half), t], 1),
+                             np.stack([-t, np.full(nb, half)], 1), np.stack([np.full(nb, -half), -t], 1)])
+    pts = np.concatenate([border, rng.uniform(-half, half, (n_points, 2))]).astype(np.float32)
+    tri = Delaunay(pts.astype(np.float64)).simplices.astype(np.uint32)
+    a, b, c = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
+    cw = ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])) < 0
+    tri[cw] = tri[cw][:, ::-1]                      # counter-clockwise seen from +z
+    if reverse:
+        tri = tri[::-1]
+    cm = _loaders.ConsolidatedMesh()
+    cm.positions = np.concatenate([pts, np.zeros((len(pts), 1), np.float32)], 1)
+    cm.normals = np.tile(np.array([[0, 0, 1]], np.float32), (len(pts), 1))
+    cm.uvs = (pts * 0.5 + 0.5).astype(np.float32)
+    cm.colors = np.ones((len(pts), 4), np.float32)
+    cm.indices = np.ascontiguousarray(tri).reshape(-1).astype(np.uint32)
+    cm.textures = []
+    cm._tex_alpha = []
+    cm.materials = [_loaders.Material(base_color=(0.8, 0.8, 0.8, 1))]
+    cm.submeshes = [_loaders.SubMesh(0, len(cm.indices), 0)]
+    return sl.Mesh.from_data(cm, hulls=[], filename="memory://sheet%d" % seed)
+
+
+def sheet_scene(sl, mesh, roll_deg=17.0, tilt_deg=0.0, distance=4.0, size=(320, 240)):
+    """The sheet in front of the camera (camera at the origin looking along its optical axis): rolled about the optical
+    axis so that no edge is pixel-aligned, optionally tilted (then depths differ across the sheet)."""
+    scene = sl.Scene(size)
+    obj = sl.Object(mesh)
+    r, t = math.radians(roll_deg), math.radians(tilt_deg)
+    Rz = np.array([[math.cos(r), -math.sin(r), 0], [math.sin(r), math.cos(r), 0], [0, 0, 1]])
+    Ry = np.array([[math.cos(t), 0, math.sin(t)], [0, 1, 0], [-math.sin(t), 0, math.cos(t)]])
+    cam = scene.camera_pose().numpy().astype(np.float64)          # camera-to-world; the camera looks along its +z
+    P = np.eye(4)
+    P[:3, :3] = Ry @ Rz @ np.diag([1.0, -1.0, -1.0])              # sheet normal towards the camera
+    P[:3, 3] = [0.0, 0.0, distance]
+    obj.set_pose(torch.from_numpy((cam @ P).astype(np.float32)))
+    scene.add_object(obj)
+    return scene

@@ -218,3 +218,23 @@ def test_c2_bench_workload_end_to_end(sl, oracle, eng):
     assert len(np.unique(ref.instance[0])) > 10   # most of the 20 objects are visible
     assert_geometry_equal(bufs, ref, mask=_abi.OUT_GT6 | _abi.OUT_CAM_COORD)
     assert_rgb_close(bufs, ref)
+
+
+def test_watertight_sheet_on_the_gpu(sl, oracle, eng):
+    """along the shared edges of a Delaunay sheet no pixel is owned twice and none never -- the same
+    check as tests/test_oracle_render.py::test_watertight_sheet_no_pixel_owned_twice_or_never, on the kernels' output
+    (visibility raster: 64-bit atomicMin of depth | triangle id), plus bit-equality with the oracle."""
+    from types import SimpleNamespace
+
+    from test_oracle_render import check_watertight
+
+    mask = _abi.OUT_INSTANCE | _abi.OUT_VERTEX_IDX | _abi.OUT_COORD
+
+    def render(scene):
+        bufs, ref = both(eng, oracle, [scene], mask=mask)
+        assert_geometry_equal(bufs, ref, mask)
+        return SimpleNamespace(instance=bufs.instance.cpu().numpy().view(np.uint16), vertex_idx=bufs.vertex_idx.cpu().numpy(),
+                               coord=bufs.coord.cpu().numpy())
+
+    for n_points, seed, tilt in ((600, 1, 0.0), (15000, 2, 0.0), (90000, 3, 0.0), (60000, 5, 50.0)):
+        check_watertight(render, sl, n_points, seed, tilt)

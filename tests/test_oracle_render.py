@@ -187,3 +187,54 @@ def test_unorm8_shortcut_is_exact():
         q = xf * c
         fast = fma(fma(-q, np.float32(255.0), xf), c, q)
         assert fast == xf / np.float32(255.0), x
+
+
+def _owners(r):
+    """Per pixel the (sorted) vertex-id triple of the owning triangle; 0,0,0 = nobody."""
+    return np.sort(r.vertex_idx[0, :, :, :3].astype(np.int64), axis=-1)
+
+
+def _interior(covered):
+    """Pixels whose 3x3 neighbourhood is inside the silhouette's filled outline: the sheet is convex, so every pixel
+    between the first and last covered pixel of its row AND of its column belongs to it."""
+    H, W = covered.shape
+    rows = np.zeros_like(covered)
+    for y in range(H):
+        xs = np.nonzero(covered[y])[0]
+        if len(xs):
+            rows[y, xs[0]:xs[-1] + 1] = True
+    cols = np.zeros_like(covered)
+    for x in range(W):
+        ys = np.nonzero(covered[:, x])[0]
+        if len(ys):
+            cols[ys[0]:ys[-1] + 1, x] = True
+    return rows & cols
+
+
+def check_watertight(render, sl, n_points, seed, tilt):
+    """VERDICT r01 item 8 / SURVEY H1: along shared edges no pixel is owned twice and none never.  `render(scene)` returns
+    the result object of one scene.  Never: the convex sheet's silhouette has no hole.  Twice (fronto-parallel sheet, every
+    triangle at the same depth): submitting the triangles in reverse order leaves every pixel with the same owner."""
+    fwd = render(S.sheet_scene(sl, S.delaunay_sheet(sl, n_points, seed), tilt_deg=tilt))
+    inst = fwd.instance[0, :, :, 0]
+    covered = inst != 0
+    assert covered.sum() > 10000 and not covered[0].any() and not covered[:, 0].any()       # the whole sheet is in view
+    holes = _interior(covered) & ~covered
+    assert not holes.any(), "pixels inside the sheet owned by no triangle: %s" % np.argwhere(holes)[:5]
+    own = _owners(fwd)
+    assert (own[covered][:, 0] > 0).all() and (own[covered][:, 0] != own[covered][:, 1]).all()
+    if tilt == 0.0:
+        depth = fwd.coord[0, :, :, 3][covered]
+        assert depth.min() == depth.max()                                                   # one depth: ties everywhere
+        rev = render(S.sheet_scene(sl, S.delaunay_sheet(sl, n_points, seed, reverse=True), tilt_deg=tilt))
+        assert np.array_equal(rev.instance[0, :, :, 0], inst)
+        moved = np.any(_owners(rev) != own, axis=-1)
+        assert not moved.any(), "%d pixels claimed by two triangles, first %s" % (moved.sum(), np.argwhere(moved)[:5])
+    return int(covered.sum())
+
+
+def test_watertight_sheet_no_pixel_owned_twice_or_never(sl, oracle):
+    # triangles of ~50 px, of ~2 px and (mostly) smaller than a pixel; fronto-parallel and tilted
+    for n_points, seed, tilt in ((600, 1, 0.0), (15000, 2, 0.0), (90000, 3, 0.0), (4000, 4, 35.0), (60000, 5, 50.0)):
+        check_watertight(lambda scene: oracle_render(oracle, [scene], flags=_abi.OUT_INSTANCE | _abi.OUT_VERTEX_IDX | _abi.OUT_COORD),
+                         sl, n_points, seed, tilt)
