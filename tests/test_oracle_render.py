@@ -238,3 +238,41 @@ def test_watertight_sheet_no_pixel_owned_twice_or_never(sl, oracle):
     for n_points, seed, tilt in ((600, 1, 0.0), (15000, 2, 0.0), (90000, 3, 0.0), (4000, 4, 35.0), (60000, 5, 50.0)):
         check_watertight(lambda scene: oracle_render(oracle, [scene], flags=_abi.OUT_INSTANCE | _abi.OUT_VERTEX_IDX | _abi.OUT_COORD),
                          sl, n_points, seed, tilt)
+
+
+def test_gl_comparison_harness_separates_silhouette_from_interior(sl, oracle, tmp_path):
+    """tools/compare_gl.py: a frame against itself is clean; against a one-pixel-shifted silhouette only
+    silhouette pixels differ; a moved object or a depth offset is an interior disagreement."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+
+    spec = importlib.util.spec_from_file_location("compare_gl", os.path.join(os.path.dirname(__file__), "..", "tools", "compare_gl.py"))
+    cg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cg)
+    r = oracle_render(oracle, [S.clutter_scene(sl, 1, n_objects=6)], flags=_abi.OUT_ALL | _abi.RENDER_SSAO)
+    ours = {"instance": r.instance[0], "cls": r.cls[0], "coord": r.coord[0], "normals": r.normals[0], "rgb": r.rgb[0]}
+    rep = cg.compare(ours, ours)
+    assert rep["ok"] and rep["silhouette_mismatch"] == 0 and rep["interior_mismatch"] == 0 and rep["max_depth_diff"] == 0.0
+    # a different fill rule: every silhouette grown by one pixel to the right
+    grown = dict(ours)
+    inst = ours["instance"].copy()
+    inst[:, 1:][(inst[:, 1:] == 0) & (inst[:, :-1] != 0)] = inst[:, :-1][(inst[:, 1:] == 0) & (inst[:, :-1] != 0)]
+    grown["instance"] = inst
+    rep = cg.compare(grown, ours)
+    assert rep["ok"] and rep["silhouette_mismatch"] > 50 and rep["interior_mismatch"] == 0
+    # a real disagreement: the frame shifted by 6 pixels, and a depth offset of 5 mm
+    moved = {k: np.roll(v, 6, axis=1) for k, v in ours.items()}
+    rep = cg.compare(moved, ours)
+    assert not rep["ok"] and rep["interior_mismatch"] > 100
+    off = dict(ours)
+    off["coord"] = ours["coord"] + np.array([0, 0, 0, 0.005], np.float32)
+    rep = cg.compare(off, ours)
+    assert not rep["ok"] and rep["interior_mismatch"] == 0 and abs(rep["max_depth_diff"] - 0.005) < 1e-6
+    # command line
+    np.savez(tmp_path / "a.npz", **ours)
+    np.savez(tmp_path / "b.npz", **moved)
+    tool = os.path.join(os.path.dirname(__file__), "..", "tools", "compare_gl.py")
+    assert subprocess.run([sys.executable, tool, str(tmp_path / "a.npz"), str(tmp_path / "a.npz")], capture_output=True).returncode == 0
+    assert subprocess.run([sys.executable, tool, str(tmp_path / "a.npz"), str(tmp_path / "b.npz")], capture_output=True).returncode == 1
