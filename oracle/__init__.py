@@ -342,3 +342,18 @@ def det_sincosf(x):
     s, c = C.c_float(), C.c_float()
     L.slref_det_sincosf(float(x), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def settle_stats(srec, bodies, hulls, hull_verts, params):
+    """settle() with the solver's work statistics switched on (single-threaded use only): returns a dict of four
+    256-bin histograms over the steps -- 'active' contacts, friction 'anchors', 'colours', 'chain' (rows a lane pair walks
+    in sequence per sweep)."""
+    L = lib()
+    h = np.zeros(1024, np.uint64)
+    L.slref_settle_set_stats.argtypes = [C.c_void_p]
+    L.slref_settle_set_stats(_p(h))
+    try:
+        settle(srec, bodies, hulls, hull_verts, params)
+    finally:
+        L.slref_settle_set_stats(None)
+    return {"active": h[:256], "anchors": h[256:512], "colours": h[512:768], "chain": h[768:]}

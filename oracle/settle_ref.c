@@ -871,6 +871,34 @@ static void color_groups(scene_ws* ws, int n_bodies)
     ws->n_colors = nc;
 }
 
+/* optional statistics of the solver's work for tools/solver_stats.py and DESIGN.md (not thread safe): four histograms of 256
+   bins each over the steps -- active contacts, friction anchors, colours, and the chain length of one sweep (sum over the colours
+   of the largest group's contacts + anchors: what a lane pair per group has to walk in sequence) */
+static uint64_t* g_stats = NULL;
+void slref_settle_set_stats(uint64_t* h) { g_stats = h; }
+
+static void step_stats(const scene_ws* ws)
+{
+    int active = 0, anchors = 0, chain = 0;
+    int longest[64] = {0};
+    for (int g = 0; g < ws->n_groups; ++g) {
+        int rows = 0;
+        for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += MAX_CONTACTS_PER_HP) {
+            int m = 0;
+            for (int k = 0; k < MAX_CONTACTS_PER_HP; ++k) m += ws->c[i + k].valid ? 1 : 0;
+            active += m;
+            anchors += m >= 2 ? 2 : m;
+            rows += m + (m >= 2 ? 2 : m);
+        }
+        if (rows > longest[ws->g_color[g]]) longest[ws->g_color[g]] = rows;
+    }
+    for (int c = 0; c < ws->n_colors; ++c) chain += longest[c];
+    g_stats[active > 255 ? 255 : active]++;
+    g_stats[256 + (anchors > 255 ? 255 : anchors)]++;
+    g_stats[512 + ws->n_colors]++;
+    g_stats[768 + (chain > 255 ? 255 : chain)]++;
+}
+
 static void solve_iteration(scene_ws* ws, const slhip_body* bodies, int nb, const slhip_settle_params* prm, int biased)
 {
     for (int col = 0; col < ws->n_colors; ++col)
@@ -1071,6 +1099,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
 
     /* (g) colouring, (h) position iterations (biased) */
     color_groups(ws, nb);
+    if (g_stats) step_stats(ws);
     for (uint32_t it = 0; it < prm->pos_iters; ++it) solve_iteration(ws, bodies, nb, prm, 1);
 
     /* (i) integrate poses with the biased velocities */
