@@ -210,7 +210,7 @@ typedef struct {
 typedef struct {
     uint64_t* d_vis;          /* u64 [B,H,W] visibility keys (depth24<<32 | prim id)         */
     float*    d_hdr;          /* f32 [B,H,W,4] HDR colour (ssaoRGBInput / postprocessInput)  */
-    float*    d_ao;           /* f32 [B,H,W]                                                 */
+    float*    d_ao;           /* f32 [B,H,W] occlusion + f32 [B,H+2,W+2] camera-z plane (SSAO)  */
     float*    d_shadow;       /* f32 [B,NUM_LIGHTS,S,S] shadow depth (only active lights)    */
     uint32_t* d_queue;        /* large-triangle work queue: [0]=count, then (prim,tile) pairs */
     float*    d_lum;          /* f32 [B,4] HDR sums for auto exposure                        */

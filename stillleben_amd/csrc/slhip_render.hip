@@ -19,6 +19,7 @@
 // All arithmetic that feeds integer outputs or depth follows rules R1..R7 of
 // oracle/render_ref.c; this file is compiled with -ffp-contract=off so that only the explicit
 // fmaf() calls fuse.
+#include <type_traits>
 #include "slhip_common.h"
 #include "slhip_cubemap.h"
 
@@ -1470,7 +1471,25 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
         if (out.d_vertex_idx) reinterpret_cast<uint4*>(out.d_vertex_idx)[gp] = make_uint4(vidx[0], vidx[1], vidx[2], vidx[3]);
         if (out.d_bary) reinterpret_cast<float4*>(out.d_bary)[gp] = make_float4(bary[0], bary[1], bary[2], bary[3]);
         if (out.d_cam_coord) reinterpret_cast<float4*>(out.d_cam_coord)[gp] = make_float4(camc[0], camc[1], camc[2], camc[3]);
-        if (zplane) zplane[gp] = camc[2];
+        if (zplane) {
+            // compact camera-z plane for the SSAO passes, with a one-texel border that repeats the edge (what the clamped
+            // texel fetches of a rect sampler return there): the 64-tap gather then needs no per-tap clamps of x + 1 / y + 1
+            const int Wp = W + 2;
+            float* zp = zplane + (size_t)scene * ((size_t)Wp * (H + 2));
+            const int zi = (int)(pix % (unsigned)W), zj = (int)(pix / (unsigned)W);
+            const int o = (zj + 1) * Wp + zi + 1;
+            const float z = camc[2];
+            const bool l = zi == 0, r = zi == W - 1, t = zj == 0, b = zj == H - 1;
+            zp[o] = z;
+            if (l) zp[o - 1] = z;
+            if (r) zp[o + 1] = z;
+            if (t) zp[o - Wp] = z;
+            if (b) zp[o + Wp] = z;
+            if (l && t) zp[o - Wp - 1] = z;
+            if (r && t) zp[o - Wp + 1] = z;
+            if (l && b) zp[o + Wp - 1] = z;
+            if (r && b) zp[o + Wp + 1] = z;
+        }
         if (prm.inline_tonemap) {
             if (out.d_rgb) reinterpret_cast<uchar4*>(out.d_rgb)[gp] = tone_map_px(color, sc->manual_exposure, 0.0f);
         } else if (hdr) {
@@ -1500,26 +1519,27 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
 __constant__ float c_ssao_noise[48];
 __constant__ float c_ssao_kernel[192];
 
+struct __attribute__((packed, aligned(4))) ZPair { float a, b; };   // two neighbouring texels: one 8-byte load, 4-byte aligned
+
+// `img`: the scene's padded camera-z plane (k_shade), pitch W + 2, texel (x, y) at [y + 1][x + 1]
 __device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, int W, int H, float x, float y)
 {
     const float xs = x - 0.5f, ys = y - 0.5f;
     const float fx = floorf(xs), fy = floorf(ys);
     const float ax = xs - fx, ay = ys - fy;
-    // clamp(int(f), 0, n-1) == int(med3(f, 0, n-1)) for every non-NaN f (integers below 2^24 are exact in
-    // fp32): one v_med3_f32 per coordinate instead of a max/min pair
-    const float wm = (float)(W - 1), hm = (float)(H - 1);
-    const unsigned x0 = (unsigned)(int)__builtin_amdgcn_fmed3f(fx, 0.0f, wm), x1 = (unsigned)(int)__builtin_amdgcn_fmed3f(fx + 1.0f, 0.0f, wm);
-    const unsigned y0 = (unsigned)(int)__builtin_amdgcn_fmed3f(fy, 0.0f, hm), y1 = (unsigned)(int)__builtin_amdgcn_fmed3f(fy + 1.0f, 0.0f, hm);
-    // `img` is the compact camera-z plane written by k_shade (same values as channel 2 of the
-    // camCoordinates target, 4 B/px instead of 16 B/px: the 64-tap gather stays L2 resident).
-    // Byte offsets in 32 bits from the wave-uniform plane base: scalar base + one VGPR offset per load
-    const unsigned w4 = (unsigned)W * 4u;
-    const unsigned r0 = __umul24(y0, w4), r1 = __umul24(y1, w4);   // < 2^24 rows * bytes: fits (W * H * 4 < 2^24 * 4)
-    const unsigned xb0 = x0 * 4u, xb1 = x1 * 4u;
+    // the rect sampler's texels clamp(int(f), 0, n-1) and clamp(int(f) + 1, 0, n-1) are the padded plane's columns
+    // c and c + 1 with c = clamp(int(f), -1, n-1) + 1; clamp(int(f), lo, hi) == int(med3(f, lo, hi)) for every non-NaN f
+    // (integers below 2^24 are exact in fp32): one v_med3_f32 per coordinate.  The plane (4 B/px instead of the 16 B/px
+    // of the camCoordinates target) keeps the 64-tap gather L2 resident.
+    const unsigned x0 = (unsigned)((int)__builtin_amdgcn_fmed3f(fx, -1.0f, (float)(W - 1)) + 1);
+    const unsigned y0 = (unsigned)((int)__builtin_amdgcn_fmed3f(fy, -1.0f, (float)(H - 1)) + 1);
+    const unsigned pitch = (unsigned)(W + 2) * 4u;
+    // byte offsets in 32 bits from the wave-uniform plane base (rows * bytes < 2^24 * 4): scalar base + one VGPR offset per load
+    const unsigned off = __umul24(y0, pitch) + x0 * 4u;
     const char* base = reinterpret_cast<const char*>(img);
-    const float a = *reinterpret_cast<const float*>(base + (r0 + xb0)), b = *reinterpret_cast<const float*>(base + (r0 + xb1));
-    const float c = *reinterpret_cast<const float*>(base + (r1 + xb0)), d = *reinterpret_cast<const float*>(base + (r1 + xb1));
-    const float top = fmaf(ax, b - a, a), bot = fmaf(ax, d - c, c);
+    const ZPair top2 = *reinterpret_cast<const ZPair*>(base + off);
+    const ZPair bot2 = *reinterpret_cast<const ZPair*>(base + (off + pitch));
+    const float top = fmaf(ax, top2.b - top2.a, top2.a), bot = fmaf(ax, bot2.b - bot2.a, bot2.a);
     return fmaf(ay, bot - top, top);
 }
 
@@ -1532,10 +1552,13 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
     unsigned scene, blk;
     if (!scene_block(blocks_per_scene, n_scenes, scene, blk)) return;
-    const unsigned pix = blk * 256 + threadIdx.x;
+    // A wave takes the pixels of ONE column class (x & 3) of the block's 256-pixel strip: the 4x4 noise tile rotates the
+    // sample kernel per class, so the 64 taps of a sample then move together and land in one strip of the z plane per row
+    // (8-9 cache lines per load instead of the ~12 of four interleaved, differently shifted classes).  Placement only.
+    const unsigned pix = blk * 256 + (threadIdx.x >> 6) + 4u * (threadIdx.x & 63u);
     if (pix >= P) return;
     const float* proj = scenes[scene].proj;
-    const float* camS = zplane + (size_t)scene * P;
+    const float* camS = zplane + (size_t)scene * ((size_t)(W + 2) * (H + 2));
     const size_t gp = (size_t)scene * P + pix;
     const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
     const float4 n4 = reinterpret_cast<const float4*>(nrm)[gp];
@@ -1565,14 +1588,18 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
     const float B1 = dot3(proj + 4, tgR), C1 = dot3(proj + 4, btR), D1 = dot3(proj + 4, nR);
     const float B3 = dot3(proj + 12, tgR), C3 = dot3(proj + 12, btR), D3 = dot3(proj + 12, nR);
     const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    // a perspective projection's last row is (0, 0, 1, 0): the clip-space w of a sample IS its camera z, bit for bit
+    // (0 * a + 0 * b + 1 * z + 0 and the products with exact zeros add nothing), and one of the four chains goes
+    const bool w_is_z = proj[12] == 0.0f && proj[13] == 0.0f && proj[14] == 1.0f && proj[15] == 0.0f;
     float occlusion = 0.0f;
+    auto taps = [&](auto w_is_z_c) {
 #pragma unroll 4
     for (int k = 0; k < 64; ++k) {
         const float s0 = kern[3 * k], s1 = kern[3 * k + 1], s2 = kern[3 * k + 2];
         const float spz = fmaf(nR[2], s2, fmaf(btR[2], s1, fmaf(tgR[2], s0, frag[2])));
         const float o0 = fmaf(D0, s2, fmaf(C0, s1, fmaf(B0, s0, A[0])));
         const float o1 = fmaf(D1, s2, fmaf(C1, s1, fmaf(B1, s0, A[1])));
-        const float o3 = fmaf(D3, s2, fmaf(C3, s1, fmaf(B3, s0, A[3])));
+        const float o3 = decltype(w_is_z_c)::value ? spz : fmaf(D3, s2, fmaf(C3, s1, fmaf(B3, s0, A[3])));
         const float rw = 1.0f / o3;
         const float sd = rect_bilinear_z(camS, W, H, fmaf(o0 * rw, hw, hw), fmaf(o1 * rw, hh, hh));
         // range check smoothstep(clamp(radius / |dz|)): exactly 1 whenever |dz| <= radius, and
@@ -1587,6 +1614,9 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
         }
         occlusion += occludes ? rc : 0.0f;
     }
+    };
+    if (w_is_z) taps(std::true_type{});   // scene-uniform: the whole wave takes one side
+    else taps(std::false_type{});
     ao[gp] = 1.0f - occlusion / 64.0f;
 }
 
@@ -1600,7 +1630,7 @@ __global__ __launch_bounds__(256) void k_ssao_apply(unsigned n_scenes, int W, in
     if (!scene_block(blocks_per_scene, n_scenes, scene, blk)) return;
     const unsigned pix = blk * 256 + threadIdx.x;
     if (pix >= P) return;
-    const float* camS = zplane + (size_t)scene * P;
+    const float* camS = zplane + (size_t)scene * ((size_t)(W + 2) * (H + 2));   // padded: texel (x, y) at [y + 1][x + 1]
     const float* aoS = ao + (size_t)scene * P;
     const size_t gp = (size_t)scene * P + pix;
     const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
@@ -1614,8 +1644,8 @@ __global__ __launch_bounds__(256) void k_ssao_apply(unsigned n_scenes, int W, in
     int colx[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        colx[k] = min(max(i - 3 + k, 0), W - 1);
-        rowo[k] = (unsigned)min(max(j - 3 + k, 0), H - 1) * (unsigned)W;
+        colx[k] = min(max(i - 3 + k, 0), W - 1) + 1;
+        rowo[k] = (unsigned)(min(max(j - 3 + k, 0), H - 1) + 1) * (unsigned)(W + 2);
     }
     float z[5][5];
 #pragma unroll
@@ -1770,7 +1800,7 @@ extern "C" int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uin
     const uint64_t blocks = (P + 255) / 256;
     bytes_out[0] = B * P * 8;                                              // d_vis
     bytes_out[1] = 2 * B * P * 16;                                         // d_hdr (two planes)
-    bytes_out[2] = 2 * B * P * 4;                                          // d_ao + camera-z plane
+    bytes_out[2] = B * P * 4 + B * (uint64_t)(width + 2) * (height + 2) * 4;  // d_ao + padded camera-z plane
     bytes_out[3] = B * SLHIP_NUM_LIGHTS * (uint64_t)shadow_res * shadow_res * 4;  // d_shadow
     bytes_out[4] = 16 + (uint64_t)queue_capacity * 16;                     // d_queue
     bytes_out[5] = B * blocks * 16;                                        // d_lum
