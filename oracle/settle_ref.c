@@ -325,7 +325,9 @@ static int reduce_simplex(sv* s, int n, float* lam, v3* v)
    features: after the warm start they get 4 iterations (86 % converge within them; an unconverged
    witness pair is still a pair of hull points, and the manifold filter below rejects far ones).  Over 96
    C2 scenes the settled state is statistically the same as with 32 (at rest 0.82, asleep 0.67). */
+static uint64_t* g_stats; /* statistics hook, see slref_settle_set_stats */
 #define GJK_TILT_MAX_ITER 4
+static int g_last_gjk_iters = 0; /* support evaluations of the last run (statistics only) */
 static int gjk_distance_seeded(const shape* A, const shape* B, v3 init_dir, float margin, v3* pa, v3* pb, float* dist,
                                const gjk_seed* seed_in, gjk_seed* seed_out, int max_iter)
 {
@@ -348,9 +350,11 @@ static int gjk_distance_seeded(const shape* A, const shape* B, v3 init_dir, floa
         vv = dot(v, v);
         if (vv < 1e-12f) return 0;
     }
+    g_last_gjk_iters = 0;
     for (int it = 0; it < max_iter; ++it) {
         sv w;
         int ia, ib;
+        g_last_gjk_iters = it + 1;
         w.a = support_i(A, neg(v), &ia);
         w.b = support_i(B, v, &ib);
         w.idx = ia | (ib << 16);
@@ -513,6 +517,7 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     float e = 0.5f * (bodies[ia].restitution + bodies[ib].restitution);
     gjk_seed seed;
     int code = gjk_distance_seeded(&A, &B, sub(ca, cb), margin, &pa, &pb, &dist, cached, &seed, GJK_MAX_ITER);
+    if (g_stats) g_stats[1024 + (g_last_gjk_iters > 63 ? 63 : g_last_gjk_iters)]++; /* [1024, 1088): iterations of the main runs */
     if (cached && code != 0) *cached = seed; /* overlap keeps the previous entry */
     if (code == 2) return 3.0e38f;
     if (code == 0) {
@@ -872,9 +877,8 @@ static void color_groups(scene_ws* ws, int n_bodies)
 }
 
 /* optional statistics of the solver's work for tools/solver_stats.py and DESIGN.md (not thread safe): four histograms of 256
-   bins each over the steps -- active contacts, friction anchors, colours, and the chain length of one sweep (sum over the colours
+   bins each over the steps (+ 64 bins from 1024 on: iterations of the main GJK runs, per hull pair) -- active contacts, friction anchors, colours, and the chain length of one sweep (sum over the colours
    of the largest group's contacts + anchors: what a lane pair per group has to walk in sequence) */
-static uint64_t* g_stats = NULL;
 void slref_settle_set_stats(uint64_t* h) { g_stats = h; }
 
 static void step_stats(const scene_ws* ws)

@@ -387,9 +387,13 @@ __device__ __forceinline__ SV seed_vertex(const Shape& A, const Shape& B, const 
     return p;
 }
 
-__device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict__ hv, v3 init_dir, float margin,
-                            v3* pa, v3* pb, float* dist, const GjkSeed seed_in, GjkSeed* seed_out, int max_iter)
+// `exhausted` (optional): set when the loop ran out of iterations instead of ending by one of its own criteria -- with the
+// full budget that is an answer like any other, with a smaller one (first pass of the lockstep narrowphase) it means "not done"
+__device__ __forceinline__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict__ hv, v3 init_dir, float margin,
+                                            v3* pa, v3* pb, float* dist, const GjkSeed seed_in, GjkSeed* seed_out, int max_iter,
+                                            bool* exhausted = nullptr)
 {
+    bool ran_out = true;
     Simplex S;
     S.n = 0;
     S.l0 = 1.0f; S.l1 = S.l2 = S.l3 = 0.0f;
@@ -424,11 +428,11 @@ __device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict
         }
         const int n = S.n;
         if (n > 0) {
-            if (vv - vw <= 1e-6f * vv) break;
+            if (vv - vw <= 1e-6f * vv) { ran_out = false; break; }
             bool dup = same_w(S.p0, w);
             if (n > 1) dup = dup || same_w(S.p1, w);
             if (n > 2) dup = dup || same_w(S.p2, w);
-            if (dup) break;
+            if (dup) { ran_out = false; break; }
         }
         if (n == 0) S.p0 = w; else if (n == 1) S.p1 = w; else if (n == 2) S.p2 = w; else S.p3 = w;
         S.n = n + 1;
@@ -436,10 +440,11 @@ __device__ int gjk_distance(const Shape& A, const Shape& B, const f3* __restrict
         const int nn = reduce_simplex(S, &nv);
         if (nn == 0) return 0;
         const float nvv = dot(nv, nv);
-        if (n + 1 > 1 && nvv >= vv && it > 0) { v = nv; vv = nvv; break; }
+        if (n + 1 > 1 && nvv >= vv && it > 0) { v = nv; vv = nvv; ran_out = false; break; }
         v = nv; vv = nvv;
         if (vv < 1e-12f) return 0;
     }
+    if (exhausted) *exhausted = ran_out;
     if (S.n == 0) return 0;
     v3 a = V(0, 0, 0), b = V(0, 0, 0);
     a = madd(a, S.p0.a, S.l0); b = madd(b, S.p0.b, S.l0);
@@ -640,9 +645,9 @@ struct MainResult {       // stage 1: plain GJK
     GjkSeed seed;         // type 1: the converged simplex, start of the tilt runs
 };
 
-__device__ bool pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
-                          const f3* __restrict__ hv, const float4* __restrict__ gv, float margin, const GjkSeed cached,
-                          MainResult& r)
+__device__ __forceinline__ bool pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
+                                          const f3* __restrict__ hv, const float4* __restrict__ gv, float margin, const GjkSeed cached,
+                                          MainResult& r, int max_iter = kGjkMaxIter, bool* unfinished = nullptr)
 {
     r.type = 0;
     Shape A, B;
@@ -653,7 +658,12 @@ __device__ bool pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, c
     v3 pa, pb, n;
     float dist;
     r.seed.n = 0; r.seed.i0 = r.seed.i1 = r.seed.i2 = 0;
-    const int code = gjk_distance(A, B, hv, sub(ca, cb), margin, &pa, &pb, &dist, cached, &r.seed, kGjkMaxIter);
+    bool ran_out = false;
+    const int code = gjk_distance(A, B, hv, sub(ca, cb), margin, &pa, &pb, &dist, cached, &r.seed, max_iter, &ran_out);
+    if (unfinished) {
+        *unfinished = ran_out && max_iter < kGjkMaxIter;
+        if (*unfinished) return false;
+    }
     if (code == 2) return true;
     if (code == 0) {
         float sep;
@@ -2035,7 +2045,10 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve), hipFuncAttributeMaxDynamicSharedMemorySize, SL.total));
         const unsigned cstride = pair_cache_stride(params);
         k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, cache_w, cstride);
-        const dim3 pair_grid(n_scenes, SLHIP_MAX_HULL_PAIRS / 64);
+        // the compacted narrowphase passes walk their work lists with a grid stride: enough waves for a step's typical list
+        // (a scene has ~40 candidate pairs), never more than the worst case needs
+        const unsigned list_stride = n_scenes * (unsigned)SLHIP_MAX_HULL_PAIRS;
+        const unsigned work_grid = n_scenes < 16u ? n_scenes * (SLHIP_MAX_HULL_PAIRS / 64) : n_scenes;
         uint32_t step = 0;
         for (uint32_t f = 0; f < params->frames; ++f)
             for (uint32_t sub = 0; sub < params->substeps; ++sub, ++step) {
@@ -2046,9 +2059,10 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                 if (timed) (void)hipEventRecord(ev[0], stream);
                 k_w_begin<<<n_scenes, 64, BL.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, W, BL, drive_w);
                 if (timed) (void)hipEventRecord(ev[1], stream);
-                k_w_gjk_main<<<pair_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride);
+                k_w_gjk_first<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride);
+                k_w_gjk_rest<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride);
                 if (timed) (void)hipEventRecord(ev[2], stream);
-                k_w_gjk_tilt<<<pair_grid, 64, 0, stream>>>(d_hull_verts, *params, W);
+                k_w_gjk_tilt<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, list_stride);
                 if (timed) (void)hipEventRecord(ev[3], stream);
                 k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL);
                 if (timed) (void)hipEventRecord(ev[4], stream);
