@@ -1521,26 +1521,40 @@ __constant__ float c_ssao_kernel[192];
 
 struct __attribute__((packed, aligned(4))) ZPair { float a, b; };   // two neighbouring texels: one 8-byte load, 4-byte aligned
 
-// `img`: the scene's padded camera-z plane (k_shade), pitch W + 2, texel (x, y) at [y + 1][x + 1]
-__device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, int W, int H, float x, float y)
+// `img`: the scene's padded camera-z plane (k_shade), pitch W + 2, texel (x, y) at [y + 1][x + 1]; `xs`, `ys`: window
+// coordinates already shifted to texel centres (oracle rect_bilinear_s)
+__device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, int W, int H, float xs, float ys)
 {
-    const float xs = x - 0.5f, ys = y - 0.5f;
     const float fx = floorf(xs), fy = floorf(ys);
     const float ax = xs - fx, ay = ys - fy;
     // the rect sampler's texels clamp(int(f), 0, n-1) and clamp(int(f) + 1, 0, n-1) are the padded plane's columns
     // c and c + 1 with c = clamp(int(f), -1, n-1) + 1; clamp(int(f), lo, hi) == int(med3(f, lo, hi)) for every non-NaN f
-    // (integers below 2^24 are exact in fp32): one v_med3_f32 per coordinate.  The plane (4 B/px instead of the 16 B/px
-    // of the camCoordinates target) keeps the 64-tap gather L2 resident.
-    const unsigned x0 = (unsigned)((int)__builtin_amdgcn_fmed3f(fx, -1.0f, (float)(W - 1)) + 1);
-    const unsigned y0 = (unsigned)((int)__builtin_amdgcn_fmed3f(fy, -1.0f, (float)(H - 1)) + 1);
-    const unsigned pitch = (unsigned)(W + 2) * 4u;
-    // byte offsets in 32 bits from the wave-uniform plane base (rows * bytes < 2^24 * 4): scalar base + one VGPR offset per load
-    const unsigned off = __umul24(y0, pitch) + x0 * 4u;
+    // (integers below 2^24 are exact in fp32, and so is row * pitch + column: one v_med3_f32 per coordinate, one fma, one
+    // conversion).  The plane (4 B/px instead of the 16 B/px of the camCoordinates target) keeps the 64-tap gather L2 resident.
+    const float xc = __builtin_amdgcn_fmed3f(fx, -1.0f, (float)(W - 1));
+    const float yc = __builtin_amdgcn_fmed3f(fy, -1.0f, (float)(H - 1));
+    const int pitch = W + 2;
+    const int idx = (int)fmaf(yc, (float)pitch, xc);                  // (row - 1) * pitch + (column - 1), may be negative
+    // byte offsets in 32 bits from the wave-uniform plane base: scalar base + one VGPR offset per load
+    const unsigned off = (unsigned)(idx * 4 + (pitch + 1) * 4);
     const char* base = reinterpret_cast<const char*>(img);
     const ZPair top2 = *reinterpret_cast<const ZPair*>(base + off);
-    const ZPair bot2 = *reinterpret_cast<const ZPair*>(base + (off + pitch));
+    const ZPair bot2 = *reinterpret_cast<const ZPair*>(base + (off + (unsigned)pitch * 4u));
     const float top = fmaf(ax, top2.b - top2.a, top2.a), bot = fmaf(ax, bot2.b - bot2.a, bot2.a);
     return fmaf(ay, bot - top, top);
+}
+
+// oracle ssao_rcp: three Newton steps on |x| from the integer-subtraction seed, sign restored
+__device__ __forceinline__ float ssao_rcp(float x)
+{
+    const float a = fabsf(x);
+    float r = __uint_as_float(0x7EF311C7u - __float_as_uint(a));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float e = fmaf(-a, r, 1.0f);
+        r = fmaf(r, e, r);
+    }
+    return __uint_as_float((__float_as_uint(r) & 0x7fffffffu) | (__float_as_uint(x) & 0x80000000u));
 }
 
 __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
@@ -1587,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
     const float B0 = dot3(proj, tgR), C0 = dot3(proj, btR), D0 = dot3(proj, nR);
     const float B1 = dot3(proj + 4, tgR), C1 = dot3(proj + 4, btR), D1 = dot3(proj + 4, nR);
     const float B3 = dot3(proj + 12, tgR), C3 = dot3(proj + 12, btR), D3 = dot3(proj + 12, nR);
-    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H, hwm = hw - 0.5f, hhm = hh - 0.5f;
     // a perspective projection's last row is (0, 0, 1, 0): the clip-space w of a sample IS its camera z, bit for bit
     // (0 * a + 0 * b + 1 * z + 0 and the products with exact zeros add nothing), and one of the four chains goes
     const bool w_is_z = proj[12] == 0.0f && proj[13] == 0.0f && proj[14] == 1.0f && proj[15] == 0.0f;
@@ -1600,8 +1614,8 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
         const float o0 = fmaf(D0, s2, fmaf(C0, s1, fmaf(B0, s0, A[0])));
         const float o1 = fmaf(D1, s2, fmaf(C1, s1, fmaf(B1, s0, A[1])));
         const float o3 = decltype(w_is_z_c)::value ? spz : fmaf(D3, s2, fmaf(C3, s1, fmaf(B3, s0, A[3])));
-        const float rw = 1.0f / o3;
-        const float sd = rect_bilinear_z(camS, W, H, fmaf(o0 * rw, hw, hw), fmaf(o1 * rw, hh, hh));
+        const float rw = ssao_rcp(o3);
+        const float sd = rect_bilinear_z(camS, W, H, fmaf(o0 * rw, hw, hwm), fmaf(o1 * rw, hh, hhm));
         // range check smoothstep(clamp(radius / |dz|)): exactly 1 whenever |dz| <= radius, and
         // irrelevant for taps that do not occlude -- the division runs only where it matters
         // (on open surfaces whole waves skip it)
