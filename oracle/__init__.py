@@ -349,11 +349,11 @@ def settle_stats(srec, bodies, hulls, hull_verts, params):
     256-bin histograms over the steps -- 'active' contacts, friction 'anchors', 'colours', 'chain' (rows a lane pair walks
     in sequence per sweep)."""
     L = lib()
-    h = np.zeros(1088, np.uint64)
+    h = np.zeros(1096, np.uint64)
     L.slref_settle_set_stats.argtypes = [C.c_void_p]
     L.slref_settle_set_stats(_p(h))
     try:
         settle(srec, bodies, hulls, hull_verts, params)
     finally:
         L.slref_settle_set_stats(None)
-    return {"active": h[:256], "anchors": h[256:512], "colours": h[512:768], "chain": h[768:1024], "gjk_iters": h[1024:]}
+    return {"active": h[:256], "anchors": h[256:512], "colours": h[512:768], "chain": h[768:1024], "gjk_iters": h[1024:1088], "tilt_iters": h[1088:]}

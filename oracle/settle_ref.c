@@ -563,6 +563,7 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
         float d2;
         int ok = tilt_a ? gjk_distance_seeded(&T, &B, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, &seed, NULL, GJK_TILT_MAX_ITER)
                         : gjk_distance_seeded(&A, &T, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, &seed, NULL, GJK_TILT_MAX_ITER);
+        if (g_stats) g_stats[1088 + (g_last_gjk_iters > 7 ? 7 : g_last_gjk_iters)]++; /* [1088, 1096): iterations of the tilt runs */
         if (ok != 1) continue;
         /* map the witness on the tilted shape back to the untilted pose */
         if (tilt_a) {

@@ -34,6 +34,9 @@ st = oracle.settle_stats(ss, bodies, hull_recs, hull_verts, SB.default_params(ta
 gi = st.pop("gjk_iters").astype(np.float64)
 print("main GJK runs per step and scene: %.1f; share by iterations:" % (gi.sum() / max(1.0, st["active"].sum())),
       " ".join("%d:%.3f" % (i, gi[i] / gi.sum()) for i in range(len(gi)) if gi[i] / gi.sum() >= 0.002))
+ti = st.pop("tilt_iters").astype(np.float64)
+print("tilt runs per step and scene: %.1f; share by iterations:" % (ti.sum() / max(1.0, st["active"].sum())),
+      " ".join("%d:%.3f" % (i, ti[i] / ti.sum()) for i in range(len(ti)) if ti[i] > 0))
 for name, h in st.items():
     h = h.astype(np.float64)
     tot = h.sum()
