@@ -333,8 +333,9 @@ typedef struct {
 #define SLHIP_MAX_ACTIVE_CONTACTS 160 /* solver contacts per scene and step: plane contacts first,
                                          then hull-pair contacts in pair order; later ones are dropped */
 
-/* Steps every scene of the batch `frames * substeps` times (one persistent workgroup per
- * scene, no host round trip), including the redrop heuristic when params->tabletop.
+/* Steps every scene of the batch `frames * substeps` times without a host round trip (six kernel
+ * launches per step over the whole batch; SLHIP_SETTLE_IMPL=persistent: one workgroup per scene for the
+ * whole call -- same results bit for bit), including the redrop heuristic when params->tabletop.
  * d_bodies is updated in place (pose, velocities, separation).  Replaces the hot loop of
  * Scene::simulateTableTopScene (scene.cpp:720-756) and, with frames=substeps=1 and
  * tabletop=0, Scene::simulate(dt) (scene.cpp:903-912).                                       */
@@ -350,10 +351,11 @@ int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
 #define SLHIP_SETTLE_REFUSED_HULLS  2u   /* more hulls than max_hulls_per_scene, or > 1024 in one body */
 int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_status, uint32_t* h_n_refused,
                         void* stream);
-/* Optional live timing of the five kernels of a lockstep step (bench.py's roofline leg): HIP events on the launch's stream
- * around every kernel of every 8th step.  slhip_settle_timings synchronises the recorded events and returns, since the last
- * call, the average launch duration [ms] and the number of timed launches of 0 k_w_begin (integrate, table contacts,
- * broadphase), 1 k_w_gjk_main, 2 k_w_gjk_tilt, 3 k_w_finish (manifolds, groups, prep, colouring), 4 k_w_solve.          */
+/* Optional live timing of the phases of a lockstep step (bench.py's roofline leg): HIP events on the launch's stream
+ * around every phase of every 8th step.  slhip_settle_timings synchronises the recorded events and returns, since the last
+ * call, the average duration [ms] and the number of timed launches of 0 k_w_begin (integrate, table contacts, broadphase),
+ * 1 k_w_gjk_first + k_w_gjk_rest (the two passes of the main GJK), 2 k_w_gjk_tilt, 3 k_w_finish (manifolds, groups, prep,
+ * colouring, cost class), 4 k_w_solve.                                                                                  */
 int slhip_settle_timing_enable(int on);
 int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5]);
 /* scratch for n_scenes scenes: accumulators + the per-scene pair cache, sized from the hints in
