@@ -121,9 +121,9 @@ struct DriveAcc { float dl[3], da[3]; };
 // carry the body indices (as integer bits) and the restitution.
 struct Contact {
     v3 ra, rb, n;
-    float err;            // sep - rest
+    float err;            // sep - rest; after prep_contact: the normal row's target velocity in the biased sweeps
     float kn, kt1, kt2, ln, lt1, lt2;
-    float bounce;         // required rebound velocity (-e * vn0) or a large negative number
+    float bounce;         // restitution; after prep_contact: the normal row's target velocity in the unbiased sweeps
     float til;            // 1 / |a| of the tangent construction (prep_contact): spares the solver a sqrt and a division per row
 };
 static_assert(sizeof(Contact) == 72, "Contact layout");
@@ -960,7 +960,7 @@ __device__ __forceinline__ float eff_mass(const WBody& a, const WBody* b, v3 ra,
     return k > 0.0f ? 1.0f / k : 0.0f;
 }
 
-__device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_threshold)
+__device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_threshold, float inv_dt)
 {
     Contact c = *cp;
     const int ia = __float_as_int(c.ln), ib = __float_as_int(c.lt1);
@@ -976,10 +976,19 @@ __device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_thresho
     v3 rel = vel_at(a, c.ra);
     if (b) rel = sub(rel, vel_at(*b, c.rb));
     const float vn0 = dot(rel, c.n);
-    // the oracle tests (vn0 < -threshold && e > 0) in every solve; fold it once
+    // The oracle builds the normal row's target velocity in every solve -- speculative contacts (err > 0) may close their gap,
+    // penetrating ones are pushed out in the biased sweeps only, a rebound above the bounce threshold overrides both.  The same
+    // expressions once per step: `err` becomes the target of the biased sweeps, `bounce` that of the unbiased ones.
     float bounce = -3.0e38f;
     if (vn0 < -bounce_threshold && e > 0.0f) bounce = -e * vn0;
-    cp->kn = c.kn; cp->kt1 = c.kt1; cp->kt2 = c.kt2; cp->bounce = bounce;
+    const float err = c.err;
+    float tb, tu;
+    if (err > 0.0f) { tb = -err * inv_dt; tu = tb; }
+    else { tb = -0.8f * err * inv_dt; tu = 0.0f; }
+    if (bounce > tb) tb = bounce;
+    if (bounce > tu) tu = bounce;
+    cp->err = tb;
+    cp->kn = c.kn; cp->kt1 = c.kt1; cp->kt2 = c.kt2; cp->bounce = tu;
     cp->ln = 0.0f; cp->lt1 = 0.0f; cp->til = c.til < 0.0f ? -til : til;
 }
 
@@ -1047,11 +1056,7 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, int
         v3 pv = add(M.v, cross(M.w, r));
         v3 d = sub(pv, pair_swap(pv));              // side 0: a - b, side 1: b - a
         const float vn = sgn * dot(d, c.n);
-        const float err = c.err;
-        float target;
-        if (err > 0.0f) target = -err * inv_dt;
-        else target = biased ? -0.8f * err * inv_dt : 0.0f;
-        if (c.bounce > target) target = c.bounce;
+        const float target = biased ? c.err : c.bounce;   // prep_contact
         float dl = (target - vn) * c.kn;
         float ln = c.ln + dl;
         if (ln < 0.0f) ln = 0.0f;
@@ -1710,7 +1715,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             PROF(5);
 
             // (f) prep
-            for (int c = lane; c < n_active; c += 64) prep_contact(&ac[c], wb, prm.bounce_threshold);
+            for (int c = lane; c < n_active; c += 64) prep_contact(&ac[c], wb, prm.bounce_threshold, 1.0f / prm.dt);
             PROF(6);
             // (g) greedy colouring, largest group first (oracle color_groups): every lane ranks its group by
             // (contacts descending, index ascending), the ranked list goes to `order` (rewritten below),
