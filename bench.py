@@ -93,8 +93,10 @@ class Pipeline:
                               shadows=not os.environ.get("SLHIP_BENCH_NO_SHADOWS"))
             b.set_camera_intrinsics(*INTRINSICS)
             self.sets.append(b)
-        self.s_settle = [torch.cuda.Stream(device=dev) for _ in range(settle_streams)]
-        self.s_render = torch.cuda.Stream(device=dev)
+        # SLHIP_BENCH_PRIO = "<settle>,<render>" stream priorities (developer knob; -1 = high, 0 = default)
+        ps, pr = (int(x) for x in os.environ.get("SLHIP_BENCH_PRIO", "0,0").split(","))
+        self.s_settle = [torch.cuda.Stream(device=dev, priority=ps) for _ in range(settle_streams)]
+        self.s_render = torch.cuda.Stream(device=dev, priority=pr)
         self.free = [None] * self.ring        # event: the set's previous render finished (its records may be rewritten)
         self.buffers = []                     # ring of render-target sets: a chunk's ground truth stays in HBM until TARGET_RING
                                               # further chunks have been rendered (50 GB of the last 4096 scenes at the defaults)

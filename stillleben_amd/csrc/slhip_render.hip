@@ -19,6 +19,7 @@
 // All arithmetic that feeds integer outputs or depth follows rules R1..R7 of
 // oracle/render_ref.c; this file is compiled with -ffp-contract=off so that only the explicit
 // fmaf() calls fuse.
+#include <vector>
 #include <type_traits>
 #include "slhip_common.h"
 #include "slhip_cubemap.h"
@@ -1745,20 +1746,24 @@ __global__ __launch_bounds__(256) void k_clear_shadow(unsigned* __restrict__ sha
 
 bool g_ssao_tables_uploaded[16] = {};
 
-// optional per-phase HIP-event timing (bench.py's roofline leg)
+// optional per-phase HIP-event timing (bench.py's roofline leg).  Every timed slhip_render call records into its OWN set of
+// events, and nothing waits for them until slhip_render_timings() asks: the host must be free to enqueue the next calls (and the
+// next step's settle) while this one runs -- a readback of the previous call's events at the start of every call kept the host
+// in lockstep with the render stream, so that settle and render of consecutive batches never overlapped.
 constexpr int kNumPhases = 8;
 bool g_timing = false;
-hipEvent_t g_ev[kNumPhases + 1];
-bool g_ev_created = false;
-bool g_ev_recorded[kNumPhases + 1];
-bool g_pending = false;
+bool g_ev_created = false;      // timing has been enabled at least once
+struct TimedCall { hipEvent_t ev[kNumPhases + 1]; bool recorded[kNumPhases + 1]; };
+std::vector<TimedCall> g_timed;
+TimedCall* g_cur = nullptr;     // the call being enqueued
 double g_acc_ms[kNumPhases] = {};
 
 inline void mark(int i, hipStream_t stream)
 {
-    if (!g_timing) return;
-    (void)hipEventRecord(g_ev[i], stream);
-    g_ev_recorded[i] = true;
+    if (!g_timing || !g_cur) return;
+    if (hipEventCreate(&g_cur->ev[i]) != hipSuccess) return;
+    (void)hipEventRecord(g_cur->ev[i], stream);
+    g_cur->recorded[i] = true;
 }
 
 }  // namespace
@@ -1767,30 +1772,33 @@ inline void mark(int i, hipStream_t stream)
 //         6 ssao apply, 7 tone map
 extern "C" int slhip_timing_enable(int on)
 {
-    if (on && !g_ev_created) {
-        for (int i = 0; i <= kNumPhases; ++i) SLHIP_CHECK(hipEventCreate(&g_ev[i]));
-        g_ev_created = true;
-    }
+    if (on) g_ev_created = true;
     g_timing = on != 0;
     return 0;
 }
 
+// waits for the recorded calls, adds their phase durations to the accumulators, frees their events
 static int flush_timings()
 {
-    if (!g_ev_created || !g_pending) return 0;
-    SLHIP_CHECK(hipEventSynchronize(g_ev[kNumPhases]));
-    int prev = -1;
-    for (int i = 0; i <= kNumPhases; ++i) {
-        if (!g_ev_recorded[i]) continue;
-        if (prev >= 0) {
-            float ms = 0.0f;
-            SLHIP_CHECK(hipEventElapsedTime(&ms, g_ev[prev], g_ev[i]));
-            g_acc_ms[prev] += ms;
+    int status = 0;
+    for (TimedCall& c : g_timed) {
+        int prev = -1;
+        for (int i = 0; i <= kNumPhases; ++i) {
+            if (!c.recorded[i]) continue;
+            if (status == 0 && hipEventSynchronize(c.ev[i]) != hipSuccess) status = -1;
+            if (status == 0 && prev >= 0) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, c.ev[prev], c.ev[i]) == hipSuccess) g_acc_ms[prev] += ms;
+            }
+            prev = i;
         }
-        prev = i;
+        for (int i = 0; i <= kNumPhases; ++i)
+            if (c.recorded[i]) (void)hipEventDestroy(c.ev[i]);
     }
-    g_pending = false;
-    return 0;
+    g_timed.clear();
+    g_cur = nullptr;
+    if (status != 0) slhip::set_error("slhip_render_timings: event readback failed");
+    return status;
 }
 
 // returns the per-phase totals accumulated over all slhip_render calls since the last query
@@ -1877,9 +1885,9 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     }
 
     if (g_timing) {
-        const int fst = flush_timings();  // previous call's events (normally already complete)
-        if (fst != 0) return fst;
-        for (int i = 0; i <= kNumPhases; ++i) g_ev_recorded[i] = false;
+        g_timed.emplace_back();
+        g_cur = &g_timed.back();
+        for (int i = 0; i <= kNumPhases; ++i) g_cur->recorded[i] = false;
     }
     // vertex transform on the matrix cores: camera clip + (if shadows) the three light clips
     if (n_chunks > 0) {
@@ -1962,6 +1970,5 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
         SLHIP_LAUNCH_CHECK();
     }
     mark(kNumPhases, stream);
-    if (g_timing) g_pending = true;
     return 0;
 }
