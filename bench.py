@@ -33,8 +33,8 @@ TARGET_RING = 8     # render-target sets kept alive (chunks of --render-chunk sc
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16384,
                     help="scenes per GPU per step = one settle launch.  Scenes settle in very different times (60 .. 410 ms against a "
                          "145 ms mean) and 2048 are resident at once, so a launch ends with a tail of idle CUs; the more rounds of "
@@ -377,6 +377,7 @@ def main():
     iso = np.array(list(ms_iso))
     t_render_iso = float(sum(a.elapsed_time(b) for a, b in iso_wall))
     # ... and ONE settle launch alone on the idle GPU (same shape: the whole step's scenes)
+    pipe.eng.L.slhip_settle_timing_enable(1)
     with torch.cuda.stream(pipe.s_settle[0]):
         b_last.stage(scene_id_base=scene_base(args.warmup + args.steps))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -385,6 +386,10 @@ def main():
         e1.record()
     torch.cuda.synchronize()
     t_settle_alone = e0.elapsed_time(e1)
+    pipe.eng.L.slhip_settle_timings(C.byref(st_ms), C.byref(st_n))     # the same kernels with the GPU to themselves
+    pipe.eng.L.slhip_settle_timing_enable(0)
+    for i, n in enumerate(settle_kernels):
+        settle_kernels[n]["avg_ms_per_launch_alone"] = float(st_ms[i])
     if rank == 0:
         out = report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso,
                      phases, iso, settle_kernels)
@@ -488,21 +493,31 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
         "unit": "GB/s", "traffic": sq["hbm_bytes_per_scene"] * args.batch if "hbm_bytes_per_scene" in sq else None,
         "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms_launch, "launches_per_settle": launches_per_settle,
         "measured": measured,
-        "note": "the time-dominant kernel is NOT HBM-bound: a step's Gauss-Seidel sweeps are chains of dependent contact solves "
-                "(4 + 4 sweeps x the longest contact chain of the scene), the limiter is the latency of that chain x the scenes "
-                "resident per CU; the HBM fraction is reported because the schema asks for one -- see valu_frac / active_lanes",
+        "note": "the time-dominant kernel is NOT HBM-bound but bound by VALU issue (a wave64 instruction holds its SIMD for four "
+                "cycles with 4.4 of 64 lanes active: Gauss-Seidel sweeps over chains of dependent contact rows); the HBM fraction "
+                "is reported because the schema asks for one -- see valu_frac / active_lanes.  ms_per_launch is taken in the "
+                "timed region, where the kernel shares the GPU with the render stream (the event pairs also bracket its wait for "
+                "free CU slots); ms_per_launch_alone / valu_frac_alone: one settle with the GPU to itself after the timed region",
         "valu_insts_per_scene_launch": valu_per_launch,
         "valu_frac": (valu_per_launch * args.batch / (ms_launch * 1e-3) / (1024 * 2.4e9 / 4)) if valu_per_launch and ms_launch > 0 else None,
         "valu_peak": "1024 SIMDs x 2.4 GHz / 4 cycles: SQ_ACTIVE_INST_VALU (quad-cycles) per SQ_INSTS_VALU is 1.0 for these kernels, "
                      "i.e. a wave64 VALU instruction holds its SIMD for four cycles",
         "active_lanes": sq.get("active_lanes"),
+        "ms_per_launch_alone": settle_kernels[kname].get("avg_ms_per_launch_alone") if lockstep else None,
         "counters_source": cnt.get("source"),
         "settle_kernels_ms_per_launch": {k: v["avg_ms_per_launch"] for k, v in settle_kernels.items()} if lockstep else None,
+        "settle_kernels_ms_per_launch_alone": {k: v.get("avg_ms_per_launch_alone") for k, v in settle_kernels.items()} if lockstep else None,
         "settle_ms_per_batch": t_settle, "settle_ms_per_batch_alone": t_settle_alone,
         "steps_scenes_per_s": args.batch * 400 / (t_settle * 1e-3),
     }
     if roofline["achieved"] is not None:
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    ms_alone = roofline.get("ms_per_launch_alone")
+    if ms_alone:
+        roofline["achieved_alone"] = alg / (ms_alone * 1e-3) / 1e9
+        roofline["frac_alone"] = roofline["achieved_alone"] / roofline["peak"]
+        if valu_per_launch:
+            roofline["valu_frac_alone"] = valu_per_launch * args.batch / (ms_alone * 1e-3) / (1024 * 2.4e9 / 4)
     k_dom = int(np.argmax(phases)) if phases.sum() > 0 else 4
     return {
         "metric": "scenes/sec (settle + 640x480 6-ch GT render), 20-obj YCB-like",
