@@ -25,6 +25,7 @@
  *   - the Gauss-Seidel order is defined by a greedy colouring of the body-pair groups and is
  *     independent of the number of lanes.
  */
+#include <stdio.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -881,6 +882,12 @@ static void color_groups(scene_ws* ws, int n_bodies)
    bins each over the steps (+ 64 bins from 1024 on: iterations of the main GJK runs, per hull pair) -- active contacts, friction anchors, colours, and the chain length of one sweep (sum over the colours
    of the largest group's contacts + anchors: what a lane pair per group has to walk in sequence) */
 void slref_settle_set_stats(uint64_t* h) { g_stats = h; }
+static FILE* g_profile_fp = NULL;
+void slref_settle_set_profile_dump(const char* path)
+{
+    if (g_profile_fp) { fclose(g_profile_fp); g_profile_fp = NULL; }
+    if (path) g_profile_fp = fopen(path, "w");
+}
 
 static void step_stats(const scene_ws* ws)
 {
@@ -898,6 +905,11 @@ static void step_stats(const scene_ws* ws)
         if (rows > longest[ws->g_color[g]]) longest[ws->g_color[g]] = rows;
     }
     for (int c = 0; c < ws->n_colors; ++c) chain += longest[c];
+    if (g_profile_fp) { /* developer dump (tools/solver_pairing.py): one line per scene and step, the longest group per colour */
+        fprintf(g_profile_fp, "%d", ws->n_colors);
+        for (int c = 0; c < ws->n_colors; ++c) fprintf(g_profile_fp, " %d", longest[c]);
+        fprintf(g_profile_fp, "\n");
+    }
     g_stats[active > 255 ? 255 : active]++;
     g_stats[256 + (anchors > 255 ? 255 : anchors)]++;
     g_stats[512 + ws->n_colors]++;
