@@ -2047,7 +2047,14 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         const BeginLds BL = begin_layout(nb_cap, lhc);
         const FinishLds FL = finish_layout(nb_cap);
         const SolveLds SL = solve_layout(nb_cap);
-        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve), hipFuncAttributeMaxDynamicSharedMemorySize, SL.total));
+        // Scenes per solver wave.  SLHIP_SOLVE_SPW=2 solves cost-sorted neighbours side by side, 32 lanes each (same bits): 28 %
+        // fewer VALU instructions (28.4 k per scene and launch against 39.6 k), but two scenes' LDS per wave leaves five waves per
+        // CU -- 2.05 against 1.33 ms per launch alone, and in the pipeline the settle becomes the critical path: 7 330 against
+        // 7 310 scenes/s.  One scene per wave stays the default.
+        int spw = 1;
+        if (const char* e = getenv("SLHIP_SOLVE_SPW")) spw = atoi(e) == 2 ? 2 : 1;
+        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SL.total));
+        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL.total));
         const unsigned cstride = pair_cache_stride(params);
         k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, cache_w, cstride);
         // the compacted narrowphase passes walk their work lists with a grid stride: enough waves for a step's typical list
@@ -2071,8 +2078,12 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                 if (timed) (void)hipEventRecord(ev[3], stream);
                 k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL);
                 if (timed) (void)hipEventRecord(ev[4], stream);
-                k_w_solve<<<n_scenes, 64, SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
-                                                              sub + 1 == params->substeps ? 1 : 0);
+                if (spw == 2)
+                    k_w_solve<2><<<(n_scenes + 1) / 2, 64, 2 * SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
+                                                                                     sub + 1 == params->substeps ? 1 : 0, n_scenes);
+                else
+                    k_w_solve<1><<<n_scenes, 64, SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
+                                                                      sub + 1 == params->substeps ? 1 : 0, n_scenes);
                 if (timed) {
                     (void)hipEventRecord(ev[5], stream);
                     for (int k = 0; k < 5; ++k) g_settle_timing.pending.push_back({k, ev[k], ev[k + 1]});

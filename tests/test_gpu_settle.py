@@ -283,7 +283,7 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
 
 
 def test_both_settle_implementations_are_bit_identical(sl, oracle, monkeypatch):
-    """The two implementations of the step -- the lockstep pipeline (default: five launches per step over the whole batch,
+    """The two implementations of the step -- the lockstep pipeline (default: six launches per step over the whole batch,
     csrc/slhip_settle_wide.inc) and the persistent kernel (SLHIP_SETTLE_IMPL=persistent: one wave per scene for the whole
     settle, optionally launched in segments of frames) -- give the oracle's bits: a batch of mixed scenes, tabletop settle."""
     cube = scaled(sl, S.CUBE, 0.15)
@@ -292,6 +292,10 @@ def test_both_settle_implementations_are_bit_identical(sl, oracle, monkeypatch):
     monkeypatch.setenv("SLHIP_SETTLE_IMPL", "lockstep")
     gpu, ref = run_both(oracle, scs, frames=60)
     assert_bodies_equal(gpu, ref)
+    monkeypatch.setenv("SLHIP_SOLVE_SPW", "2")        # the lockstep solver with two cost-sorted scenes per wave
+    gpu2, ref2 = run_both(oracle, scs + [heap(sl, 310, 9, cube, bunny)], frames=60)   # odd number: the last wave holds one scene
+    assert_bodies_equal(gpu2, ref2)
+    monkeypatch.delenv("SLHIP_SOLVE_SPW")
     monkeypatch.setenv("SLHIP_SETTLE_IMPL", "persistent")
     gpu1, _ = run_both(oracle, scs, frames=60)
     assert_bodies_equal(gpu1, ref)
