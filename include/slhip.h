@@ -333,9 +333,10 @@ typedef struct {
 #define SLHIP_MAX_ACTIVE_CONTACTS 160 /* solver contacts per scene and step: plane contacts first,
                                          then hull-pair contacts in pair order; later ones are dropped */
 
-/* Steps every scene of the batch `frames * substeps` times without a host round trip (six kernel
- * launches per step over the whole batch; SLHIP_SETTLE_IMPL=persistent: one workgroup per scene for the
- * whole call -- same results bit for bit), including the redrop heuristic when params->tabletop.
+/* Steps every scene of the batch `frames * substeps` times without a host round trip (batches above
+ * 1024 scenes: six kernel launches per step over the whole batch; smaller ones: one workgroup per scene for
+ * the whole call -- same results bit for bit, SLHIP_SETTLE_IMPL=lockstep|persistent overrides the choice),
+ * including the redrop heuristic when params->tabletop.
  * d_bodies is updated in place (pose, velocities, separation).  Replaces the hot loop of
  * Scene::simulateTableTopScene (scene.cpp:720-756) and, with frames=substeps=1 and
  * tabletop=0, Scene::simulate(dt) (scene.cpp:903-912).                                       */

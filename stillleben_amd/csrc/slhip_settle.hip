@@ -1993,15 +1993,19 @@ extern "C" int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5
 }
 
 // Two implementations of the same step (same device functions, bit-identical results, both parity-tested):
-//   lockstep (default)    slhip_settle_wide.inc: five launches per step over the whole batch, state in HBM / L2
-//   persistent            k_settle: one wave per scene for the whole settle, scene state in LDS (SLHIP_SETTLE_IMPL=persistent)
-// Measured on the C2 workload (profiles/r02): alone, a settle of 16384 scenes takes 1.54 s either way; in the
-// pipelined benchmark the lockstep kernels leave the render stream alone (its launch sequences run at their isolated speed, where
-// the persistent workgroups -- 256 VGPRs, ~150 ms lifetime -- make them wait for SIMDs): 5 800 against 5 590 scenes/s.
-static bool use_persistent_settle()
+//   lockstep     slhip_settle_wide.inc: six launches per step over the whole batch, state in HBM / L2
+//   persistent   k_settle: one wave per scene for the whole settle, scene state in LDS
+// Which one runs is a matter of speed only (profiles/r02).  Large batches: lockstep -- a settle of 16384 C2
+// scenes takes 1.19 s against 1.59 s, and its short kernels share the GPU with the render stream where the persistent
+// workgroups (256 VGPRs, ~150 ms lifetime) make it wait.  Small batches: persistent -- up to ~1000 scenes everything is resident
+// at once and a step costs one pass through LDS instead of six launches through L2 (64 scenes 256 against 365 ms, 1024 scenes
+// 368 against 452 ms; 2048: 454 against 470; 4096: 738 against 515).  SLHIP_SETTLE_IMPL=lockstep / persistent overrides.
+static bool use_persistent_settle(uint32_t n_scenes)
 {
     const char* e = getenv("SLHIP_SETTLE_IMPL");
-    return e && e[0] == 'p';
+    if (e && e[0] == 'p') return true;
+    if (e && e[0] == 'l') return false;
+    return n_scenes <= 1024u;
 }
 
 extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out)
@@ -2033,7 +2037,7 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         slhip::set_error("slhip_settle: at most %d bodies per scene", SLHIP_MAX_BODIES);
         return -1;
     }
-    if (!use_persistent_settle()) {
+    if (!use_persistent_settle(n_scenes)) {
         const int lhc = hint_lh_cap(params);
         if (n_scenes > 65535u) {
             slhip::set_error("slhip_settle: at most 65535 scenes per launch");

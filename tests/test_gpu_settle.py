@@ -247,10 +247,12 @@ def test_c2_soak_distinct_scenes(sl, oracle):
     assert_bodies_equal(gpu, ref)
 
 
-def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
+@pytest.mark.parametrize("impl", ["lockstep", "persistent"])
+def test_physics_kat_scenarios_match_the_oracle(sl, oracle, impl, monkeypatch):
     """The scenarios of tests/test_oracle_physics_kat.py (tilted gravity, impacts above / below the bounce threshold,
     free spin, clamped spin, cube columns, head-on collision) through slhip_settle: bit-exact with the oracle, so the
     known answers checked there on the CPU hold for the HIP path as well."""
+    monkeypatch.setenv("SLHIP_SETTLE_IMPL", impl)     # small batches default to the persistent kernel: both are held to the oracle
     import math
 
     import test_oracle_physics_kat as K
