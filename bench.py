@@ -33,8 +33,8 @@ TARGET_RING = 8     # render-target sets kept alive (chunks of --render-chunk sc
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16384,
                     help="scenes per GPU per step = one settle launch.  Scenes settle in very different times (60 .. 410 ms against a "
                          "145 ms mean) and 2048 are resident at once, so a launch ends with a tail of idle CUs; the more rounds of "

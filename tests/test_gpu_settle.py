@@ -294,9 +294,11 @@ def test_both_settle_implementations_are_bit_identical(sl, oracle, monkeypatch):
     monkeypatch.setenv("SLHIP_SETTLE_IMPL", "lockstep")
     gpu, ref = run_both(oracle, scs, frames=60)
     assert_bodies_equal(gpu, ref)
-    monkeypatch.setenv("SLHIP_SOLVE_SPW", "2")        # the lockstep solver with two cost-sorted scenes per wave
-    gpu2, ref2 = run_both(oracle, scs + [heap(sl, 310, 9, cube, bunny)], frames=60)   # odd number: the last wave holds one scene
+    gpu2, ref2 = run_both(oracle, scs + [heap(sl, 310, 9, cube, bunny)], frames=60)   # odd number: the last solver wave holds one scene
     assert_bodies_equal(gpu2, ref2)
+    monkeypatch.setenv("SLHIP_SOLVE_SPW", "1")        # the lockstep solver with one scene per wave instead of two
+    gpu1s, _ = run_both(oracle, scs, frames=60)
+    assert_bodies_equal(gpu1s, ref)
     monkeypatch.delenv("SLHIP_SOLVE_SPW")
     monkeypatch.setenv("SLHIP_SETTLE_IMPL", "persistent")
     gpu1, _ = run_both(oracle, scs, frames=60)
