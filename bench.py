@@ -308,8 +308,18 @@ def main():
             if os.environ.get("SLHIP_BENCH_ONE_DEVICE") or os.environ.get("SLHIP_BENCH_GATHER") == "torch":
                 pipe.gatherer = BatchGatherer(dist, world, depth=2)
             else:
-                comm = SlhipComm(rank, world, dist=dist)
-                pipe.gatherer = BatchGatherer(dist, world, depth=2, comm=comm)
+                try:
+                    comm = SlhipComm(rank, world, dist=dist)
+                    ok = 1
+                except Exception as e:      # e.g. librccl not loadable through the C-ABI on this box
+                    print("[bench] rank %d: slhip_comm_* unavailable (%s); exchanging through torch.distributed" % (rank, e), file=sys.stderr)
+                    comm, ok = None, 0
+                flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # all ranks take the same path
+                if int(flag.item()) == 0 and comm is not None:
+                    comm.close()
+                    comm = None
+                pipe.gatherer = BatchGatherer(dist, world, depth=2, comm=comm) if comm is not None else BatchGatherer(dist, world, depth=2)
 
     def scene_base(k):      # disjoint random streams per rank and step
         return (rank * 4096 + k) * args.batch
