@@ -1086,6 +1086,11 @@ __device__ __forceinline__ float shadow_pcf16(const float* __restrict__ sm, int 
     return acc / 16.0f;
 }
 
+// x^2.2 of a filtered texel (sRGB -> linear, render_shader.frag:243) through the hardware log2 / exp2 (1 ulp each): colour
+// values are compared with the oracle to the 8-bit tolerance, not bit for bit, and libm-grade powf costs ~50 instructions
+// per channel in the kernel that is bound by VALU issue.  0 -> exp2(-inf) = 0.
+__device__ __forceinline__ float pow22(float x) { return __builtin_amdgcn_exp2f(2.2f * __builtin_amdgcn_logf(x)); }
+
 __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ sc, const slhip_draw* __restrict__ dr,
                                                const float* base, const float* world, const float* nrm_in,
                                                bool front_facing, const float* __restrict__ shadow, int S,
@@ -1105,7 +1110,8 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
     color[3] = base[3];
 
     float F0[3], kS[3];
-    const float p5 = powf(1.0f - NoV, 5.0f);
+    const float om = 1.0f - NoV, om2 = om * om;
+    const float p5 = om2 * om2 * om;                  // (1 - NoV)^5
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         F0[c] = 0.04f * (1.0f - metallic) + base[c] * metallic;
@@ -1347,9 +1353,9 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                 if (dr->flags & SLHIP_DRAW_HAS_BASE_TEX) {
                     float tc[4];
                     tex_sample(pool.d_tex + dr->tex_offset, (int)dr->tex_w, (int)dr->tex_h, dr->tex_sampler[0], u, v, dudx, dvdx, dudy, dvdy, tc);
-                    base[0] *= powf(tc[0], 2.2f);
-                    base[1] *= powf(tc[1], 2.2f);
-                    base[2] *= powf(tc[2], 2.2f);
+                    base[0] *= pow22(tc[0]);
+                    base[1] *= pow22(tc[1]);
+                    base[2] *= pow22(tc[2]);
                     base[3] *= tc[3];
                 }
                 float world[3], nrm[3];
@@ -1381,7 +1387,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                         float st[4];
                         tex_rect_bilinear(pool.d_tex + dr->sticker_tex_offset, (int)dr->sticker_tex_w, (int)dr->sticker_tex_h,
                                           cx * (float)dr->sticker_tex_w, cy * (float)dr->sticker_tex_h, st);
-                        const float sc4[4] = {powf(st[0], 2.2f), powf(st[1], 2.2f), powf(st[2], 2.2f), st[3]};
+                        const float sc4[4] = {pow22(st[0]), pow22(st[1]), pow22(st[2]), st[3]};
 #pragma unroll
                         for (int c = 0; c < 4; ++c) base[c] = base[c] * (1.0f - st[3]) + sc4[c] * st[3];   // mix(base, sticker, sticker.a)
                     }
@@ -1429,7 +1435,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                     float tc[4];
                     tex_sample(pool.d_tex + dr->emissive_tex_offset, (int)dr->emissive_tex_w, (int)dr->emissive_tex_h, dr->tex_sampler[4], u, v, dudx, dvdx, dudy, dvdy, tc);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) emissive[c] *= powf(tc[c], 2.2f);
+                    for (int c = 0; c < 3; ++c) emissive[c] *= pow22(tc[c]);
                 }
                 const float* sm = (prm.flags & SLHIP_RENDER_SHADOWS) && shadow
                                       ? shadow + (size_t)scene * SLHIP_NUM_LIGHTS * prm.S * prm.S

@@ -76,9 +76,10 @@ def test_examples_ycb_call_sequence(slx):
     assert int(rgb[inst[..., 0].cpu().numpy() > 0].max()) == 0
     # settled: nothing below the table; like the reference's fixed-length simulation (scene.cpp:700-760) the call does not
     # promise rest -- about 4 % of the objects of such heaps still move faster than 0.2 m/s (a can rolling, a re-dropped
-    # object still falling), so: at most one of the six
+    # object still falling), and like the example the test does not seed the scene: at most two of the six (three or more
+    # happen once in ~800 runs)
     assert all(float(o.pose()[2, 3]) > 0.0 for o in scene.objects)
-    assert sum(float(o.linear_velocity.abs().max()) >= 0.2 for o in scene.objects) <= 1
+    assert sum(float(o.linear_velocity.abs().max()) >= 0.2 for o in scene.objects) <= 2
     # with a light the same frame shows the objects
     scene.choose_random_light_direction()
     lit = renderer.render(scene).rgb()[:, :, :3].cpu().numpy()
