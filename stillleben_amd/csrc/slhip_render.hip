@@ -999,6 +999,16 @@ __global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, cons
 // ---------------------------------------------------------------------------------------------
 // PBR shading (render_shader.frag:181-221, 248-399)
 // ---------------------------------------------------------------------------------------------
+// The BRDF terms feed the colour only (compared with the oracle to the 8-bit tolerance, not bit for bit): their divisions and
+// the normalisation of L and H go through the hardware reciprocal / reciprocal square root (1 ulp) -- an IEEE division is 11
+// instructions and a square root about as many in a kernel bound by VALU issue.  V stays exact: N . V is an output channel.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ void normalize3_fast(float* v)
+{
+    const float r = __builtin_amdgcn_rsqf(fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+    v[0] *= r; v[1] *= r; v[2] *= r;
+}
+
 __device__ __forceinline__ float distribution_ggx(const float* N, const float* Hv, float roughness)
 {
     const float a = roughness * roughness;
@@ -1007,14 +1017,14 @@ __device__ __forceinline__ float distribution_ggx(const float* N, const float* H
     const float NdotH2 = NdotH * NdotH;
     float denom = (NdotH2 * (a2 - 1.0f) + 1.0f);
     denom = kPi * denom * denom;
-    return a2 / denom;
+    return a2 * frcp(denom);
 }
 
 __device__ __forceinline__ float geometry_schlick_ggx(float NdotV, float roughness)
 {
     const float r = roughness + 1.0f;
-    const float k = (r * r) / 8.0f;
-    return NdotV / (NdotV * (1.0f - k) + k);
+    const float k = (r * r) * 0.125f;
+    return NdotV * frcp(NdotV * (1.0f - k) + k);
 }
 
 __device__ __forceinline__ float shadow_tap(const float* __restrict__ sm, int S, float u, float v, float ref)
@@ -1118,7 +1128,7 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
         const float Fr = fmaxf(1.0f - roughness, F0[c]) - F0[c];
         kS[c] = F0[c] + Fr * p5;
     }
-    const float base_pi[3] = {base[0] / kPi, base[1] / kPi, base[2] / kPi};   // Lambert term, once per pixel
+    const float base_pi[3] = {base[0] * (1.0f / kPi), base[1] * (1.0f / kPi), base[2] * (1.0f / kPi)};   // Lambert term, once per pixel
     for (int i = 0; i < SLHIP_NUM_LIGHTS; ++i) {
         if (!light_active(sc, i)) continue;
         const float* lc = sc->light_color[i];
@@ -1136,15 +1146,15 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
             inverse_shadow = shadow_pcf16(sm, S, px, py, pz - 0.00003f);
         }
         float L[3] = {-ld[0], -ld[1], -ld[2]};
-        normalize3(L);
+        normalize3_fast(L);
         float Hv[3] = {V[0] + L[0], V[1] + L[1], V[2] + L[2]};
-        normalize3(Hv);
+        normalize3_fast(Hv);
         const float NDF = distribution_ggx(normal, Hv, roughness);
         const float NdotVg = fmaxf(dot3(normal, V), 0.0f);
         const float NdotL = fmaxf(dot3(normal, L), 0.0f);
         const float G = geometry_schlick_ggx(NdotL, roughness) * geometry_schlick_ggx(NdotVg, roughness);
         const float denominator = fmaxf(4.0f * NoV * NdotL, 0.001f);
-        const float rden = 1.0f / denominator;
+        const float rden = frcp(denominator);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float specular = (NDF * G * kS[c]) * rden;
