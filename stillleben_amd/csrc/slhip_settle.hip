@@ -2075,7 +2075,7 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                 if (timed) (void)hipEventRecord(ev[0], stream);
                 k_w_begin<<<n_scenes, 64, BL.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, W, BL, drive_w);
                 if (timed) (void)hipEventRecord(ev[1], stream);
-                k_w_gjk_first<<<(work_grid + 3) / 4, 256, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride);
+                k_w_gjk_first<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride);
                 k_w_gjk_rest<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride);
                 if (timed) (void)hipEventRecord(ev[2], stream);
                 k_w_gjk_tilt<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, list_stride);
