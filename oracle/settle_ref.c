@@ -141,6 +141,24 @@ typedef struct {
 #define MAX_CONTACTS_PER_HP 4
 #define PLANE_SLOTS 4
 
+/* Persistent contact manifold of one hull pair (PhysX keeps one per shape pair, PCM [ext]): the contact points in the two
+   bodies' object frames, the normal in B's frame, and the impulses the solver ended the step with -- the next step refreshes
+   the points in the new poses, adds the new closest-point pair and starts its sweeps from those impulses. */
+typedef struct {
+    int stamp;             /* step that wrote it (1-based); valid for the step after */
+    int count;
+    v3 nb;                 /* contact normal in B's object frame */
+    v3 la[4], lb[4];       /* contact points in A's / B's object frame */
+    float ln[4];           /* accumulated normal impulses at the end of the step */
+} pmanifold;
+
+/* ... and of one body against the table: the contact points are hull vertices, matched by their number */
+typedef struct {
+    int stamp, count;
+    int id[4];
+    float ln[4];
+} pplane;
+
 typedef struct {
     /* hull pair list */
     int n_hp;
@@ -159,6 +177,10 @@ typedef struct {
        ordinals, cleared when a settle call starts.  Scenes with more than
        SLHIP_PAIR_CACHE_MAX_HULLS hulls run without it (cache == NULL). */
     struct gjk_seed_s* cache;
+    pmanifold* pm;                       /* [n_hulls][n_hulls], beside the cache */
+    pmanifold* hp_pm[SLHIP_MAX_HULL_PAIRS];
+    pplane pp[SLHIP_MAX_BODIES];
+    int step;                            /* 1-based step number within the settle call */
     int n_hulls;
     int body_lh[SLHIP_MAX_BODIES + 1]; /* first hull ordinal of every body */
 } scene_ws;
@@ -438,6 +460,100 @@ static void overlap_fallback(const shape* A, const shape* B, v3 ca, v3 cb, v3* n
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* penetration of two OVERLAPPING hulls: Minkowski portal refinement (Snethen, "XenoCollide", Game Programming Gems 7;       */
+/* the published algorithm, fixed-size state like GJK's simplex).  PhysX answers the same question with GJK + EPA [ext].     */
+/* M = A - B contains the origin.  From an interior point v0 (difference of the hulls' sphere centres) the ray through the    */
+/* origin leaves M through a boundary triangle -- the portal (v1 v2 v3), refined by support points along its normal until it   */
+/* lies within MPR_TOL of the boundary.  The point of the portal closest to the origin, pt = pa - pb, gives the contact:      */
+/* normal n = -pt / |pt| (from B to A), separation -|pt|, witnesses pa on A and pb on B by the portal's barycentric weights.   */
+/* Returns 1 on success, 0 when no portal is found (the hulls only touch): the caller falls back to overlap_fallback.         */
+/* ------------------------------------------------------------------------------------------ */
+#define MPR_TOL 1.0e-4f
+#define MPR_MAX_DISCOVER 16
+#define MPR_MAX_REFINE 24
+static inline sv mpr_support(const shape* A, const shape* B, v3 d)
+{
+    sv w;
+    int ia, ib;
+    w.a = support_i(A, d, &ia);
+    w.b = support_i(B, neg(d), &ib);
+    w.idx = ia | (ib << 16);
+    w.w = sub(w.a, w.b);
+    return w;
+}
+static inline v3 normalized(v3 a) { return scale(a, 1.0f / sqrtf(dot(a, a))); }
+
+static int mpr_penetration(const shape* A, const shape* B, v3 ca, v3 cb, v3* n, float* sep, v3* pa, v3* pb)
+{
+    v3 v0 = sub(ca, cb);
+    if (dot(v0, v0) < 1.0e-12f) v0 = V(1.0e-5f, 0.0f, 0.0f);
+    v3 dir = normalized(neg(v0));
+    sv v1 = mpr_support(A, B, dir);
+    if (!(dot(v1.w, dir) > 0.0f)) return 0;
+    dir = cross(v0, v1.w);
+    if (dot(dir, dir) < 1.0e-20f) {
+        /* the origin lies on the ray through v1: the boundary point IS v1 */
+        float l = sqrtf(dot(v1.w, v1.w));
+        if (l < 1.0e-9f) return 0;
+        *n = scale(v1.w, -1.0f / l); *sep = -l; *pa = v1.a; *pb = v1.b;
+        return 1;
+    }
+    dir = normalized(dir);
+    sv v2 = mpr_support(A, B, dir);
+    if (!(dot(v2.w, dir) > 0.0f)) return 0;
+    dir = cross(sub(v1.w, v0), sub(v2.w, v0));
+    if (dot(dir, dir) < 1.0e-24f) return 0;
+    dir = normalized(dir);
+    if (dot(dir, v0) > 0.0f) { sv t = v1; v1 = v2; v2 = t; dir = neg(dir); }
+    sv v3_;
+    int found = 0;
+    for (int it = 0; it < MPR_MAX_DISCOVER; ++it) {
+        v3_ = mpr_support(A, B, dir);
+        if (!(dot(v3_.w, dir) > 0.0f)) return 0;
+        int cont = 0;
+        if (dot(cross(v1.w, v3_.w), v0) < 0.0f) { v2 = v3_; cont = 1; }
+        else if (dot(cross(v3_.w, v2.w), v0) < 0.0f) { v1 = v3_; cont = 1; }
+        if (!cont) { found = 1; break; }
+        dir = cross(sub(v1.w, v0), sub(v2.w, v0));
+        if (dot(dir, dir) < 1.0e-24f) return 0;
+        dir = normalized(dir);
+    }
+    if (!found) return 0;
+    for (int it = 0; it < MPR_MAX_REFINE; ++it) {
+        dir = cross(sub(v2.w, v1.w), sub(v3_.w, v1.w));
+        if (dot(dir, dir) < 1.0e-24f) break;
+        dir = normalized(dir);
+        sv v4 = mpr_support(A, B, dir);
+        float d4 = dot(v4.w, dir);
+        float m = d4 - dot(v1.w, dir);
+        float m2 = d4 - dot(v2.w, dir), m3 = d4 - dot(v3_.w, dir);
+        if (m2 < m) m = m2;
+        if (m3 < m) m = m3;
+        if (m <= MPR_TOL) break;
+        v3 x = cross(v4.w, v0);
+        if (dot(v1.w, x) > 0.0f) {
+            if (dot(v2.w, x) > 0.0f) v1 = v4; else v3_ = v4;
+        } else {
+            if (dot(v3_.w, x) > 0.0f) v2 = v4; else v1 = v4;
+        }
+    }
+    float l[3];
+    closest_triangle(v1.w, v2.w, v3_.w, l);
+    v3 pt = comb3(v1.w, v2.w, v3_.w, l);
+    float d = sqrtf(dot(pt, pt));
+    *pa = comb3(v1.a, v2.a, v3_.a, l);
+    *pb = comb3(v1.b, v2.b, v3_.b, l);
+    if (d > 1.0e-7f) *n = scale(pt, -1.0f / d);
+    else {
+        v3 pn = cross(sub(v2.w, v1.w), sub(v3_.w, v1.w));
+        if (dot(pn, pn) < 1.0e-24f) return 0;
+        *n = neg(normalized(pn));
+    }
+    *sep = -d;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* contact generation                                                                          */
 /* ------------------------------------------------------------------------------------------ */
 static void make_shape(const wbody* wb, const slhip_hull* h, const float* hull_verts, shape* s)
@@ -497,10 +613,80 @@ static void fill_contact(contact* c, int a, int b, const wbody* wa, const wbody*
     c->valid = 1;
 }
 
-/* hull pair -> up to 4 contacts written to out[0..3]; returns min separation (or +inf) */
+/* Contact persistence (the part of PhysX's pipeline that lets piles come to rest [ext]: persistent manifolds, impulses carried
+   from step to step).  Constants of this restatement: */
+#define WARM_START 0.8f          /* share of the previous step's normal impulses the sweeps start from (friction rows start at 0) */
+#define DRIFT_OFFSETS 2.0f       /* a persistent point breaks when its two witnesses drift apart laterally by more than this many
+                                    contact offsets ... */
+#define NORMAL_COS 0.9848f       /* ... and all of a manifold's points when the normal turned by more than 10 degrees */
+#define PLANE_DEPTH_WEIGHT 5.0f  /* table contacts: a metre of extra separation costs this many metres of lateral reach (the far
+                                    edge of a slightly tilted box has to stay in the manifold as a speculative contact, or the
+                                    push-out of the near edge rocks the box for ever) */
+
+/* the four tilted runs of the perturbation manifold around normal n: candidates appended to (cp, cq, cs) */
+static int tilt_candidates(const wbody* wa, const wbody* wb, const slhip_hull* ha, const slhip_hull* hb, const shape* A,
+                           const shape* B, v3 ca, v3 cb, v3 n, float margin, const slhip_settle_params* prm,
+                           const gjk_seed* seed, v3* cp, v3* cq, float* cs, int nc)
+{
+    int tilt_a = ha->sphere[3] <= hb->sphere[3];
+    float radius = tilt_a ? ha->sphere[3] : hb->sphere[3];
+    float ang = 2.0f * prm->contact_offset / radius; /* lifts the far rim by ~ the contact band */
+    if (ang > 0.2f) ang = 0.2f;
+    float lift = radius * ang;
+    float sh = 0.5f * ang;               /* sin(ang/2) ~ ang/2 */
+    float ch = sqrtf(1.0f - sh * sh);
+    v3 t1, t2;
+    tangents(n, &t1, &t2);
+    const wbody* wt = tilt_a ? wa : wb;
+    for (int k = 0; k < 4; ++k) {
+        v3 ax = (k == 0) ? t1 : (k == 1) ? t2 : (k == 2) ? neg(t1) : neg(t2);
+        quat dq = {ax.x * sh, ax.y * sh, ax.z * sh, ch};
+        quat q2 = quat_normalize(quat_mul(dq, wt->q));
+        shape T = tilt_a ? *A : *B;
+        quat_to_m3(q2, &T.R);
+        /* rotate about the shape's bounding-sphere centre so that the tilt is local */
+        v3 cl = tilt_a ? V(ha->sphere[0], ha->sphere[1], ha->sphere[2]) : V(hb->sphere[0], hb->sphere[1], hb->sphere[2]);
+        v3 cw = tilt_a ? ca : cb;
+        /* ... and back the tilted shape off along the normal by the rim lift so that the tilt
+           cannot create an overlap; separations are re-measured in the untilted pose below */
+        cw = madd(cw, n, tilt_a ? lift : -lift);
+        T.t = sub(cw, m3_mul(&T.R, cl));
+        v3 qa, qb;
+        float d2;
+        int ok = tilt_a ? gjk_distance_seeded(&T, B, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, NULL, GJK_TILT_MAX_ITER)
+                        : gjk_distance_seeded(A, &T, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, NULL, GJK_TILT_MAX_ITER);
+        if (g_stats) g_stats[1088 + (g_last_gjk_iters > 7 ? 7 : g_last_gjk_iters)]++; /* [1088, 1096): iterations of the tilt runs */
+        if (ok != 1) continue;
+        /* map the witness on the tilted shape back to the untilted pose */
+        if (tilt_a) {
+            v3 loc = m3_tmul(&T.R, sub(qa, T.t));
+            qa = add(m3_mul(&A->R, loc), A->t);
+        } else {
+            v3 loc = m3_tmul(&T.R, sub(qb, T.t));
+            qb = add(m3_mul(&B->R, loc), B->t);
+        }
+        float s = dot(sub(qa, qb), n);
+        if (s > margin) continue;
+        /* lateral offset between the two witnesses must be small, else it is not a contact */
+        v3 lat = sub(sub(qa, qb), scale(n, s));
+        if (dot(lat, lat) > 4.0f * margin * margin) continue;
+        int dup = 0;
+        for (int j = 0; j < nc; ++j) {
+            v3 dd = sub(cp[j], qa);
+            if (dot(dd, dd) < 2.5e-3f * radius * radius) dup = 1;
+        }
+        if (dup) continue;
+        cp[nc] = qa; cq[nc] = qb; cs[nc] = s; ++nc;
+    }
+    return nc;
+}
+
+/* hull pair -> up to 4 contacts written to out[0..3]; returns min separation (or +inf).
+   `pm`: the pair's persistent manifold (NULL: none is kept -- every step builds its manifold from scratch). */
 static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int ia, int ib,
                                 const slhip_hull* ha, const slhip_hull* hb, const float* hull_verts,
-                                const slhip_settle_params* prm, float margin, contact* out, gjk_seed* cached)
+                                const slhip_settle_params* prm, float margin, contact* out, gjk_seed* cached,
+                                pmanifold* pm, int step)
 {
     for (int i = 0; i < MAX_CONTACTS_PER_HP; ++i) out[i].valid = 0;
     const wbody* wa = &wbs[ia];
@@ -517,75 +703,64 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     float mu_d = 0.5f * (bodies[ia].mu_d + bodies[ib].mu_d);
     float e = 0.5f * (bodies[ia].restitution + bodies[ib].restitution);
     gjk_seed seed;
+    pmanifold prev;
+    prev.count = 0;
+    if (pm && pm->stamp == step - 1) prev = *pm;
+    if (pm) { pm->stamp = step; pm->count = 0; }
     int code = gjk_distance_seeded(&A, &B, sub(ca, cb), margin, &pa, &pb, &dist, cached, &seed, GJK_MAX_ITER);
     if (g_stats) g_stats[1024 + (g_last_gjk_iters > 63 ? 63 : g_last_gjk_iters)]++; /* [1024, 1088): iterations of the main runs */
     if (cached && code != 0) *cached = seed; /* overlap keeps the previous entry */
     if (code == 2) return 3.0e38f;
-    if (code == 0) {
-        float sep;
-        overlap_fallback(&A, &B, ca, cb, &n, &sep, &pa, &pb);
-        if (sep > 0.0f) sep = 0.0f;
-        fill_contact(&out[0], ia, ib, wa, wb, pa, pb, n, sep, rest, mu_s, mu_d, e);
-        return sep;
-    }
-    if (dist > margin) return 3.0e38f;
-    n = scale(sub(pa, pb), 1.0f / dist);
+    if (code == 1 && dist > margin) return 3.0e38f;
+    const float radius = ha->sphere[3] <= hb->sphere[3] ? ha->sphere[3] : hb->sphere[3];
+    const float dup2 = 2.5e-3f * radius * radius;
 
     v3 cp[5], cq[5];
-    float cs[5];
+    float cs[5], cw[5];
     int nc = 0;
-    cp[0] = pa; cq[0] = pb; cs[0] = dist; nc = 1;
-
-    /* perturbation manifold: tilt the smaller shape about 4 axes perpendicular to n */
-    int tilt_a = ha->sphere[3] <= hb->sphere[3];
-    float radius = tilt_a ? ha->sphere[3] : hb->sphere[3];
-    float ang = 2.0f * prm->contact_offset / radius; /* lifts the far rim by ~ the contact band */
-    if (ang > 0.2f) ang = 0.2f;
-    float lift = radius * ang;
-    float sh = 0.5f * ang;               /* sin(ang/2) ~ ang/2 */
-    float ch = sqrtf(1.0f - sh * sh);
-    v3 t1, t2;
-    tangents(n, &t1, &t2);
-    const wbody* wt = tilt_a ? wa : wb;
-    for (int k = 0; k < 4; ++k) {
-        v3 ax = (k == 0) ? t1 : (k == 1) ? t2 : (k == 2) ? neg(t1) : neg(t2);
-        quat dq = {ax.x * sh, ax.y * sh, ax.z * sh, ch};
-        quat q2 = quat_normalize(quat_mul(dq, wt->q));
-        shape T = tilt_a ? A : B;
-        quat_to_m3(q2, &T.R);
-        /* rotate about the shape's bounding-sphere centre so that the tilt is local */
-        v3 cl = tilt_a ? V(ha->sphere[0], ha->sphere[1], ha->sphere[2]) : V(hb->sphere[0], hb->sphere[1], hb->sphere[2]);
-        v3 cw = tilt_a ? ca : cb;
-        /* ... and back the tilted shape off along the normal by the rim lift so that the tilt
-           cannot create an overlap; separations are re-measured in the untilted pose below */
-        cw = madd(cw, n, tilt_a ? lift : -lift);
-        T.t = sub(cw, m3_mul(&T.R, cl));
-        v3 qa, qb;
-        float d2;
-        int ok = tilt_a ? gjk_distance_seeded(&T, &B, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, &seed, NULL, GJK_TILT_MAX_ITER)
-                        : gjk_distance_seeded(&A, &T, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, &seed, NULL, GJK_TILT_MAX_ITER);
-        if (g_stats) g_stats[1088 + (g_last_gjk_iters > 7 ? 7 : g_last_gjk_iters)]++; /* [1088, 1096): iterations of the tilt runs */
-        if (ok != 1) continue;
-        /* map the witness on the tilted shape back to the untilted pose */
-        if (tilt_a) {
-            v3 loc = m3_tmul(&T.R, sub(qa, T.t));
-            qa = add(m3_mul(&A.R, loc), A.t);
-        } else {
-            v3 loc = m3_tmul(&T.R, sub(qb, T.t));
-            qb = add(m3_mul(&B.R, loc), B.t);
+    float sep_new;
+    if (code == 0) {
+        /* overlap: penetration depth, normal and witnesses by portal refinement (7 fixed axes if it finds no portal) */
+        if (!mpr_penetration(&A, &B, ca, cb, &n, &sep_new, &pa, &pb)) {
+            overlap_fallback(&A, &B, ca, cb, &n, &sep_new, &pa, &pb);
+            if (sep_new > 0.0f) sep_new = 0.0f;
         }
-        float s = dot(sub(qa, qb), n);
-        if (s > margin) continue;
-        /* lateral offset between the two witnesses must be small, else it is not a contact */
-        v3 lat = sub(sub(qa, qb), scale(n, s));
-        if (dot(lat, lat) > 4.0f * margin * margin) continue;
-        int dup = 0;
-        for (int j = 0; j < nc; ++j) {
-            v3 dd = sub(cp[j], qa);
-            if (dot(dd, dd) < 2.5e-3f * radius * radius) dup = 1;
+    } else {
+        n = scale(sub(pa, pb), 1.0f / dist);
+        sep_new = dist;
+    }
+    if (prev.count == 0 && code == 1) {
+        /* a NEW contact pair: the closest-point pair + four tilted runs give its first manifold */
+        cp[0] = pa; cq[0] = pb; cs[0] = dist;
+        nc = tilt_candidates(wa, wb, ha, hb, &A, &B, ca, cb, n, margin, prm, &seed, cp, cq, cs, 1);
+        for (int j = 0; j < nc; ++j) cw[j] = 0.0f;
+    } else {
+        /* refresh the previous step's points in the new poses: separations along the new normal; a point whose witnesses
+           drifted apart laterally, or that left the contact band, is dropped */
+        if (prev.count > 0) {
+            v3 npw = m3_mul(&wb->R, prev.nb);
+            const float lim = DRIFT_OFFSETS * prm->contact_offset;
+            if (dot(n, npw) >= NORMAL_COS)
+                for (int i = 0; i < prev.count; ++i) {
+                    v3 qa = add(m3_mul(&wa->R, prev.la[i]), wa->t);
+                    v3 qb = add(m3_mul(&wb->R, prev.lb[i]), wb->t);
+                    v3 d = sub(qa, qb);
+                    float sp = dot(d, n);
+                    if (sp > margin) continue;
+                    v3 lat = sub(d, scale(n, sp));
+                    if (dot(lat, lat) > lim * lim) continue;
+                    cp[nc] = qa; cq[nc] = qb; cs[nc] = sp; cw[nc] = prev.ln[i]; ++nc;
+                }
         }
-        if (dup) continue;
-        cp[nc] = qa; cq[nc] = qb; cs[nc] = s; ++nc;
+        /* the new closest-point (or deepest-point) pair: replaces the old point it coincides with (which keeps its impulse),
+           else joins as a fifth candidate */
+        int dup = -1;
+        for (int j = 0; j < nc && dup < 0; ++j) {
+            v3 dd = sub(cp[j], pa);
+            if (dot(dd, dd) < dup2) dup = j;
+        }
+        if (dup >= 0) { cp[dup] = pa; cq[dup] = pb; cs[dup] = sep_new; }
+        else { cp[nc] = pa; cq[nc] = pb; cs[nc] = sep_new; cw[nc] = 0.0f; ++nc; }
     }
     int keep[4];
     int nk = reduce4(nc, cp, cs, n, keep);
@@ -593,7 +768,17 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     for (int i = 0; i < nk; ++i) {
         int j = keep[i];
         fill_contact(&out[i], ia, ib, wa, wb, cp[j], cq[j], n, cs[j], rest, mu_s, mu_d, e);
+        out[i].ln = WARM_START * cw[j];
         if (cs[j] < mins) mins = cs[j];
+        if (pm) {
+            pm->la[i] = m3_tmul(&wa->R, sub(cp[j], wa->t));
+            pm->lb[i] = m3_tmul(&wb->R, sub(cq[j], wb->t));
+            pm->ln[i] = 0.0f;
+        }
+    }
+    if (pm) {
+        pm->count = nk;
+        pm->nb = m3_tmul(&wb->R, n);
     }
     return mins;
 }
@@ -617,7 +802,7 @@ static int plane_vertex(const plane_it* it, uint32_t h, uint32_t i, v3* p, float
 
 static void plane_contacts(const slhip_body* bodies, const wbody* wbs, int ia, const slhip_hull* hulls,
                            const float* hull_verts, const slhip_settle_params* prm, float plane_z,
-                           float margin, contact* out)
+                           float margin, contact* out, pplane* pp, int step)
 {
     for (int i = 0; i < PLANE_SLOTS; ++i) out[i].valid = 0;
     const slhip_body* b = &bodies[ia];
@@ -625,11 +810,17 @@ static void plane_contacts(const slhip_body* bodies, const wbody* wbs, int ia, c
     plane_it it = {w, b, hulls, hull_verts, plane_z, margin};
     /* pass 0: deepest */
     int have0 = 0; v3 p0 = V(0, 0, 0); float s0 = 0.0f;
+    int id0 = 0, id1 = 0, id2 = 0, id3 = 0;
+    pplane prev;
+    prev.count = 0;
+    if (pp && pp->stamp == step - 1) prev = *pp;
+    if (pp) { pp->stamp = step; pp->count = 0; }
+#define PLANE_ID(h, i) ((int)(((h) - b->hull_begin) << 8 | (i)))
     for (uint32_t h = b->hull_begin; h < b->hull_end; ++h)
         for (uint32_t i = 0; i < hulls[h].vtx_count; ++i) {
             v3 p; float d;
             if (!plane_vertex(&it, h, i, &p, &d)) continue;
-            if (!have0 || d < s0) { have0 = 1; p0 = p; s0 = d; }
+            if (!have0 || d < s0) { have0 = 1; p0 = p; s0 = d; id0 = PLANE_ID(h, i); }
         }
     if (!have0) return;
     /* pass 1: farthest (depth-penalised) */
@@ -639,14 +830,14 @@ static void plane_contacts(const slhip_body* bodies, const wbody* wbs, int ia, c
             v3 p; float d;
             if (!plane_vertex(&it, h, i, &p, &d)) continue;
             v3 dd = sub(p, p0);
-            float score = sqrtf(dot(dd, dd)) - DEPTH_WEIGHT * (d - s0);
-            if (score > 0.0f && (!have1 || score > best)) { have1 = 1; best = score; p1 = p; s1 = d; }
+            float score = sqrtf(dot(dd, dd)) - PLANE_DEPTH_WEIGHT * (d - s0);
+            if (score > 0.0f && (!have1 || score > best)) { have1 = 1; best = score; p1 = p; s1 = d; id1 = PLANE_ID(h, i); }
         }
     v3 n = V(0, 0, 1);
-    v3 sel[4]; float ss[4]; int nk = 0;
-    sel[nk] = p0; ss[nk++] = s0;
+    v3 sel[4]; float ss[4]; int ids[4]; int nk = 0;
+    sel[nk] = p0; ids[nk] = id0; ss[nk++] = s0;
     if (have1) {
-        sel[nk] = p1; ss[nk++] = s1;
+        sel[nk] = p1; ids[nk] = id1; ss[nk++] = s1;
         /* pass 2+3: area extremes */
         v3 e = sub(p1, p0);
         float el = sqrtf(dot(e, e));
@@ -656,20 +847,26 @@ static void plane_contacts(const slhip_body* bodies, const wbody* wbs, int ia, c
                 v3 p; float d;
                 if (!plane_vertex(&it, h, i, &p, &d)) continue;
                 float a = dot(cross(e, sub(p, p0)), n);
-                float pen = DEPTH_WEIGHT * (d - s0) * el;
-                if (a - pen > mx) { mx = a - pen; have2 = 1; p2 = p; s2 = d; }
-                if (a + pen < mn) { mn = a + pen; have3 = 1; p3 = p; s3 = d; }
+                float pen = PLANE_DEPTH_WEIGHT * (d - s0) * el;
+                if (a - pen > mx) { mx = a - pen; have2 = 1; p2 = p; s2 = d; id2 = PLANE_ID(h, i); }
+                if (a + pen < mn) { mn = a + pen; have3 = 1; p3 = p; s3 = d; id3 = PLANE_ID(h, i); }
             }
-        if (have2) { sel[nk] = p2; ss[nk++] = s2; }
-        if (have3) { sel[nk] = p3; ss[nk++] = s3; }
+        if (have2) { sel[nk] = p2; ids[nk] = id2; ss[nk++] = s2; }
+        if (have3) { sel[nk] = p3; ids[nk] = id3; ss[nk++] = s3; }
     }
+#undef PLANE_ID
     float mu_s = 0.5f * (b->mu_s + prm->plane_mu_s);
     float mu_d = 0.5f * (b->mu_d + prm->plane_mu_d);
     float e_ = 0.5f * (b->restitution + prm->plane_restitution);
     for (int i = 0; i < nk; ++i) {
         v3 pb = V(sel[i].x, sel[i].y, plane_z);
         fill_contact(&out[i], ia, -1, w, NULL, sel[i], pb, n, ss[i], prm->rest_offset, mu_s, mu_d, e_);
+        /* the vertex was a contact in the last step: its impulse is where the sweeps start */
+        for (int j = 0; j < prev.count; ++j)
+            if (prev.id[j] == ids[i]) out[i].ln = WARM_START * prev.ln[j];
+        if (pp) { pp->id[i] = ids[i]; pp->ln[i] = 0.0f; }
     }
+    if (pp) pp->count = nk;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -729,7 +926,9 @@ static void solve_normal(contact* c, wbody* wbs, const slhip_settle_params* prm,
     float err = c->sep - c->rest;
     float target; /* required vn >= target */
     if (err > 0.0f) target = -err * inv_dt;                 /* speculative: may close the gap */
-    else target = biased ? -0.8f * err * inv_dt : 0.0f;     /* push out (position iterations only) */
+    else {                                                  /* push out (position iterations only) */
+        target = biased ? -0.8f * err * inv_dt : 0.0f;
+    }
     if (c->vn0 < -prm->bounce_threshold && c->e > 0.0f) {
         float bounce = -c->e * c->vn0;
         if (bounce > target) target = bounce;
@@ -1018,7 +1217,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
             float margin = prm->contact_offset + vz;
             if (ci.z - bodies[i].bsphere[3] - sc->plane_z > margin) continue;
             contact* out = &ws->c[plane_base + i * PLANE_SLOTS];
-            plane_contacts(bodies, wb, i, hulls, hull_verts, prm, sc->plane_z, margin, out);
+            plane_contacts(bodies, wb, i, hulls, hull_verts, prm, sc->plane_z, margin, out, &ws->pp[i], ws->step);
             int g = ws->n_groups++;
             ws->g_a[g] = i; ws->g_b[g] = -1;
             ws->g_begin[g] = plane_base + i * PLANE_SLOTS;
@@ -1066,13 +1265,15 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         v3 dv = sub(wb[i].v, wb[j].v);
         float margin = 2.0f * prm->contact_offset + sqrtf(dot(dv, dv)) * dt;
         gjk_seed* cached = NULL;
+        ws->hp_pm[k] = NULL;
         if (ws->cache) {
             int la = ws->body_lh[i] + (ws->hp_ha[k] - (int)bodies[i].hull_begin);
             int lb = ws->body_lh[j] + (ws->hp_hb[k] - (int)bodies[j].hull_begin);
             cached = &ws->cache[(size_t)la * ws->n_hulls + lb];
+            ws->hp_pm[k] = &ws->pm[(size_t)la * ws->n_hulls + lb];
         }
         float s = hull_pair_contacts(bodies, wb, i, j, &hulls[ws->hp_ha[k]], &hulls[ws->hp_hb[k]], hull_verts, prm,
-                                     margin, &ws->c[k * MAX_CONTACTS_PER_HP], cached);
+                                     margin, &ws->c[k * MAX_CONTACTS_PER_HP], cached, ws->hp_pm[k], ws->step);
         /* min separation per object (scene.cpp:73-116; plane contacts are ignored there) */
         if (s < bodies[i].separation) bodies[i].separation = s;
         if (s < bodies[j].separation) bodies[j].separation = s;
@@ -1117,6 +1318,17 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
     /* (g) colouring, (h) position iterations (biased) */
     color_groups(ws, nb);
     if (g_stats) step_stats(ws);
+    /* warm start: the normal impulses carried over from the previous step (fill: WARM_START of what the manifold's points ended
+       with), applied to the bodies in the sweeps' order before the first sweep; the rows then accumulate on top of them */
+    for (int col = 0; col < ws->n_colors; ++col)
+        for (int g = 0; g < ws->n_groups; ++g) {
+            if (ws->g_color[g] != col) continue;
+            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) {
+                contact* c = &ws->c[i];
+                if (!c->valid) continue;
+                apply_impulse(&wb[c->a], c->b >= 0 ? &wb[c->b] : NULL, c, scale(c->n, c->ln));
+            }
+        }
     for (uint32_t it = 0; it < prm->pos_iters; ++it) solve_iteration(ws, bodies, nb, prm, 1);
 
     /* (i) integrate poses with the biased velocities */
@@ -1139,14 +1351,37 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
     /* (j) velocity iterations (unbiased): what is left in v,w is carried to the next step */
     for (uint32_t it = 0; it < prm->vel_iters; ++it) solve_iteration(ws, bodies, nb, prm, 0);
 
+    /* the impulses the manifolds carry into the next step */
+    for (int k = 0; k < ws->n_hp; ++k) {
+        pmanifold* pm = ws->hp_pm[k];
+        if (!pm) continue;
+        const contact* c = &ws->c[k * MAX_CONTACTS_PER_HP];
+        for (int i = 0; i < pm->count; ++i) pm->ln[i] = c[i].valid ? c[i].ln : 0.0f;
+    }
+    if (sc->has_plane)
+        for (int i = 0; i < nb; ++i) {
+            pplane* pp = &ws->pp[i];
+            if (pp->stamp != ws->step) continue;
+            const contact* c = &ws->c[plane_base + i * PLANE_SLOTS];
+            for (int k = 0; k < pp->count; ++k) pp->ln[k] = c[k].valid ? c[k].ln : 0.0f;
+        }
+    ws->step++;
+
     /* (k) store, sleep bookkeeping */
     for (int i = 0; i < nb; ++i) {
         if (!wb[i].dynamic) continue;
         quat_to_m3(wb[i].q, &wb[i].R);
         wb[i].t = sub(wb[i].x, m3_mul(&wb[i].R, V(bodies[i].com[0], bodies[i].com[1], bodies[i].com[2])));
-        /* mass-normalised kinetic energy; the angular part uses the bounding radius as lever */
-        float r = bodies[i].bsphere[3];
-        float en = 0.5f * (dot(wb[i].v, wb[i].v) + r * r * dot(wb[i].w, wb[i].w));
+        /* mass-normalised kinetic energy [ext]: 0.5 (v.v + w.(I w) / m), I = inverse of inv_inertia (object axes, by cofactors) */
+        const float* L = bodies[i].inv_inertia;
+        v3 wl = m3_tmul(&wb[i].R, wb[i].w);
+        float c00 = L[5] * L[10] - L[6] * L[9], c01 = L[6] * L[8] - L[4] * L[10], c02 = L[4] * L[9] - L[5] * L[8];
+        float c11 = L[0] * L[10] - L[2] * L[8], c12 = L[1] * L[8] - L[0] * L[9], c22 = L[0] * L[5] - L[1] * L[4];
+        float det = fmaf(L[2], c02, fmaf(L[1], c01, L[0] * c00));
+        v3 iw = V(fmaf(c02, wl.z, fmaf(c01, wl.y, c00 * wl.x)), fmaf(c12, wl.z, fmaf(c11, wl.y, c01 * wl.x)),
+                  fmaf(c22, wl.z, fmaf(c12, wl.y, c02 * wl.x)));
+        float ang = det != 0.0f ? dot(wl, iw) / det * wb[i].inv_mass : 0.0f;
+        float en = 0.5f * (dot(wb[i].v, wb[i].v) + ang);
         if (en >= prm->sleep_threshold || (bodies[i].drive_flags & 1u)) bodies[i].wake_counter = prm->wake_time;
         else {
             bodies[i].wake_counter -= dt;
@@ -1205,9 +1440,13 @@ int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body
         for (int i = 0; i < nb; ++i) { ws->body_lh[i] = ws->n_hulls; ws->n_hulls += (int)(b[i].hull_end - b[i].hull_begin); }
         ws->body_lh[nb] = ws->n_hulls;
         ws->cache = NULL;
+        ws->pm = NULL;
+        ws->step = 1;
+        memset(ws->pp, 0, sizeof(ws->pp));
         if (ws->n_hulls > 0 && ws->n_hulls <= SLHIP_PAIR_CACHE_MAX_HULLS) {
             ws->cache = (gjk_seed*)calloc((size_t)ws->n_hulls * ws->n_hulls, sizeof(gjk_seed));
-            if (!ws->cache) { free(ws); return -1; }
+            ws->pm = (pmanifold*)calloc((size_t)ws->n_hulls * ws->n_hulls, sizeof(pmanifold));
+            if (!ws->cache || !ws->pm) { free(ws); return -1; }
         }
         for (uint32_t f = 0; f < prm->frames; ++f) {
             for (uint32_t ss = 0; ss < prm->substeps; ++ss) step_scene(sc, bodies, hulls, hull_verts, prm, ws);
@@ -1217,7 +1456,8 @@ int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body
                 if (b[i].flags & SLHIP_BODY_STATIC) continue;
                 if (b[i].pose[11] < prm->redrop_z) { redrop(sc, b, i, prm); moved = 1; }
                 else if (b[i].separation < prm->stuck_separation) {
-                    if (++b[i].stuck_counter > prm->stuck_frames) { redrop(sc, b, i, prm); moved = 1; }
+                    if (++b[i].stuck_counter > prm->stuck_frames) {
+                        redrop(sc, b, i, prm); moved = 1; }
                 } else if (b[i].stuck_counter > 0) b[i].stuck_counter--;
             }
             if (g_trace) {
@@ -1235,7 +1475,9 @@ int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body
             }
         }
         free(ws->cache);
+        free(ws->pm);
         ws->cache = NULL;
+        ws->pm = NULL;
     }
     free(ws);
     return 0;
@@ -1307,7 +1549,7 @@ int slref_debug_contacts(const slhip_settle_scene* sc, const slhip_body* bodies_
                 for (uint32_t hb = bodies[j].hull_begin; hb < bodies[j].hull_end; ++hb) {
                     contact c[MAX_CONTACTS_PER_HP];
                     hull_pair_contacts(bodies, ws->wb, i, j, &hulls[ha], &hulls[hb], hull_verts, prm,
-                                       2.0f * prm->contact_offset, c, NULL);
+                                       2.0f * prm->contact_offset, c, NULL, NULL, 0);
                     for (int k = 0; k < MAX_CONTACTS_PER_HP; ++k) {
                         if (!c[k].valid || rows >= max_rows) continue;
                         float* o = out + 12 * rows++;
@@ -1320,7 +1562,7 @@ int slref_debug_contacts(const slhip_settle_scene* sc, const slhip_body* bodies_
     if (sc->has_plane)
         for (int i = 0; i < nb; ++i) {
             contact c[PLANE_SLOTS];
-            plane_contacts(bodies, ws->wb, i, hulls, hull_verts, prm, sc->plane_z, prm->contact_offset, c);
+            plane_contacts(bodies, ws->wb, i, hulls, hull_verts, prm, sc->plane_z, prm->contact_offset, c, NULL, 0);
             for (int k = 0; k < PLANE_SLOTS; ++k) {
                 if (!c[k].valid || rows >= max_rows) continue;
                 float* o = out + 12 * rows++;
