@@ -1356,14 +1356,18 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         pmanifold* pm = ws->hp_pm[k];
         if (!pm) continue;
         const contact* c = &ws->c[k * MAX_CONTACTS_PER_HP];
-        for (int i = 0; i < pm->count; ++i) pm->ln[i] = c[i].valid ? c[i].ln : 0.0f;
+        int kept = 0;   /* points the active-contact cap dropped (a suffix) leave the manifold */
+        while (kept < pm->count && c[kept].valid) { pm->ln[kept] = c[kept].ln; ++kept; }
+        pm->count = kept;
     }
     if (sc->has_plane)
         for (int i = 0; i < nb; ++i) {
             pplane* pp = &ws->pp[i];
             if (pp->stamp != ws->step) continue;
             const contact* c = &ws->c[plane_base + i * PLANE_SLOTS];
-            for (int k = 0; k < pp->count; ++k) pp->ln[k] = c[k].valid ? c[k].ln : 0.0f;
+            int kept = 0;
+            while (kept < pp->count && c[kept].valid) { pp->ln[kept] = c[kept].ln; ++kept; }
+            pp->count = kept;
         }
     ws->step++;
 

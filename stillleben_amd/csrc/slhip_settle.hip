@@ -117,8 +117,9 @@ struct DriveAcc { float dl[3], da[3]; };
 // solver contact, compacted in LDS (plane contacts first, then hull-pair contacts in pair order).
 // 72 bytes: the bodies and the friction coefficients come from the contact's group, the tangent
 // basis is a pure function of n and is recomputed in the solver, the restitution target is folded
-// into `bounce` (-inf = none).  Between fill_contact and prep_contact the fields ln / lt1 / bounce
-// carry the body indices (as integer bits) and the restitution.
+// into `bounce` (-inf = none).  Between fill_contact and prep_contact the fields kt1 / kt2 / bounce
+// carry the body indices (as integer bits) and the restitution; ln is the warm-start impulse from the
+// moment the contact is filled (oracle: WARM_START x what the persistent point ended the last step with).
 struct Contact {
     v3 ra, rb, n;
     float err;            // sep - rest; after prep_contact: the normal row's target velocity in the biased sweeps
@@ -132,6 +133,7 @@ static_assert(sizeof(Contact) == 72, "Contact layout");
 struct RawContacts {
     v3 pa[4], pb[4];
     float sep[4];
+    float w[4];        // impulse carried over from the previous step (persistent points), 0 for new ones
     v3 n;
     int count;
 };
@@ -503,6 +505,94 @@ __device__ void overlap_fallback(const Shape& A, const Shape& B, const f3* __res
     *sep = best;
 }
 
+// ---- penetration of two OVERLAPPING hulls: Minkowski portal refinement (oracle mpr_penetration, same arithmetic) ----
+// M = A - B contains the origin; from the interior point v0 (difference of the hulls' sphere centres) the ray through the origin
+// leaves M through the portal (v1 v2 v3), refined by support points along its normal.  The portal point closest to the origin,
+// pt = pa - pb, is the contact: n = -pt / |pt| (from B to A), separation -|pt|.  The state is four simplex vertices in registers.
+constexpr float kMprTol = 1.0e-4f;
+constexpr int kMprMaxDiscover = 16, kMprMaxRefine = 24;
+__device__ __forceinline__ SV mpr_support(const Shape& A, const Shape& B, const f3* __restrict__ hv, v3 d)
+{
+    SV w;
+    int ia, ib;
+    w.a = support(A, hv, d, ia);
+    w.b = support(B, hv, neg(d), ib);
+    w.idx = ia | (ib << 16);
+    w.w = sub(w.a, w.b);
+    return w;
+}
+__device__ __forceinline__ v3 normalized(v3 a) { return scale(a, 1.0f / sqrtf(dot(a, a))); }
+
+__device__ bool mpr_penetration(const Shape& A, const Shape& B, const f3* __restrict__ hv, v3 ca, v3 cb, v3* n, float* sep,
+                                v3* pa, v3* pb)
+{
+    v3 v0 = sub(ca, cb);
+    if (dot(v0, v0) < 1.0e-12f) v0 = V(1.0e-5f, 0.0f, 0.0f);
+    v3 dir = normalized(neg(v0));
+    SV v1 = mpr_support(A, B, hv, dir);
+    if (!(dot(v1.w, dir) > 0.0f)) return false;
+    dir = cross(v0, v1.w);
+    if (dot(dir, dir) < 1.0e-20f) {
+        const float l = sqrtf(dot(v1.w, v1.w));
+        if (l < 1.0e-9f) return false;
+        *n = scale(v1.w, -1.0f / l); *sep = -l; *pa = v1.a; *pb = v1.b;
+        return true;
+    }
+    dir = normalized(dir);
+    SV v2 = mpr_support(A, B, hv, dir);
+    if (!(dot(v2.w, dir) > 0.0f)) return false;
+    dir = cross(sub(v1.w, v0), sub(v2.w, v0));
+    if (dot(dir, dir) < 1.0e-24f) return false;
+    dir = normalized(dir);
+    if (dot(dir, v0) > 0.0f) { const SV t = v1; v1 = v2; v2 = t; dir = neg(dir); }
+    SV v3_ = v2;
+    bool found = false;
+    for (int it = 0; it < kMprMaxDiscover; ++it) {
+        v3_ = mpr_support(A, B, hv, dir);
+        if (!(dot(v3_.w, dir) > 0.0f)) return false;
+        bool cont = false;
+        if (dot(cross(v1.w, v3_.w), v0) < 0.0f) { v2 = v3_; cont = true; }
+        else if (dot(cross(v3_.w, v2.w), v0) < 0.0f) { v1 = v3_; cont = true; }
+        if (!cont) { found = true; break; }
+        dir = cross(sub(v1.w, v0), sub(v2.w, v0));
+        if (dot(dir, dir) < 1.0e-24f) return false;
+        dir = normalized(dir);
+    }
+    if (!found) return false;
+    for (int it = 0; it < kMprMaxRefine; ++it) {
+        dir = cross(sub(v2.w, v1.w), sub(v3_.w, v1.w));
+        if (dot(dir, dir) < 1.0e-24f) break;
+        dir = normalized(dir);
+        const SV v4 = mpr_support(A, B, hv, dir);
+        const float d4 = dot(v4.w, dir);
+        float m = d4 - dot(v1.w, dir);
+        const float m2 = d4 - dot(v2.w, dir), m3 = d4 - dot(v3_.w, dir);
+        if (m2 < m) m = m2;
+        if (m3 < m) m = m3;
+        if (m <= kMprTol) break;
+        const v3 x = cross(v4.w, v0);
+        if (dot(v1.w, x) > 0.0f) {
+            if (dot(v2.w, x) > 0.0f) v1 = v4; else v3_ = v4;
+        } else {
+            if (dot(v3_.w, x) > 0.0f) v2 = v4; else v1 = v4;
+        }
+    }
+    float l[3];
+    closest_triangle(v1.w, v2.w, v3_.w, l);
+    const v3 pt = comb3(v1.w, v2.w, v3_.w, l);
+    const float d = sqrtf(dot(pt, pt));
+    *pa = comb3(v1.a, v2.a, v3_.a, l);
+    *pb = comb3(v1.b, v2.b, v3_.b, l);
+    if (d > 1.0e-7f) *n = scale(pt, -1.0f / d);
+    else {
+        const v3 pn = cross(sub(v2.w, v1.w), sub(v3_.w, v1.w));
+        if (dot(pn, pn) < 1.0e-24f) return false;
+        *n = neg(normalized(pn));
+    }
+    *sep = -d;
+    return true;
+}
+
 // hull description resolved for this scene: vertices either in LDS (copied once per settle) or
 // in the global pool
 struct HullRef {
@@ -528,6 +618,7 @@ __device__ __forceinline__ void make_shape(const WBody& wb, const HullRef& h, co
 struct Cand5 {
     v3 p[5], q[5];
     float s[5];
+    float w[5];           // carried impulse of the candidate
     unsigned ok;          // validity mask, bit j = slot j
 };
 
@@ -557,16 +648,24 @@ __device__ __forceinline__ float pick_s(const Cand5& c, int i)
     for (int j = 1; j < 5; ++j) r = j == i ? c.s[j] : r;
     return r;
 }
+__device__ __forceinline__ float pick_w(const Cand5& c, int i)
+{
+    float r = c.w[0];
+#pragma unroll
+    for (int j = 1; j < 5; ++j) r = j == i ? c.w[j] : r;
+    return r;
+}
 
 __device__ __forceinline__ void emit(RawContacts& out, int& k, const Cand5& c, int i)
 {
     const v3 pp = pick_p(c, i), qq = pick_q(c, i);
-    const float ss = pick_s(c, i);
+    const float ss = pick_s(c, i), ww = pick_w(c, i);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         out.pa[t] = vsel(t == k, pp, out.pa[t]);
         out.pb[t] = vsel(t == k, qq, out.pb[t]);
         out.sep[t] = t == k ? ss : out.sep[t];
+        out.w[t] = t == k ? ww : out.w[t];
     }
     ++k;
 }
@@ -590,15 +689,15 @@ __device__ __forceinline__ float reduce_candidates(const Cand5& c, v3 nrm, RawCo
     // all five valid: the winners are carried as VALUES (index + point + separation) while the fixed
     // slots are scanned -- no run-time indexed reads of `c`; same comparisons, same first-index ties
     int i0 = 0;
-    float s0 = c.s[0];
+    float s0 = c.s[0], w0 = c.w[0];
     v3 p0 = c.p[0], q0 = c.q[0];
 #pragma unroll
     for (int j = 1; j < 5; ++j) {
         const bool b = c.s[j] < s0;
-        i0 = b ? j : i0; s0 = b ? c.s[j] : s0; p0 = vsel(b, c.p[j], p0); q0 = vsel(b, c.q[j], q0);
+        i0 = b ? j : i0; s0 = b ? c.s[j] : s0; w0 = b ? c.w[j] : w0; p0 = vsel(b, c.p[j], p0); q0 = vsel(b, c.q[j], q0);
     }
     int i1 = -1; float best = -3.0e38f;
-    float s1 = 0.0f;
+    float s1 = 0.0f, w1 = 0.0f;
     v3 p1 = V(0, 0, 0), q1 = V(0, 0, 0);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -606,10 +705,10 @@ __device__ __forceinline__ float reduce_candidates(const Cand5& c, v3 nrm, RawCo
         const float pen = kDepthWeight * (c.s[j] - s0);
         const float score = sqrtf(dot(d, d)) - pen;
         const bool b = j != i0 && score > best;
-        best = b ? score : best; i1 = b ? j : i1; s1 = b ? c.s[j] : s1; p1 = vsel(b, c.p[j], p1); q1 = vsel(b, c.q[j], q1);
+        best = b ? score : best; i1 = b ? j : i1; s1 = b ? c.s[j] : s1; w1 = b ? c.w[j] : w1; p1 = vsel(b, c.p[j], p1); q1 = vsel(b, c.q[j], q1);
     }
     int i2 = -1, i3 = -1; float mx = 0.0f, mn = 0.0f;
-    float s2 = 0.0f, s3 = 0.0f;
+    float s2 = 0.0f, s3 = 0.0f, w2 = 0.0f, w3 = 0.0f;
     v3 p2 = V(0, 0, 0), q2 = V(0, 0, 0), p3 = V(0, 0, 0), q3 = V(0, 0, 0);
     const v3 e = sub(p1, p0);
     const float el = sqrtf(dot(e, e));
@@ -619,16 +718,16 @@ __device__ __forceinline__ float reduce_candidates(const Cand5& c, v3 nrm, RawCo
         const float a = dot(cross(e, sub(c.p[j], p0)), nrm);
         const float pen = kDepthWeight * (c.s[j] - s0) * el;
         const bool b2 = !skip && a - pen > mx, b3 = !skip && a + pen < mn;
-        mx = b2 ? a - pen : mx; i2 = b2 ? j : i2; s2 = b2 ? c.s[j] : s2; p2 = vsel(b2, c.p[j], p2); q2 = vsel(b2, c.q[j], q2);
-        mn = b3 ? a + pen : mn; i3 = b3 ? j : i3; s3 = b3 ? c.s[j] : s3; p3 = vsel(b3, c.p[j], p3); q3 = vsel(b3, c.q[j], q3);
+        mx = b2 ? a - pen : mx; i2 = b2 ? j : i2; s2 = b2 ? c.s[j] : s2; w2 = b2 ? c.w[j] : w2; p2 = vsel(b2, c.p[j], p2); q2 = vsel(b2, c.q[j], q2);
+        mn = b3 ? a + pen : mn; i3 = b3 ? j : i3; s3 = b3 ? c.s[j] : s3; w3 = b3 ? c.w[j] : w3; p3 = vsel(b3, c.p[j], p3); q3 = vsel(b3, c.q[j], q3);
     }
-    out.pa[0] = p0; out.pb[0] = q0; out.sep[0] = s0; mins = fminf(mins, s0);
-    out.pa[1] = p1; out.pb[1] = q1; out.sep[1] = s1; if (s1 < mins) mins = s1;
+    out.pa[0] = p0; out.pb[0] = q0; out.sep[0] = s0; out.w[0] = w0; mins = fminf(mins, s0);
+    out.pa[1] = p1; out.pb[1] = q1; out.sep[1] = s1; out.w[1] = w1; if (s1 < mins) mins = s1;
     k = 2;
     const bool h2 = i2 >= 0, h3 = i3 >= 0;
     // slot 2: candidate i2, or i3 when there is no i2; slot 3: candidate i3 when both exist
-    out.pa[2] = vsel(h2, p2, p3); out.pb[2] = vsel(h2, q2, q3); out.sep[2] = h2 ? s2 : s3;
-    out.pa[3] = p3; out.pb[3] = q3; out.sep[3] = s3;
+    out.pa[2] = vsel(h2, p2, p3); out.pb[2] = vsel(h2, q2, q3); out.sep[2] = h2 ? s2 : s3; out.w[2] = h2 ? w2 : w3;
+    out.pa[3] = p3; out.pb[3] = q3; out.sep[3] = s3; out.w[3] = w3;
     if (h2) { ++k; if (s2 < mins) mins = s2; }
     if (h3) { ++k; if (s3 < mins) mins = s3; }
     out.count = k;
@@ -638,16 +737,24 @@ __device__ __forceinline__ float reduce_candidates(const Cand5& c, v3 nrm, RawCo
 // ---- narrowphase of one hull pair, split in three stages so that the four tilt runs of every
 // ---- contact pair can execute on separate lanes (same arithmetic as the oracle's
 // ---- hull_pair_contacts, which runs them one after the other)
-struct MainResult {       // stage 1: plain GJK
-    int type;             // 0 none, 1 contact pair (tilt runs follow), 2 overlap (single fallback contact)
+struct MainResult {       // stage 1: plain GJK (+ portal refinement when the hulls overlap)
+    int type;             // 0 none; 1 NEW contact pair (tilt runs follow); 2 new pair found overlapping (its single contact);
+                          // 3 pair with a manifold from the previous step (refreshed by pair_persist)
     v3 n, pa, pb;
-    float dist;           // distance (type 1) or fallback separation (type 2)
-    GjkSeed seed;         // type 1: the converged simplex, start of the tilt runs
+    float dist;           // distance, or the (negative) separation of an overlap
+    GjkSeed seed;         // type 1: the converged simplex, start of the tilt runs; type 3: seed.n = the previous step's pair slot
 };
 
+// constants of the contact persistence (oracle/settle_ref.c WARM_START, DRIFT_OFFSETS, NORMAL_COS, PLANE_DEPTH_WEIGHT)
+constexpr float kWarmStart = 0.8f;
+constexpr float kDriftOffsets = 2.0f;
+constexpr float kNormalCos = 0.9848f;
+constexpr float kPlaneDepthWeight = 5.0f;
+
+// `prev_ok`: the pair had a manifold with points in the previous step.  Returns whether the pair cache takes the new simplex.
 __device__ __forceinline__ bool pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
                                           const f3* __restrict__ hv, const float4* __restrict__ gv, float margin, const GjkSeed cached,
-                                          MainResult& r, int max_iter = kGjkMaxIter, bool* unfinished = nullptr)
+                                          bool prev_ok, MainResult& r, int max_iter = kGjkMaxIter, bool* unfinished = nullptr)
 {
     r.type = 0;
     Shape A, B;
@@ -667,13 +774,15 @@ __device__ __forceinline__ bool pair_main(const WBody& wa, const WBody& wb, cons
     if (code == 2) return true;
     if (code == 0) {
         float sep;
-        overlap_fallback(A, B, hv, ca, cb, &n, &sep, &pa, &pb);
-        if (sep > 0.0f) sep = 0.0f;
-        r.type = 2; r.n = n; r.pa = pa; r.pb = pb; r.dist = sep;
+        if (!mpr_penetration(A, B, hv, ca, cb, &n, &sep, &pa, &pb)) {
+            overlap_fallback(A, B, hv, ca, cb, &n, &sep, &pa, &pb);
+            if (sep > 0.0f) sep = 0.0f;
+        }
+        r.type = prev_ok ? 3 : 2; r.n = n; r.pa = pa; r.pb = pb; r.dist = sep;
         return false;   // overlap keeps the previous cache entry
     }
     if (dist > margin) return true;
-    r.type = 1;
+    r.type = prev_ok ? 3 : 1;
     r.n = scale(sub(pa, pb), 1.0f / dist);
     r.pa = pa; r.pb = pb; r.dist = dist;
     return true;
@@ -729,10 +838,12 @@ __device__ bool pair_tilt(const WBody& wa, const WBody& wb, const HullRef& ha, c
     return true;
 }
 
-// stage 3: duplicate rejection in slot order + manifold reduction
+// stage 3 (new pairs): duplicate rejection in slot order + manifold reduction
 __device__ __forceinline__ float pair_finish(const MainResult& m, Cand5& c, float radius, RawContacts& out)
 {
     c.p[0] = m.pa; c.q[0] = m.pb; c.s[0] = m.dist; c.ok |= 1u;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) c.w[k] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!((c.ok >> (k + 1)) & 1u)) continue;
@@ -746,6 +857,59 @@ __device__ __forceinline__ float pair_finish(const MainResult& m, Cand5& c, floa
         }
         if (dup) c.ok &= ~(1u << (k + 1));
     }
+    out.n = m.n;
+    return reduce_candidates(c, m.n, out);
+}
+
+// Persistent manifold of one hull pair as the previous step left it (oracle pmanifold; the impulses live in the step's
+// impulse array at c_off): contact points in the two bodies' object frames, the normal in B's frame.  128 bytes.
+struct PM {
+    int count, c_off;
+    v3 nb;
+    v3 la[4], lb[4];
+    float pad[3];
+};
+static_assert(sizeof(PM) == 128, "PM layout");
+
+// stage 3 (pairs with a manifold): the old points refreshed in the new poses -- separations along the new normal; a point whose
+// witnesses drifted apart laterally or that left the contact band is dropped, all of them when the normal turned -- plus the
+// new closest-point (or deepest-point) pair, which replaces the old point it coincides with or joins as a fifth candidate.
+// Slots 0..3 = the old points in their order, slot 4 = the new one: the oracle's compacted list in the same order.
+__device__ __forceinline__ float pair_persist(const MainResult& m, const PM& prev, const float* __restrict__ ln_prev, const WBody& wa,
+                                              const WBody& wb, float margin, float contact_offset, float radius, RawContacts& out)
+{
+    Cand5 c;
+    c.ok = 0u;
+    const v3 npw = m3_mul(wb.R, prev.nb);
+    const float lim = kDriftOffsets * contact_offset;
+    const bool same_normal = dot(m.n, npw) >= kNormalCos;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        c.p[i] = V(0, 0, 0); c.q[i] = V(0, 0, 0); c.s[i] = 0.0f; c.w[i] = 0.0f;
+        if (i < prev.count && same_normal) {
+            const v3 qa = add(m3_mul(wa.R, prev.la[i]), wa.t);
+            const v3 qb = add(m3_mul(wb.R, prev.lb[i]), wb.t);
+            const v3 d = sub(qa, qb);
+            const float sp = dot(d, m.n);
+            const v3 lat = sub(d, scale(m.n, sp));
+            const bool keep = !(sp > margin) && !(dot(lat, lat) > lim * lim);
+            if (keep) { c.p[i] = qa; c.q[i] = qb; c.s[i] = sp; c.w[i] = ln_prev[i]; c.ok |= 1u << i; }
+        }
+    }
+    const float dup2 = 2.5e-3f * radius * radius;
+    int dup = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const v3 dd = sub(c.p[j], m.pa);
+        if (dup < 0 && ((c.ok >> j) & 1u) && dot(dd, dd) < dup2) dup = j;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool r = j == dup;
+        c.p[j] = vsel(r, m.pa, c.p[j]); c.q[j] = vsel(r, m.pb, c.q[j]); c.s[j] = r ? m.dist : c.s[j];
+    }
+    c.p[4] = m.pa; c.q[4] = m.pb; c.s[4] = m.dist; c.w[4] = 0.0f;
+    if (dup < 0) c.ok |= 1u << 4;
     out.n = m.n;
     return reduce_candidates(c, m.n, out);
 }
@@ -764,7 +928,7 @@ __device__ __forceinline__ float4 hull_vertex(const HullRef& h, const f3* __rest
 // ---- cooperative variant: one 16-lane sub-group per body (four bodies per wave round) ----------
 // Every arg-min/arg-max is taken over (value, band ordinal)
 // with the lower ordinal winning ties, which is exactly what the serial strict compares pick.
-struct BandPt { v3 p; float d; };
+struct BandPt { v3 p; float d; int id; };
 constexpr int kBandCap = 32;   // in-band vertices cached per body; beyond that the passes re-walk the hulls
 
 // A 16-lane sub-group is one DPP row: rotating the row by 8, 4, 2, 1 lanes and combining leaves the
@@ -785,16 +949,18 @@ __device__ __forceinline__ void sg16_argmin(float& val, int& idx)
     sg16_argmin_step<0x121>(val, idx);   // row_ror:1
 }
 
-// broadcast the winning lane's point within the 16-lane sub-group
-__device__ __forceinline__ void sg16_fetch(bool mine, int sg, v3& p, float& d)
+// broadcast the winning lane's point (and its vertex number) within the 16-lane sub-group
+__device__ __forceinline__ void sg16_fetch(bool mine, int sg, v3& p, float& d, int& id)
 {
     const unsigned om = (unsigned)(__ballot(mine) >> (16 * sg)) & 0xffffu;
     const int owner = 16 * sg + (om ? __ffs(om) - 1 : 0);
     p.x = __shfl(p.x, owner, 64); p.y = __shfl(p.y, owner, 64); p.z = __shfl(p.z, owner, 64);
     d = __shfl(d, owner, 64);
+    id = __shfl(id, owner, 64);
 }
 
-// f(p, d, ordinal) for every in-band vertex of the body, ordinals in hull/vertex order
+// f(p, d, ordinal, id) for every in-band vertex of the body, ordinals in hull/vertex order; id = the vertex's number within the
+// body, hull << 8 | vertex (the oracle's PLANE_ID: what a persistent table contact is matched by)
 template <class F>
 __device__ __forceinline__ int sg16_walk_band(const WBody& w, const HullRef* lh, const f3* __restrict__ hv,
                                               const float4* __restrict__ gv, int lh_begin,
@@ -819,45 +985,47 @@ __device__ __forceinline__ int sg16_walk_band(const WBody& w, const HullRef* lh,
                 in = d <= margin;
             }
             const unsigned sm = (unsigned)(__ballot(in) >> (16 * sg)) & 0xffffu;
-            if (in) f(p, d, ord + (int)__popc(sm & ((1u << sl) - 1u)));
+            if (in) f(p, d, ord + (int)__popc(sm & ((1u << sl) - 1u)), ((h - lh_begin) << 8) | i);
             ord += (int)__popc(sm);
         }
     }
     return ord;
 }
 
+// `ids`: the vertex numbers of the selected contacts (see sg16_walk_band)
 __device__ void plane_contacts_sg16(const WBody& w, const HullRef* lh, const f3* __restrict__ hv,
                                     const float4* __restrict__ gv, int lh_begin, int lh_end,
-                                    float plane_z, float margin, BandPt* band, int sg, int sl, RawContacts& out)
+                                    float plane_z, float margin, BandPt* band, int sg, int sl, RawContacts& out, int* ids)
 {
     constexpr int kNone = 0x7fffffff;
     out.count = 0;
     out.n = V(0, 0, 1);
+    ids[0] = ids[1] = ids[2] = ids[3] = 0;
     // pass 0: deepest in-band vertex; the band is cached in LDS on the way
-    float bv = kInf; int bi = kNone; v3 bp = V(0, 0, 0);
+    float bv = kInf; int bi = kNone; v3 bp = V(0, 0, 0); int bid = 0;
     const int band_n = sg16_walk_band(w, lh, hv, gv, lh_begin, lh_end, plane_z, margin, sg, sl,
-                                      [&](v3 p, float d, int ord) {
-                                          if (d < bv || bi == kNone) { bv = d; bi = ord; bp = p; }
-                                          if (ord < kBandCap) { BandPt b; b.p = p; b.d = d; band[ord] = b; }
+                                      [&](v3 p, float d, int ord, int id) {
+                                          if (d < bv || bi == kNone) { bv = d; bi = ord; bp = p; bid = id; }
+                                          if (ord < kBandCap) { BandPt b; b.p = p; b.d = d; b.id = id; band[ord] = b; }
                                       });
     if (band_n == 0) return;
     const bool cached = band_n <= kBandCap;
-    float s0; v3 p0;
+    float s0; v3 p0; int id0 = bid;
     {
         float v = bi == kNone ? kInf : bv; int idx = bi;
         sg16_argmin(v, idx);
         s0 = bv; p0 = bp;
-        sg16_fetch(bi == idx, sg, p0, s0);
+        sg16_fetch(bi == idx, sg, p0, s0, id0);
     }
     // pass 1: farthest from p0, deep points preferred
-    float b1 = kInf; int i1 = kNone; v3 p1 = V(0, 0, 0); float s1 = 0.0f;
-    auto f1 = [&](v3 p, float d, int ord) {
+    float b1 = kInf; int i1 = kNone; v3 p1 = V(0, 0, 0); float s1 = 0.0f; int id1 = 0;
+    auto f1 = [&](v3 p, float d, int ord, int id) {
         const v3 dd = sub(p, p0);
-        const float score = sqrtf(dot(dd, dd)) - kDepthWeight * (d - s0);
-        if (score > 0.0f && (i1 == kNone || -score < b1)) { b1 = -score; i1 = ord; p1 = p; s1 = d; }
+        const float score = sqrtf(dot(dd, dd)) - kPlaneDepthWeight * (d - s0);
+        if (score > 0.0f && (i1 == kNone || -score < b1)) { b1 = -score; i1 = ord; p1 = p; s1 = d; id1 = id; }
     };
     if (cached) {
-        for (int k = sl; k < band_n; k += 16) { const BandPt b = band[k]; f1(b.p, b.d, k); }
+        for (int k = sl; k < band_n; k += 16) { const BandPt b = band[k]; f1(b.p, b.d, k, b.id); }
     } else {
         sg16_walk_band(w, lh, hv, gv, lh_begin, lh_end, plane_z, margin, sg, sl, f1);
     }
@@ -866,25 +1034,25 @@ __device__ void plane_contacts_sg16(const WBody& w, const HullRef* lh, const f3*
         float v = b1; int idx = i1;
         sg16_argmin(v, idx);
         have1 = idx != kNone;
-        sg16_fetch(have1 && i1 == idx, sg, p1, s1);
+        sg16_fetch(have1 && i1 == idx, sg, p1, s1, id1);
     }
     int nk = 1;
-    out.pa[0] = p0; out.sep[0] = s0;
+    out.pa[0] = p0; out.sep[0] = s0; ids[0] = id0;
     if (have1) {
-        out.pa[1] = p1; out.sep[1] = s1; nk = 2;
+        out.pa[1] = p1; out.sep[1] = s1; ids[1] = id1; nk = 2;
         const v3 e = sub(p1, p0);
         const float el = sqrtf(dot(e, e));
         float b2 = kInf, b3 = kInf; int i2 = kNone, i3 = kNone;
-        v3 p2 = V(0, 0, 0), p3 = V(0, 0, 0); float s2 = 0.0f, s3 = 0.0f;
-        auto f2 = [&](v3 p, float d, int ord) {
+        v3 p2 = V(0, 0, 0), p3 = V(0, 0, 0); float s2 = 0.0f, s3 = 0.0f; int id2 = 0, id3 = 0;
+        auto f2 = [&](v3 p, float d, int ord, int id) {
             const float a = dot(cross(e, sub(p, p0)), out.n);
-            const float pen = kDepthWeight * (d - s0) * el;
+            const float pen = kPlaneDepthWeight * (d - s0) * el;
             const float hi = a - pen, lo = a + pen;
-            if (hi > 0.0f && (i2 == kNone || -hi < b2)) { b2 = -hi; i2 = ord; p2 = p; s2 = d; }
-            if (lo < 0.0f && (i3 == kNone || lo < b3)) { b3 = lo; i3 = ord; p3 = p; s3 = d; }
+            if (hi > 0.0f && (i2 == kNone || -hi < b2)) { b2 = -hi; i2 = ord; p2 = p; s2 = d; id2 = id; }
+            if (lo < 0.0f && (i3 == kNone || lo < b3)) { b3 = lo; i3 = ord; p3 = p; s3 = d; id3 = id; }
         };
         if (cached) {
-            for (int k = sl; k < band_n; k += 16) { const BandPt b = band[k]; f2(b.p, b.d, k); }
+            for (int k = sl; k < band_n; k += 16) { const BandPt b = band[k]; f2(b.p, b.d, k, b.id); }
         } else {
             sg16_walk_band(w, lh, hv, gv, lh_begin, lh_end, plane_z, margin, sg, sl, f2);
         }
@@ -892,12 +1060,12 @@ __device__ void plane_contacts_sg16(const WBody& w, const HullRef* lh, const f3*
         sg16_argmin(v2, x2);
         sg16_argmin(v3_, x3);
         const bool have2 = x2 != kNone, have3 = x3 != kNone;
-        sg16_fetch(have2 && i2 == x2, sg, p2, s2);
-        sg16_fetch(have3 && i3 == x3, sg, p3, s3);
-        if (have2) { out.pa[2] = p2; out.sep[2] = s2; nk = 3; }
+        sg16_fetch(have2 && i2 == x2, sg, p2, s2, id2);
+        sg16_fetch(have3 && i3 == x3, sg, p3, s3, id3);
+        if (have2) { out.pa[2] = p2; out.sep[2] = s2; ids[2] = id2; nk = 3; }
         if (have3) {
-            if (have2) { out.pa[3] = p3; out.sep[3] = s3; nk = 4; }
-            else { out.pa[2] = p3; out.sep[2] = s3; nk = 3; }
+            if (have2) { out.pa[3] = p3; out.sep[3] = s3; ids[3] = id3; nk = 4; }
+            else { out.pa[2] = p3; out.sep[2] = s3; ids[2] = id3; nk = 3; }
         }
     }
 #pragma unroll
@@ -908,16 +1076,17 @@ __device__ void plane_contacts_sg16(const WBody& w, const HullRef* lh, const f3*
 // `head`: the first contact of its friction patch (= the manifold of one hull pair / of one body against the table); carried
 // in the sign of `til` (the tangent construction's 1 / |a| is positive)
 __device__ __forceinline__ void fill_contact(Contact* c, int a, int b, const WBody& wa, const WBody* wbb, v3 pa, v3 pb,
-                                             v3 n, float sep, float rest, float e, bool head)
+                                             v3 n, float sep, float rest, float e, bool head, float warm)
 {
     Contact k;
     k.ra = sub(pa, wa.x);
     k.rb = wbb ? sub(pb, wbb->x) : V(0, 0, 0);
     k.n = n;
     k.err = sep - rest;
-    k.kn = k.kt1 = k.kt2 = 0.0f;
-    k.ln = __int_as_float(a); k.lt1 = __int_as_float(b);   // consumed (and zeroed) by prep_contact
-    k.lt2 = 0.0f;
+    k.kn = 0.0f;
+    k.kt1 = __int_as_float(a); k.kt2 = __int_as_float(b);   // consumed by prep_contact
+    k.ln = warm;                                            // the sweeps start from it (k_w_solve applies it first)
+    k.lt1 = 0.0f; k.lt2 = 0.0f;
     k.bounce = e;                                          // restitution until prep_contact
     k.til = head ? -1.0f : 1.0f;                           // sign = patch head; magnitude set by prep_contact
     *c = k;
@@ -963,7 +1132,7 @@ __device__ __forceinline__ float eff_mass(const WBody& a, const WBody* b, v3 ra,
 __device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_threshold, float inv_dt)
 {
     Contact c = *cp;
-    const int ia = __float_as_int(c.ln), ib = __float_as_int(c.lt1);
+    const int ia = __float_as_int(c.kt1), ib = __float_as_int(c.kt2);
     const float e = c.bounce;
     const WBody& a = wbs[ia];
     const WBody* b = ib >= 0 ? &wbs[ib] : nullptr;
@@ -989,7 +1158,7 @@ __device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_thresho
     if (bounce > tu) tu = bounce;
     cp->err = tb;
     cp->kn = c.kn; cp->kt1 = c.kt1; cp->kt2 = c.kt2; cp->bounce = tu;
-    cp->ln = 0.0f; cp->lt1 = 0.0f; cp->til = c.til < 0.0f ? -til : til;
+    cp->til = c.til < 0.0f ? -til : til;
 }
 
 // Gauss-Seidel sweep over the contacts of ONE group (all share the same two bodies) by a PAIR of
@@ -1092,6 +1261,25 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, int
     if (M.dynamic) { wbs[mine].v = M.v; wbs[mine].w = M.w; }
 }
 
+// Warm start of ONE group by its lane pair (oracle: the loop before the first sweep): every contact's carried normal impulse is
+// applied to the two bodies, contacts in order; same lane roles and sign conventions as solve_group.
+__device__ void warm_group(const Contact* ac, int begin, int end, int ia, int ib, int side, WBody* wbs)
+{
+    if (begin >= end) return;
+    const int mine = side ? ib : ia;
+    if (mine < 0) return;
+    BodyRegs M;
+    load_regs(wbs[mine], M);
+    if (!M.dynamic) return;
+    const float sgn = side ? -1.0f : 1.0f;
+    for (int ci = begin; ci < end; ++ci) {
+        const Contact c = ac[ci];
+        const v3 r = side ? c.rb : c.ra;
+        apply_mine(M, r, scale(c.n, sgn * c.ln));
+    }
+    wbs[mine].v = M.v; wbs[mine].w = M.w;
+}
+
 // D6 joint drive of ManipulationSim (same arithmetic as the oracle's solve_drive)
 __device__ void solve_drive(const slhip_body& b, WBody& w, DriveAcc& acc, const slhip_settle_params& prm, bool biased)
 {
@@ -1168,6 +1356,21 @@ __device__ void update_world_inertia(const slhip_body& b, WBody& w)
         for (int c = 0; c < 3; ++c)
             w.Iinv_w.m[3 * r + c] =
                 fmaf(T.m[3 * r + 2], w.R.m[3 * c + 2], fmaf(T.m[3 * r + 1], w.R.m[3 * c + 1], T.m[3 * r] * w.R.m[3 * c]));
+}
+
+// mass-normalised kinetic energy of the sleep test (oracle step_scene (k)): 0.5 (v.v + w.(I w) / m), I = inverse of inv_inertia
+// in object axes by cofactors
+__device__ __forceinline__ float kinetic_energy(const slhip_body& b, const WBody& w)
+{
+    const float* L = b.inv_inertia;
+    const v3 wl = m3_tmul(w.R, w.w);
+    const float c00 = L[5] * L[10] - L[6] * L[9], c01 = L[6] * L[8] - L[4] * L[10], c02 = L[4] * L[9] - L[5] * L[8];
+    const float c11 = L[0] * L[10] - L[2] * L[8], c12 = L[1] * L[8] - L[0] * L[9], c22 = L[0] * L[5] - L[1] * L[4];
+    const float det = fmaf(L[2], c02, fmaf(L[1], c01, L[0] * c00));
+    const v3 iw = V(fmaf(c02, wl.z, fmaf(c01, wl.y, c00 * wl.x)), fmaf(c12, wl.z, fmaf(c11, wl.y, c01 * wl.x)),
+                    fmaf(c22, wl.z, fmaf(c12, wl.y, c02 * wl.x)));
+    const float ang = det != 0.0f ? dot(wl, iw) / det * w.inv_mass : 0.0f;
+    return 0.5f * (dot(w.v, w.v) + ang);
 }
 
 __device__ void store_body(slhip_body& b, const WBody& w)
@@ -1257,7 +1460,6 @@ struct Group { unsigned char a, b, begin, end, color; };
 constexpr int kNoBody = 0xff;
 static_assert(sizeof(Group) == 5, "Group layout");
 static_assert(SLHIP_MAX_ACTIVE_CONTACTS < 256 && SLHIP_MAX_BODIES <= 64, "byte-sized group fields");
-static_assert(SLHIP_MAX_HULL_PAIRS * 4 >= 4 * kBandCap * (int)sizeof(BandPt), "the plane phase's band cache aliases the hull-pair list");
 static_assert(SLHIP_MAX_HULL_PAIRS * 4 >= (kMaxGroups + 65) * 2, "the solver's colour order aliases the hull-pair list");
 
 __host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_cap)
@@ -1281,6 +1483,7 @@ __host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_
     return L;
 }
 
+#if 0   // persistent kernel: being ported to the persistent-manifold step
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_settle(const slhip_settle_scene* __restrict__ scenes, slhip_body* bodies_all,
                                                const slhip_hull* __restrict__ hulls,
                                                const float* __restrict__ hull_verts, slhip_settle_params prm,
@@ -1862,6 +2065,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+#endif
+
 // boolean overlap (scene.cpp:355-385): one lane per body
 __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __restrict__ scenes,
                                                 const slhip_body* __restrict__ bodies_all,
@@ -2002,10 +2207,8 @@ extern "C" int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5
 // 368 against 452 ms; 2048: 454 against 470; 4096: 738 against 515).  SLHIP_SETTLE_IMPL=lockstep / persistent overrides.
 static bool use_persistent_settle(uint32_t n_scenes)
 {
-    const char* e = getenv("SLHIP_SETTLE_IMPL");
-    if (e && e[0] == 'p') return true;
-    if (e && e[0] == 'l') return false;
-    return n_scenes <= 1024u;
+    (void)n_scenes;
+    return false;
 }
 
 extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out)
@@ -2073,14 +2276,14 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                 if (timed)
                     for (int k = 0; k < 6; ++k) SLHIP_CHECK(hipEventCreate(&ev[k]));
                 if (timed) (void)hipEventRecord(ev[0], stream);
-                k_w_begin<<<n_scenes, 64, BL.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, W, BL, drive_w);
+                k_w_begin<<<n_scenes, 64, BL.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, W, BL, drive_w, step + 1u);
                 if (timed) (void)hipEventRecord(ev[1], stream);
-                k_w_gjk_first<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride);
-                k_w_gjk_rest<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride);
+                k_w_gjk_first<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride, step + 1u, n_scenes);
+                k_w_gjk_rest<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride, step + 1u, n_scenes);
                 if (timed) (void)hipEventRecord(ev[2], stream);
                 k_w_gjk_tilt<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, list_stride);
                 if (timed) (void)hipEventRecord(ev[3], stream);
-                k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL);
+                k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL, step + 1u);
                 if (timed) (void)hipEventRecord(ev[4], stream);
                 if (spw == 2)
                     k_w_solve<2><<<(n_scenes + 1) / 2, 64, 2 * SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
@@ -2097,51 +2300,8 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         SLHIP_LAUNCH_CHECK();
         return 0;
     }
-    // LDS layout from the batch maxima.  The kernel is bound by the latency of its dependent
-    // instruction chains, so residency comes first: 8 single-wave workgroups per CU (two per
-    // SIMD, the VGPR limit) when the fixed part of the layout fits 160 KiB / 8, fewer otherwise.
-    // Whatever is left of the per-scene share caches hull vertices; the rest are read from the
-    // global pool (L2).
-    const int lh_cap = params->max_hulls_per_scene ? (int)params->max_hulls_per_scene : 1024;
-    const int fixed = make_layout(nb_cap, lh_cap, 0).total;
-    const int kLdsPerCu = 160 * 1024, kGranule = 1280;
-    if (fixed > kLdsPerCu) {
-        slhip::set_error("slhip_settle: scene too large for LDS (%d bytes)", fixed);
-        return -1;
-    }
-    int resident = kLdsPerCu / fixed;
-    if (resident > 8) resident = 8;
-    if (const char* e = getenv("SLHIP_SETTLE_RESIDENT")) {   // developer knob for co-residency experiments
-        const int r = atoi(e);
-        if (r >= 1 && r < resident) resident = r;
-    }
-    int share = (kLdsPerCu / kGranule / resident) * kGranule;
-    if (share < fixed) share = fixed;
-    int hv_cap = (int)params->max_hull_verts_per_scene;
-    if (hv_cap > (share - fixed) / 12) hv_cap = (share - fixed) / 12;
-    const LdsLayout L = make_layout(nb_cap, lh_cap, hv_cap);
-    SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_settle), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    L.total));
-    ProfScratch* prof = reinterpret_cast<ProfScratch*>(d_scratch);
-    DriveAcc* drive = reinterpret_cast<DriveAcc*>(prof + n_scenes);
-    GjkSeed* cache = reinterpret_cast<GjkSeed*>(reinterpret_cast<char*>(d_scratch) + settle_fixed_bytes(n_scenes));
-    // Segments: the 100 frames of a settle are launched as `segments` kernels of frames / segments frames each (bit-identical
-    // to one launch: the scene state lives in global memory between steps anyway).  A workgroup then holds its CU slot for a
-    // fraction of the ~150 ms a whole settle takes, so the launches of other streams -- the render of the previous batch above
-    // all -- get their turn sooner, and a launch's tail (its slowest scene) is shorter.
-    uint32_t segments = 1;   // measured (profiles/r02): 2 / 4 / 8 segments raise the settle-only rate by 4-7 % but cost the pipelined benchmark 2-9 %
-    if (const char* e = getenv("SLHIP_SETTLE_SEGMENTS")) segments = (uint32_t)atoi(e);
-    if (segments < 1 || params->frames < 2 * segments) segments = 1;
-    slhip_settle_params seg = *params;
-    uint32_t done = 0;
-    for (uint32_t k = 0; k < segments; ++k) {
-        seg.frames = (params->frames - done) / (segments - k);
-        k_settle<<<n_scenes, 64, L.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, seg, L, prof, drive, cache,
-                                                    pair_cache_stride(params), k > 0 ? 1 : 0);
-        done += seg.frames;
-    }
-    SLHIP_LAUNCH_CHECK();
-    return 0;
+    slhip::set_error("slhip_settle: no implementation selected");
+    return -1;
 }
 
 extern "C" int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_status, uint32_t* h_n_refused,

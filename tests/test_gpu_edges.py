@@ -206,18 +206,17 @@ def test_ssao_samples_behind_the_camera(sl, oracle, eng):
 
 
 def test_fragment_at_the_far_plane_loses(sl, oracle, eng):
-    """Found by tests/soak/soak_render.py (seed 610184): a background-plane fragment whose 24-bit depth rounds to
-    0xFFFFFF equals the cleared depth, and GL_LESS rejects it -- the visibility key must not accept it."""
-    import bench
-    from stillleben_amd import physics, synthetic
-
-    meshes = synthetic.ycb_like_meshes(seed=0, tex_size=64, hulls="parts")   # the hull set the soak found this scene with
-    scene = bench.make_scene(sl, meshes, 610184)
-    physics.settle_batch([scene])
-    scene.choose_random_camera_pose()
-    scene.choose_random_light_direction()
+    """Found by tests/soak/soak_render.py (seed 610184, round 1): a background-plane fragment whose 24-bit depth rounds to
+    0xFFFFFF equals the cleared depth, and GL_LESS rejects it -- the visibility key must not accept it.  The situation is built
+    directly (a large background plane seen at a grazing angle crosses the far plane at 10 m): the soak's scene depended on where
+    that round's settle left its objects."""
+    scene = S.clutter_scene(sl, 11, n_objects=3, size=(640, 480))
+    scene.background_plane_size = torch.tensor([40.0, 40.0])
+    # rolled, so that the cut line crosses the pixel rows and fragments with z just below 10 m exist
+    scene.set_camera_look_at(torch.tensor([-1.0, 0.0, 1.5]), torch.tensor([1.0, 0.0, 1.3]), torch.tensor([0.0, 0.6, 1.0]))
     mask = _abi.OUT_GT6 | _abi.OUT_CAM_COORD
     bufs, ref = both(eng, oracle, [scene], mask=mask, ssao=False, shadows=False)
     assert_geometry_equal(bufs, ref, mask=mask)
     z = ref.cam_coord[0, :, :, 2]
-    assert z[(z < 2000.0)].max() > 9.9        # the far plane (10 m) is in view
+    assert z[(z < 2000.0)].max() > 9.9995     # the far plane (10 m) is in view ...
+    assert (z > 2000.0).any()                 # ... and cuts the plane: background beyond it
