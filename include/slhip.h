@@ -329,14 +329,17 @@ typedef struct {
 /* per-scene scratch (device), sized by slhip_settle_scratch_bytes */
 #define SLHIP_MAX_BODIES     64   /* bodies per scene                                          */
 #define SLHIP_MAX_HULL_PAIRS 512  /* candidate hull pairs per scene and step                   */
-#define SLHIP_PAIR_CACHE_MAX_HULLS 256 /* scenes with more convex hulls settle without the pair cache */
-#define SLHIP_MAX_ACTIVE_CONTACTS 160 /* solver contacts per scene and step: plane contacts first,
-                                         then hull-pair contacts in pair order; later ones are dropped */
+#define SLHIP_PAIR_CACHE_MAX_HULLS 256 /* scenes with more convex hulls settle without the pair cache (and without
+                                          persistent manifolds: every step builds its manifolds from scratch) */
+#define SLHIP_MAX_ACTIVE_CONTACTS 160 /* solver contacts per scene and step (PhysX has no such cap, scene.cpp:738-739): the table
+                                         contacts first; when the body pairs offer more than what is left, every pair keeps its
+                                         first B contacts with the largest B that fits -- slhip_settle_caps says how often */
 
-/* Steps every scene of the batch `frames * substeps` times without a host round trip (batches above
- * 1024 scenes: six kernel launches per step over the whole batch; smaller ones: one workgroup per scene for
- * the whole call -- same results bit for bit, SLHIP_SETTLE_IMPL=lockstep|persistent overrides the choice),
- * including the redrop heuristic when params->tabletop.
+/* Steps every scene of the batch `frames * substeps` times without a host round trip -- a short sequence of kernel launches per
+ * step over the whole batch (broadphase; GJK / portal refinement per hull pair; tilted runs for NEW contact pairs; persistent
+ * manifolds, contact list and colouring; the warm-started 4 + 4 Gauss-Seidel sweeps, integration, sleeping), including the redrop
+ * heuristic when params->tabletop.  State that PhysX keeps from step to step lives in the scratch for the duration of the call:
+ * the cached simplex, the persistent contact manifold and its impulses per hull pair, the table contacts per body.
  * d_bodies is updated in place (pose, velocities, separation).  Replaces the hot loop of
  * Scene::simulateTableTopScene (scene.cpp:720-756) and, with frames=substeps=1 and
  * tabletop=0, Scene::simulate(dt) (scene.cpp:903-912).                                       */
@@ -350,6 +353,12 @@ int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
  * message) when any scene was refused -- a wrong hint must never pass silently.                       */
 #define SLHIP_SETTLE_REFUSED_BODIES 1u   /* more bodies than max_bodies_per_scene                      */
 #define SLHIP_SETTLE_REFUSED_HULLS  2u   /* more hulls than max_hulls_per_scene, or > 1024 in one body */
+/* (below) Cap saturation of the last slhip_settle on `d_scratch` (synchronises `stream`; same `params` as that call):
+ * the number of (scene, step) pairs in which the contacts offered exceeded SLHIP_MAX_ACTIVE_CONTACTS (the fair cut applied) and
+ * in which the broadphase found more than SLHIP_MAX_HULL_PAIRS hull pairs (the rest were dropped).  The reference has no cap:
+ * a caller that cares divides by n_scenes * frames * substeps and decides.                                   */
+int slhip_settle_caps(const void* d_scratch, uint32_t n_scenes, const slhip_settle_params* params,
+                      uint64_t* contact_cap_steps, uint64_t* pair_cap_steps, void* stream);
 int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_status, uint32_t* h_n_refused,
                         void* stream);
 /* Optional live timing of the phases of a lockstep step (bench.py's roofline leg): HIP events on the launch's stream

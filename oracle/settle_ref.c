@@ -181,6 +181,9 @@ typedef struct {
     pmanifold* hp_pm[SLHIP_MAX_HULL_PAIRS];
     pplane pp[SLHIP_MAX_BODIES];
     int step;                            /* 1-based step number within the settle call */
+    int hp_overflow;
+    unsigned cap_hits[4];                /* steps of this scene that dropped contacts at the active-contact cap / hull pairs at the
+                                            pair cap; [2] = the most contacts a step offered */
     int n_hulls;
     int body_lh[SLHIP_MAX_BODIES + 1]; /* first hull ordinal of every body */
 } scene_ws;
@@ -619,6 +622,8 @@ static void fill_contact(contact* c, int a, int b, const wbody* wa, const wbody*
 #define DRIFT_OFFSETS 2.0f       /* a persistent point breaks when its two witnesses drift apart laterally by more than this many
                                     contact offsets ... */
 #define NORMAL_COS 0.9848f       /* ... and all of a manifold's points when the normal turned by more than 10 degrees */
+#define THIN_FULL 4
+#define THIN_HALF 8
 #define PLANE_DEPTH_WEIGHT 5.0f  /* table contacts: a metre of extra separation costs this many metres of lateral reach (the far
                                     edge of a slightly tilted box has to stay in the manifold as a speculative contact, or the
                                     push-out of the near edge rocks the box for ever) */
@@ -1081,6 +1086,8 @@ static void color_groups(scene_ws* ws, int n_bodies)
    bins each over the steps (+ 64 bins from 1024 on: iterations of the main GJK runs, per hull pair) -- active contacts, friction anchors, colours, and the chain length of one sweep (sum over the colours
    of the largest group's contacts + anchors: what a lane pair per group has to walk in sequence) */
 void slref_settle_set_stats(uint64_t* h) { g_stats = h; }
+static uint64_t* g_offered = NULL; /* histogram [2048] of the contacts a step offers before the cap (tools/physics_quality.py) */
+void slref_settle_set_offered_hist(uint64_t* h) { g_offered = h; }
 static FILE* g_profile_fp = NULL;
 void slref_settle_set_profile_dump(const char* path)
 {
@@ -1206,6 +1213,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
 
     ws->n_hp = 0;
     ws->n_groups = 0;
+    ws->hp_overflow = 0;
     /* (b) plane contacts FIRST: one group per dynamic body near the table (their contacts have
        priority under the active-contact cap); slots live after the hull-pair slots */
     const int plane_base = SLHIP_MAX_HULL_PAIRS * MAX_CONTACTS_PER_HP;
@@ -1247,7 +1255,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
                     float r2 = hulls[ha].sphere[3] + hulls[hb].sphere[3] + margin;
                     if (dot(dd, dd) > r2 * r2) continue;
                     if (!aabb_overlap(&wb[i], &hulls[ha], &wb[j], &hulls[hb], margin)) continue;
-                    if (ws->n_hp >= SLHIP_MAX_HULL_PAIRS) continue; /* overflow: dropped (deterministic) */
+                    if (ws->n_hp >= SLHIP_MAX_HULL_PAIRS) { ws->hp_overflow = 1; continue; } /* overflow: dropped (deterministic) */
                     int k = ws->n_hp++;
                     ws->hp_ba[k] = i; ws->hp_bb[k] = j; ws->hp_ha[k] = (int)ha; ws->hp_hb[k] = (int)hb;
                 }
@@ -1259,6 +1267,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
             }
         }
 
+    if (ws->hp_overflow) ws->cap_hits[1]++;
     /* (d) narrowphase per hull pair */
     for (int k = 0; k < ws->n_hp; ++k) {
         int i = ws->hp_ba[k], j = ws->hp_bb[k];
@@ -1279,8 +1288,56 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         if (s < bodies[j].separation) bodies[j].separation = s;
     }
 
-    /* active-contact cap (SLHIP_MAX_ACTIVE_CONTACTS): walk the groups in order, drop the rest */
+    /* manifold thinning: a body pair in contact through MANY hull pairs (decomposed shapes) keeps fewer points per hull pair --
+       all four up to THIN_FULL contact pairs, two up to THIN_HALF, one beyond (reduce4's order: the deepest first) */
+    for (int g = 0; g < ws->n_groups; ++g) {
+        if (ws->g_b[g] < 0) continue;
+        int n_cp = 0;
+        for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += MAX_CONTACTS_PER_HP) n_cp += ws->c[i].valid ? 1 : 0;
+        const int limit = n_cp <= THIN_FULL ? 4 : n_cp <= THIN_HALF ? 2 : 1;
+        for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += MAX_CONTACTS_PER_HP)
+            for (int k = limit; k < MAX_CONTACTS_PER_HP; ++k) ws->c[i + k].valid = 0;
+    }
+
+    /* active-contact cap (SLHIP_MAX_ACTIVE_CONTACTS; PhysX has none).  The table contacts come first.  When the body pairs offer
+       more than what is left, every pair group keeps its first B contacts (slot order) with the largest B that fits -- no pair
+       loses ALL its contacts while others keep dozens; the walk in group order below only cuts what even B = 1 cannot fit. */
     {
+        int plane_active = 0, total = 0, bmax = 0;
+        for (int g = 0; g < ws->n_groups; ++g) {
+            int n = 0;
+            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) n += ws->c[i].valid ? 1 : 0;
+            if (ws->g_b[g] < 0) plane_active += n;
+            else { total += n; if (n > bmax) bmax = n; }
+        }
+        if (plane_active > SLHIP_MAX_ACTIVE_CONTACTS) plane_active = SLHIP_MAX_ACTIVE_CONTACTS;
+        const int budget = SLHIP_MAX_ACTIVE_CONTACTS - plane_active;
+        if (g_offered) g_offered[plane_active + total > 2047 ? 2047 : plane_active + total]++;
+        if (plane_active + total > ws->cap_hits[2]) ws->cap_hits[2] = plane_active + total;
+        if (total > budget) {
+            ws->cap_hits[0]++;
+            int B = 1;
+            for (int t = 2; t <= bmax; ++t) {
+                int sum = 0;
+                for (int g = 0; g < ws->n_groups; ++g) {
+                    if (ws->g_b[g] < 0) continue;
+                    int n = 0;
+                    for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) n += ws->c[i].valid ? 1 : 0;
+                    sum += n < t ? n : t;
+                }
+                if (sum > budget) break;
+                B = t;
+            }
+            for (int g = 0; g < ws->n_groups; ++g) {
+                if (ws->g_b[g] < 0) continue;
+                int kept = 0;
+                for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) {
+                    if (!ws->c[i].valid) continue;
+                    if (kept >= B) ws->c[i].valid = 0;
+                    else ++kept;
+                }
+            }
+        }
         int active = 0;
         for (int g = 0; g < ws->n_groups; ++g)
             for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) {
@@ -1427,6 +1484,8 @@ static void redrop(const slhip_settle_scene* sc, slhip_body* bodies, int me, con
 
 /* optional per-frame trace for the tests: trace[(s * frames + f) * 4 + {0,1,2,3}] = bodies asleep, redrops so far,
    active contacts of the frame's last step, max |v| */
+static unsigned* g_caps = NULL; /* per scene {steps at the contact cap, steps at the pair cap, max contacts offered, steps} */
+void slref_settle_set_caps(unsigned* c) { g_caps = c; }
 static float* g_trace = NULL;
 void slref_settle_set_trace(float* t) { g_trace = t; }
 
@@ -1447,6 +1506,7 @@ int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body
         ws->pm = NULL;
         ws->step = 1;
         memset(ws->pp, 0, sizeof(ws->pp));
+        memset(ws->cap_hits, 0, sizeof(ws->cap_hits));
         if (ws->n_hulls > 0 && ws->n_hulls <= SLHIP_PAIR_CACHE_MAX_HULLS) {
             ws->cache = (gjk_seed*)calloc((size_t)ws->n_hulls * ws->n_hulls, sizeof(gjk_seed));
             ws->pm = (pmanifold*)calloc((size_t)ws->n_hulls * ws->n_hulls, sizeof(pmanifold));
@@ -1478,6 +1538,7 @@ int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body
                 t[0] = (float)asleep; t[1] = (f ? t[1 - 4] : 0.0f) + (moved ? 1.0f : 0.0f); t[2] = (float)active; t[3] = vmax;
             }
         }
+        if (g_caps) { g_caps[4 * s] = ws->cap_hits[0]; g_caps[4 * s + 1] = ws->cap_hits[1]; g_caps[4 * s + 2] = ws->cap_hits[2]; g_caps[4 * s + 3] = (unsigned)(ws->step - 1); }
         free(ws->cache);
         free(ws->pm);
         ws->cache = NULL;

@@ -248,6 +248,7 @@ def lib():
     L.slhip_settle.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint64, C.c_void_p]
     L.slhip_settle_status.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]
+    L.slhip_settle_caps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]
     L.slhip_settle_timing_enable.argtypes = [C.c_int]
     L.slhip_settle_timings.argtypes = [C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32 * 5)]
     L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]

@@ -1,17 +1,15 @@
 // slhip_settle.hip -- batched rigid-body settling for gfx950 (MI355X), replacing the PhysX calls
 // of Scene::simulateTableTopScene / Scene::simulate (reference src/scene.cpp:612-759, :903-912).
 //
-// Execution model (DESIGN.md "Settle half"): ONE persistent 64-lane workgroup (one wavefront)
-// per scene runs all frames x substeps without returning to the host -- the 400 dependent
-// steps of a settle are a latency chain, so throughput comes from running thousands of scenes
-// side by side (8 waves/SIMD x 4 SIMDs x 256 CUs), not from splitting one scene.  Inside a step
-// the 64 lanes fan out over independent items:
+// Execution model (DESIGN.md "Settle half"): the 400 dependent steps of a settle are a latency chain, so throughput comes from
+// running thousands of scenes side by side.  Every step is a short sequence of kernels over the WHOLE batch (the lockstep
+// pipeline, slhip_settle_wide.inc); this file holds the device functions of the step -- the arithmetic of oracle/settle_ref.c:
 //     bodies      -> force integration, pose integration, sleep bookkeeping
 //     body pairs  -> bounding-sphere broadphase, survivors compacted IN ORDER with a
 //                    wave ballot + popcount prefix (no atomics, deterministic)
-//     hull pairs  -> GJK distance + 4 tilted GJK runs for the contact manifold (hull vertices
-//                    are <= 64 float4, read through L1/L2; body state lives in LDS)
-//     groups      -> Gauss-Seidel contact solve, one colour at a time (groups of one colour
+//     hull pairs  -> GJK distance (portal refinement when the hulls overlap); NEW contact pairs get 4 tilted GJK runs for their
+//                    first manifold, the others refresh the persistent manifold the previous step filed
+//     groups      -> warm-started Gauss-Seidel contact solve, one colour at a time (groups of one colour
 //                    touch disjoint bodies, so lanes never race on a body's velocity)
 // Only + - * / sqrt and explicit fmaf are used and every reduction has a fixed order, so the
 // result is bit-identical to oracle/settle_ref.c (the parity contract) for any lane count.
@@ -1416,9 +1414,6 @@ __device__ __forceinline__ int compact_slot(bool pred, int count)
     return pred ? count + prefix : -1;
 }
 
-// ---------------------------------------------------------------------------------------------
-// the persistent per-scene kernel
-// ---------------------------------------------------------------------------------------------
 // exclusive prefix sum of a small per-lane count over the wave, plus the total
 __device__ __forceinline__ int wave_excl_scan(int v, int& total)
 {
@@ -1432,15 +1427,6 @@ __device__ __forceinline__ int wave_excl_scan(int v, int& total)
     total = __shfl(x, 63, 64);
     return x - v;
 }
-
-// ---------------------------------------------------------------------------------------------
-// LDS layout (dynamic): sized by the host from the batch maxima (slhip_settle_params hints)
-// ---------------------------------------------------------------------------------------------
-struct LdsLayout {
-    int nb_cap, lh_cap, hv_cap;   // bodies, local hulls, hull vertices (0 = vertices stay global)
-    int off_wb, off_lh, off_body_lh, off_hv, off_contacts, off_hp, off_hp_off, off_groups, off_misc;
-    int total;
-};
 
 // candidate hull pair, 32 bits: body a [0,6) | body b [6,12) | hull of a [12,22) | hull of b [22,32)
 // (hull numbers are local to their body: at most 1024 hulls per body)
@@ -1460,612 +1446,6 @@ struct Group { unsigned char a, b, begin, end, color; };
 constexpr int kNoBody = 0xff;
 static_assert(sizeof(Group) == 5, "Group layout");
 static_assert(SLHIP_MAX_ACTIVE_CONTACTS < 256 && SLHIP_MAX_BODIES <= 64, "byte-sized group fields");
-static_assert(SLHIP_MAX_HULL_PAIRS * 4 >= (kMaxGroups + 65) * 2, "the solver's colour order aliases the hull-pair list");
-
-__host__ __device__ inline LdsLayout make_layout(int nb_cap, int lh_cap, int hv_cap)
-{
-    LdsLayout L;
-    L.nb_cap = nb_cap; L.lh_cap = lh_cap; L.hv_cap = hv_cap;
-    int o = 0;
-    auto take = [&](int bytes) { const int r = o; o += (bytes + 15) & ~15; return r; };
-    L.off_wb = take(nb_cap * (int)sizeof(WBody));
-    L.off_lh = take(lh_cap * (int)sizeof(HullRef));
-    L.off_body_lh = take((nb_cap + 1) * 4);
-    L.off_contacts = take(kMaxActive * (int)sizeof(Contact));
-    L.off_hp = take(SLHIP_MAX_HULL_PAIRS * 4);
-    L.off_hp_off = take(SLHIP_MAX_HULL_PAIRS + 1);
-    int g_cap = nb_cap + nb_cap * (nb_cap - 1) / 2;   // plane groups + body pairs
-    if (g_cap > kMaxGroups) g_cap = kMaxGroups;
-    L.off_groups = take(g_cap * (int)sizeof(Group));
-    L.off_misc = take(nb_cap * 8 + nb_cap * 4 + nb_cap * 4 + 64 + 64 + 64);
-    L.off_hv = take(hv_cap * 12);
-    L.total = o;
-    return L;
-}
-
-#if 0   // persistent kernel: being ported to the persistent-manifold step
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_settle(const slhip_settle_scene* __restrict__ scenes, slhip_body* bodies_all,
-                                               const slhip_hull* __restrict__ hulls,
-                                               const float* __restrict__ hull_verts, slhip_settle_params prm,
-                                               LdsLayout L, ProfScratch* prof_all, DriveAcc* drive_all,
-                                               GjkSeed* cache_all, unsigned cache_stride, int continued)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    WBody* wb = reinterpret_cast<WBody*>(smem + L.off_wb);
-    HullRef* lh = reinterpret_cast<HullRef*>(smem + L.off_lh);
-    int* body_lh = reinterpret_cast<int*>(smem + L.off_body_lh);
-    f3* hv = reinterpret_cast<f3*>(smem + L.off_hv);
-    Contact* ac = reinterpret_cast<Contact*>(smem + L.off_contacts);
-    unsigned* hp = reinterpret_cast<unsigned*>(smem + L.off_hp);
-    unsigned char* hp_off = reinterpret_cast<unsigned char*>(smem + L.off_hp_off);   // contacts per pair, then their prefix
-    Group* groups = reinterpret_cast<Group*>(smem + L.off_groups);
-    unsigned long long* used = reinterpret_cast<unsigned long long*>(smem + L.off_misc);
-    int* wake = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 8);
-    int* sep_key = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 12);   // min separation, ordered-int
-    int* counters = reinterpret_cast<int*>(smem + L.off_misc + L.nb_cap * 16);  // [0]=n_groups [1]=n_colors
-    unsigned char* plist = reinterpret_cast<unsigned char*>(smem + L.off_misc + L.nb_cap * 16 + 64);   // bodies near the plane
-    unsigned char* cpl = plist + 64;                 // lanes of the contact pairs of a narrowphase window
-    BandPt* band = reinterpret_cast<BandPt*>(hp);    // plane phase only: 4 x kBandCap cached in-band vertices
-    unsigned short* order = reinterpret_cast<unsigned short*>(hp);   // solver only: groups sorted by colour ...
-    unsigned short* cstart = order + kMaxGroups;                     // ... and each colour's first slot
-    const float4* gv = reinterpret_cast<const float4*>(hull_verts);
-    DriveAcc* drv = drive_all + (size_t)blockIdx.x * SLHIP_MAX_BODIES;
-
-    const slhip_settle_scene sc = scenes[blockIdx.x];
-    slhip_body* bodies = bodies_all + sc.body_begin;
-    const int nb = (int)(sc.body_end - sc.body_begin);
-#ifdef SLHIP_SETTLE_PROFILE
-    ProfScratch& X = prof_all[blockIdx.x];
-#endif
-    const int lane = threadIdx.x;
-    const float dt = prm.dt;
-    if (nb > L.nb_cap) {  // host sizing error: refuse rather than corrupt LDS, and say so (slhip_settle_status)
-        if (lane == 0) prof_all[blockIdx.x].status = SLHIP_SETTLE_REFUSED_BODIES;
-        return;
-    }
-    if (lane == 0) prof_all[blockIdx.x].status = 0;
-
-    // ---- prologue (once per settle): local hull table, hull vertices into LDS ----
-    // serial over bodies/hulls (<= a few hundred), lanes copy the vertices
-    {
-        int n_lh = 0, n_hv = 0;
-        bool fits = true;
-        for (int i = 0; i < nb; ++i) {
-            const int h0 = (int)bodies[i].hull_begin, h1 = (int)bodies[i].hull_end;
-            if (lane == 0) body_lh[i] = n_lh;
-            for (int h = h0; h < h1; ++h) {
-                const int cnt = (int)hulls[h].vtx_count;
-                if (n_lh >= L.lh_cap || h1 - h0 > kMaxHullsPerBody) { fits = false; break; }
-                const bool in_lds = n_hv + cnt <= L.hv_cap;
-                if (lane == 0) {
-                    HullRef r;
-                    r.src = in_lds ? ~n_hv : (int)hulls[h].vtx_begin;
-                    r.count = cnt;
-                    r.sc = V(hulls[h].sphere[0], hulls[h].sphere[1], hulls[h].sphere[2]);
-                    r.sr = hulls[h].sphere[3];
-                    lh[n_lh] = r;
-                }
-                if (in_lds) {
-                    const float4* src = reinterpret_cast<const float4*>(hull_verts) + hulls[h].vtx_begin;
-                    for (int k = lane; k < cnt; k += 64) {
-                        const float4 q = src[k];
-                        f3 t; t.x = q.x; t.y = q.y; t.z = q.z;
-                        hv[n_hv + k] = t;
-                    }
-                    n_hv += cnt;
-                }
-                ++n_lh;
-            }
-            if (!fits) break;
-        }
-        if (lane == 0) body_lh[nb] = n_lh;
-        if (!fits) {  // more hulls than the host sized for
-            if (lane == 0) prof_all[blockIdx.x].status = SLHIP_SETTLE_REFUSED_HULLS;
-            return;
-        }
-    }
-    __syncthreads();
-    // pair cache (oracle scene_ws.cache): [n_hulls][n_hulls] seeds in global scratch, cleared per launch;
-    // scenes with more than SLHIP_PAIR_CACHE_MAX_HULLS hulls run without it
-    const int n_hulls = body_lh[nb];
-    GjkSeed* cache = nullptr;
-    if (n_hulls > 0 && n_hulls <= SLHIP_PAIR_CACHE_MAX_HULLS && (unsigned)(n_hulls * n_hulls) <= cache_stride) {
-        cache = cache_all + (size_t)blockIdx.x * cache_stride;
-        int4* z = reinterpret_cast<int4*>(cache);
-        // a settle may be launched in segments of frames (slhip_settle): everything a scene carries from step to step
-        // lives in global memory (bodies, pair cache, drive accumulators), so a continuation only keeps the cache
-        if (!continued)
-            for (int k = lane; k < n_hulls * n_hulls; k += 64) z[k] = make_int4(0, 0, 0, 0);
-    }
-    __syncthreads();
-
-    for (unsigned frame = 0; frame < prm.frames; ++frame) {
-        for (unsigned sub_ = 0; sub_ < prm.substeps; ++sub_) {
-            PROF_T0();
-            // (a) load, integrate forces
-            for (int i = lane; i < nb; i += 64) {
-                load_body(bodies[i], wb[i]);
-                update_world_inertia(bodies[i], wb[i]);
-                if (wb[i].dynamic) {
-                    wb[i].v = madd(wb[i].v, V(prm.gravity[0], prm.gravity[1], prm.gravity[2]), dt);
-                    float damp = 1.0f - prm.angular_damping * dt;
-                    if (damp < 0.0f) damp = 0.0f;
-                    wb[i].w = scale(wb[i].w, damp);
-                }
-                if (bodies[i].drive_flags & 1u) {
-                    DriveAcc z;
-                    z.dl[0] = z.dl[1] = z.dl[2] = z.da[0] = z.da[1] = z.da[2] = 0.0f;
-                    drv[i] = z;
-                }
-                wake[i] = 0;
-                sep_key[i] = 0x7f7fffff;  // ordered key of the largest finite float (>= kInf)
-            }
-            __syncthreads();
-            PROF(0);
-
-            int n_groups = 0;  // wave-uniform running counters
-            int n_active = 0;
-
-            // (b) plane contacts first, groups + contacts appended in body order.  Lanes = bodies for the
-            // bounding-sphere test; the survivors are then handled four at a time, one 16-lane
-            // sub-group per body (plane_contacts_sg16)
-            if (sc.has_plane) {
-                int off_run = n_active;
-                for (int base = 0; base < nb; base += 64) {
-                    const int i = base + lane;
-                    bool pass = false;
-                    if (i < nb && wb[i].dynamic) {
-                        const v3 ci = add(m3_mul(wb[i].R, V(bodies[i].bsphere[0], bodies[i].bsphere[1], bodies[i].bsphere[2])), wb[i].t);
-                        const float vz = wb[i].v.z < 0.0f ? -wb[i].v.z * dt : 0.0f;
-                        pass = !(ci.z - bodies[i].bsphere[3] - sc.plane_z > prm.contact_offset + vz);
-                    }
-                    const int rank = compact_slot(pass, 0);
-                    const int n_pass = __popcll(__ballot(pass));
-                    if (pass) plist[rank] = (unsigned char)lane;
-                    __syncthreads();
-                    const int sg = lane >> 4, sl = lane & 15;
-                    for (int r0 = 0; r0 < n_pass; r0 += 4) {
-                        const bool on = r0 + sg < n_pass;
-                        const int bi = on ? base + (int)plist[r0 + sg] : 0;
-                        RawContacts rc;
-                        rc.count = 0;
-                        if (on) {
-                            const float vz = wb[bi].v.z < 0.0f ? -wb[bi].v.z * dt : 0.0f;
-                            plane_contacts_sg16(wb[bi], lh, hv, gv, body_lh[bi], body_lh[bi + 1], sc.plane_z,
-                                                prm.contact_offset + vz, band + sg * kBandCap, sg, sl, rc);
-                        }
-                        const int c0 = __shfl(rc.count, 0, 64), c1 = __shfl(rc.count, 16, 64), c2 = __shfl(rc.count, 32, 64);
-                        const int c3 = __shfl(rc.count, 48, 64);
-                        const int off = off_run + (sg > 0 ? c0 : 0) + (sg > 1 ? c1 : 0) + (sg > 2 ? c2 : 0);
-                        if (on) {
-                            if (sl < rc.count && off + sl < kMaxActive) {
-                                const float e = 0.5f * (bodies[bi].restitution + prm.plane_restitution);
-                                const v3 pa = vsel(sl == 0, rc.pa[0], vsel(sl == 1, rc.pa[1], vsel(sl == 2, rc.pa[2], rc.pa[3])));
-                                const float sp = sl == 0 ? rc.sep[0] : sl == 1 ? rc.sep[1] : sl == 2 ? rc.sep[2] : rc.sep[3];
-                                fill_contact(&ac[off + sl], bi, -1, wb[bi], nullptr, pa, V(pa.x, pa.y, sc.plane_z), rc.n, sp,
-                                             prm.rest_offset, e, sl == 0);
-                            }
-                            if (sl == 0) {
-                                Group G;
-                                G.a = (unsigned char)bi; G.b = (unsigned char)kNoBody;
-                                G.begin = (unsigned char)min(off, kMaxActive); G.end = (unsigned char)min(off + rc.count, kMaxActive);
-                                G.color = 0;
-                                groups[n_groups + r0 + sg] = G;
-                            }
-                        }
-                        off_run += c0 + c1 + c2 + c3;
-                        __syncthreads();   // the band cache is reused by the next round
-                    }
-                    n_groups += n_pass;
-                }
-                n_active = min(off_run, kMaxActive);
-            }
-            const int n_plane_groups = n_groups;
-            const int n_active_before_pairs = n_active;
-            PROF(1);
-
-            // (c) broadphase: body pairs in (i<j) order -> hull pairs, ballot-compacted in order
-            int n_hp = 0;
-            {
-                const int n_pairs = nb * (nb - 1) / 2;
-                for (int base = 0; base < n_pairs; base += 64) {
-                    const int p = base + lane;
-                    bool pass = false;
-                    int pi = 0, pj = 0;
-                    if (p < n_pairs) {
-                        int rem = p, row = nb - 1;
-                        while (rem >= row) { rem -= row; ++pi; --row; }
-                        pj = pi + 1 + rem;
-                        if (wb[pi].dynamic || wb[pj].dynamic) {
-                            const v3 ci = add(m3_mul(wb[pi].R, V(bodies[pi].bsphere[0], bodies[pi].bsphere[1], bodies[pi].bsphere[2])), wb[pi].t);
-                            const v3 cj = add(m3_mul(wb[pj].R, V(bodies[pj].bsphere[0], bodies[pj].bsphere[1], bodies[pj].bsphere[2])), wb[pj].t);
-                            const v3 dv = sub(wb[pi].v, wb[pj].v);
-                            const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
-                            const v3 d = sub(ci, cj);
-                            const float rr = bodies[pi].bsphere[3] + bodies[pj].bsphere[3] + margin;
-                            pass = !(dot(d, d) > rr * rr);
-                        }
-                    }
-                    unsigned long long mask = __ballot(pass);
-                    while (mask) {
-                        const int src = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        const int i = __shfl(pi, src, 64), j = __shfl(pj, src, 64);
-                        const int la0 = body_lh[i], na = body_lh[i + 1] - la0;
-                        const int lb0 = body_lh[j], nbh = body_lh[j + 1] - lb0;
-                        const unsigned ga0 = bodies[i].hull_begin, gb0 = bodies[j].hull_begin;
-                        const v3 dv = sub(wb[i].v, wb[j].v);
-                        const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
-                        const int first = n_hp;
-                        const int combos = na * nbh;
-                        for (int cb = 0; cb < combos; cb += 64) {
-                            const int q = cb + lane;
-                            bool ok = false;
-                            int a = 0, b = 0;
-                            if (q < combos) {
-                                a = q / nbh; b = q % nbh;
-                                const HullRef& A = lh[la0 + a];
-                                const HullRef& B = lh[lb0 + b];
-                                const v3 ca = add(m3_mul(wb[i].R, A.sc), wb[i].t);
-                                const v3 cbw = add(m3_mul(wb[j].R, B.sc), wb[j].t);
-                                const v3 dd = sub(ca, cbw);
-                                const float r2 = A.sr + B.sr + margin;
-                                ok = !(dot(dd, dd) > r2 * r2);
-                                if (ok) ok = aabb_overlap(wb[i], hulls[ga0 + a], wb[j], hulls[gb0 + b], margin);
-                            }
-                            const int slot = compact_slot(ok, n_hp);
-                            if (ok && slot < SLHIP_MAX_HULL_PAIRS) hp[slot] = hp_pack(i, j, a, b);
-                            n_hp = min(n_hp + (int)__popcll(__ballot(ok)), (int)SLHIP_MAX_HULL_PAIRS);
-                        }
-                        if (n_hp > first) {
-                            if (lane == 0) {
-                                Group G;
-                                G.a = (unsigned char)i; G.b = (unsigned char)j;
-                                G.begin = 0; G.end = 0;   // contact range: filled in after the narrowphase
-                                G.color = 0;
-                                groups[n_groups] = G;
-                            }
-                            ++n_groups;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            PROF(2);
-            PROF_COUNT(0, n_hp);
-
-            // (d) narrowphase in windows of 64 hull pairs:
-            //   d1  lane = hull pair: plain GJK (most pairs leave through the margin early-out); the
-            //       result stays in the lane's registers, the lanes of the contact pairs are listed
-            //       (in order) in cpl
-            //   d2  lane = (contact pair, tilt run): fetches the pair's main result with shuffles and
-            //       does one of the four tilted GJK runs, 16 pairs per pass
-            //   d3  the tilt-0 lane of every pair gathers the candidates with shuffles, rejects
-            //       duplicates, reduces the manifold and appends the contacts in pair order
-            for (int k = lane; k <= n_hp; k += 64) hp_off[k] = 0;
-            __syncthreads();
-            for (int base = 0; base < n_hp; base += 64) {
-                const int k = base + lane;
-                MainResult mr;
-                mr.type = 0; mr.dist = 0.0f;
-                mr.n = V(0, 0, 0); mr.pa = V(0, 0, 0); mr.pb = V(0, 0, 0);
-                mr.seed.n = 0; mr.seed.i0 = mr.seed.i1 = mr.seed.i2 = 0;
-                if (k < n_hp) {
-                    const unsigned e = hp[k];
-                    const int ba = hp_ba(e), bb = hp_bb(e);
-                    const v3 dv = sub(wb[ba].v, wb[bb].v);
-                    const float margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
-                    const int la = body_lh[ba] + hp_ha(e), lb = body_lh[bb] + hp_hb(e);
-                    GjkSeed cached;
-                    cached.n = 0; cached.i0 = cached.i1 = cached.i2 = 0;
-                    GjkSeed* slot_c = cache ? cache + (size_t)la * n_hulls + lb : nullptr;
-                    if (slot_c) {
-                        const int4 q = *reinterpret_cast<const int4*>(slot_c);
-                        cached.n = q.x; cached.i0 = q.y; cached.i1 = q.z; cached.i2 = q.w;
-                    }
-                    const bool rewrite = pair_main(wb[ba], wb[bb], lh[la], lh[lb], hv, gv, margin, cached, mr);
-                    if (slot_c && rewrite) *reinterpret_cast<int4*>(slot_c) = make_int4(mr.seed.n, mr.seed.i0, mr.seed.i1, mr.seed.i2);
-                }
-                PROF(12);   // d1: main GJK
-                const int slot = compact_slot(mr.type != 0, 0);
-                const int ncp = __popcll(__ballot(mr.type != 0));
-                if (mr.type != 0) cpl[slot] = (unsigned char)lane;
-                __syncthreads();
-                for (int ib = 0; ib < 4 * ncp; ib += 64) {
-                    const int item = ib + lane;
-                    const int m = item >> 2, t = item & 3;
-                    const bool on = m < ncp;
-                    const int src = on ? (int)cpl[m] : lane;
-                    MainResult mm;
-                    mm.type = __shfl(mr.type, src, 64);
-                    mm.n = V(__shfl(mr.n.x, src, 64), __shfl(mr.n.y, src, 64), __shfl(mr.n.z, src, 64));
-                    mm.pa = V(__shfl(mr.pa.x, src, 64), __shfl(mr.pa.y, src, 64), __shfl(mr.pa.z, src, 64));
-                    mm.pb = V(__shfl(mr.pb.x, src, 64), __shfl(mr.pb.y, src, 64), __shfl(mr.pb.z, src, 64));
-                    mm.dist = __shfl(mr.dist, src, 64);
-                    mm.seed.n = __shfl(mr.seed.n, src, 64);
-                    mm.seed.i0 = __shfl(mr.seed.i0, src, 64); mm.seed.i1 = __shfl(mr.seed.i1, src, 64);
-                    mm.seed.i2 = __shfl(mr.seed.i2, src, 64);
-                    const int kk = base + src;   // hull pair of this item
-                    bool have = false;
-                    v3 qa = V(0, 0, 0), qb = V(0, 0, 0);
-                    float sp = 0.0f;
-                    int bi = 0, bj = 0;
-                    float margin = 0.0f, radius = 1.0f;
-                    if (on) {
-                        const unsigned e = hp[kk];
-                        bi = hp_ba(e); bj = hp_bb(e);
-                        const v3 dv = sub(wb[bi].v, wb[bj].v);
-                        margin = 2.0f * prm.contact_offset + sqrtf(dot(dv, dv)) * dt;
-                        const HullRef& ha = lh[body_lh[bi] + hp_ha(e)];
-                        const HullRef& hb = lh[body_lh[bj] + hp_hb(e)];
-                        radius = ha.sr <= hb.sr ? ha.sr : hb.sr;
-                        if (mm.type == 1) have = pair_tilt(wb[bi], wb[bj], ha, hb, hv, gv, prm, margin, mm.n, mm.seed, t, &qa, &qb, &sp);
-                    }
-                    PROF(14);   // d2: tilt runs
-                    // gather the four candidates of a pair into its tilt-0 lane
-                    Cand5 c;
-                    c.ok = 0u;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int from = (lane & ~3) + q;
-                        c.p[q + 1] = V(__shfl(qa.x, from, 64), __shfl(qa.y, from, 64), __shfl(qa.z, from, 64));
-                        c.q[q + 1] = V(__shfl(qb.x, from, 64), __shfl(qb.y, from, 64), __shfl(qb.z, from, 64));
-                        c.s[q + 1] = __shfl(sp, from, 64);
-                        c.ok |= (unsigned)(__shfl(have ? 1 : 0, from, 64) != 0) << (q + 1);
-                    }
-                    RawContacts rc;
-                    rc.count = 0;
-                    if (on && t == 0) {
-                        float smin;
-                        if (mm.type == 2) {
-                            rc.n = mm.n; rc.pa[0] = mm.pa; rc.pb[0] = mm.pb; rc.sep[0] = mm.dist; rc.count = 1;
-                            smin = mm.dist;
-                        } else {
-                            smin = pair_finish(mm, c, radius, rc);
-                        }
-                        int key = __float_as_int(smin);
-                        key = key >= 0 ? key : key ^ 0x7fffffff;
-                        atomicMin(&sep_key[bi], key);
-                        atomicMin(&sep_key[bj], key);
-                    }
-                    int total;
-                    const int off = n_active + wave_excl_scan(rc.count, total);
-                    if (rc.count > 0) {
-                        const float rest = 2.0f * prm.rest_offset;
-                        const float e = 0.5f * (bodies[bi].restitution + bodies[bj].restitution);
-                        int written = 0;
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc)
-                            if (cc < rc.count && off + cc < kMaxActive) {
-                                fill_contact(&ac[off + cc], bi, bj, wb[bi], &wb[bj], rc.pa[cc], rc.pb[cc], rc.n, rc.sep[cc], rest, e, cc == 0);
-                                ++written;
-                            }
-                        hp_off[kk] = (unsigned char)written;
-                    }
-                    n_active = min(n_active + total, kMaxActive);
-                }
-                __syncthreads();
-                PROF(13);   // d2 + d3: tilt runs, manifold, contact fill
-            }
-            // contact offsets per hull pair: exclusive prefix of the counts, in place
-            {
-                int run = n_active_before_pairs;
-                for (int base = 0; base < n_hp; base += 64) {
-                    const int k = base + lane;
-                    const int cnt = k < n_hp ? (int)hp_off[k] : 0;
-                    int total;
-                    const int off = run + wave_excl_scan(cnt, total);
-                    if (k < n_hp) hp_off[k] = (unsigned char)off;
-                    run += total;
-                }
-                if (lane == 0) hp_off[n_hp] = (unsigned char)run;
-            }
-            __syncthreads();
-            PROF(3);
-            // pair groups were appended in hull-pair order: a group's contact range runs from the
-            // offset of its first hull pair to the end of its last one; min separation per body
-            {
-                int gi = n_plane_groups;
-                for (int base = 0; base < n_hp; base += 64) {
-                    const int k = base + lane;
-                    bool first = false, last = false;
-                    if (k < n_hp) {
-                        const unsigned key = hp[k] & 0xfffu;
-                        first = k == 0 || (hp[k - 1] & 0xfffu) != key;
-                        last = k == n_hp - 1 || (hp[k + 1] & 0xfffu) != key;
-                    }
-                    const unsigned long long fm = __ballot(first);
-                    const int gk = gi + (int)__popcll(fm & ((2ull << lane) - 1ull)) - 1;
-                    if (first) groups[gk].begin = hp_off[k];
-                    if (last) groups[gk].end = hp_off[k + 1];
-                    gi += (int)__popcll(fm);
-                }
-            }
-            for (int i = lane; i < nb; i += 64) {
-                int key = sep_key[i];
-                key = key >= 0 ? key : key ^ 0x7fffffff;
-                const float sv = __int_as_float(key);
-                bodies[i].separation = sv > kInf ? kInf : sv;
-            }
-            __syncthreads();
-            PROF(4);
-
-            // wake sleeping bodies touched by a moving body (pair groups only)
-            {
-                const float touch = 2.0f * prm.contact_offset - 2.0f * prm.rest_offset;  // sep < 2 co
-                for (int g = n_plane_groups + lane; g < n_groups; g += 64) {
-                    const Group G = groups[g];
-                    bool touching = false;
-                    for (int c = G.begin; c < G.end; ++c)
-                        if (ac[c].err + 2.0f * prm.rest_offset < 2.0f * prm.contact_offset) touching = true;
-                    (void)touch;
-                    if (!touching) continue;
-                    for (int s = 0; s < 2; ++s) {
-                        const int me = s ? G.b : G.a, other = s ? G.a : G.b;   // pair groups: both are bodies
-                        if ((bodies[me].flags & SLHIP_BODY_ASLEEP) && wb[other].dynamic) {
-                            const float en = 0.5f * dot(wb[other].v, wb[other].v);
-                            if (en > prm.sleep_threshold) wake[me] = 1;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            for (int i = lane; i < nb; i += 64)
-                if (wake[i]) {
-                    bodies[i].flags &= ~SLHIP_BODY_ASLEEP;
-                    bodies[i].wake_counter = prm.wake_time;
-                }
-            PROF(5);
-
-            // (f) prep
-            for (int c = lane; c < n_active; c += 64) prep_contact(&ac[c], wb, prm.bounce_threshold, 1.0f / prm.dt);
-            PROF(6);
-            // (g) greedy colouring, largest group first (oracle color_groups): every lane ranks its group by
-            // (contacts descending, index ascending), the ranked list goes to `order` (rewritten below),
-            // lane 0 walks it -- the greedy pass itself is serial by definition
-            for (int g0 = 0; g0 < n_groups; g0 += 64) {
-                const int g = g0 + lane;
-                if (g < n_groups) {
-                    const int sz = (int)groups[g].end - (int)groups[g].begin;
-                    int rank = 0;
-                    for (int h = 0; h < n_groups; ++h) {
-                        const int sh = (int)groups[h].end - (int)groups[h].begin;
-                        rank += (sh > sz || (sh == sz && h < g)) ? 1 : 0;
-                    }
-                    order[rank] = (unsigned short)g;
-                }
-            }
-            __syncthreads();
-            if (lane == 0) {
-                for (int i = 0; i < nb; ++i) used[i] = 0ull;
-                int ncol = 0;
-                for (int q = 0; q < n_groups; ++q) {
-                    const int g = order[q];
-                    const int a = groups[g].a, b = groups[g].b == kNoBody ? -1 : (int)groups[g].b;
-                    unsigned long long m = used[a];
-                    if (b >= 0) m |= used[b];
-                    int c = 0;
-                    while (c < 63 && ((m >> c) & 1ull)) ++c;
-                    groups[g].color = (unsigned char)c;
-                    used[a] |= 1ull << c;
-                    if (b >= 0) used[b] |= 1ull << c;
-                    if (c + 1 > ncol) ncol = c + 1;
-                }
-                counters[1] = ncol;
-            }
-            __syncthreads();
-            const int ncol = counters[1];
-            // groups listed colour by colour (ballot + popcount prefix, in group order); the list and the
-            // colour offsets alias the hull-pair list, which is dead until the next broadphase
-            {
-                int base = 0;
-                for (int col = 0; col < ncol; ++col) {
-                    if (lane == 0) cstart[col] = (unsigned short)base;
-                    for (int g0 = 0; g0 < n_groups; g0 += 64) {
-                        const int g = g0 + lane;
-                        const bool p = g < n_groups && groups[g].color == col;
-                        const int slot = compact_slot(p, base);
-                        if (p) order[slot] = (unsigned short)g;
-                        base += __popcll(__ballot(p));
-                    }
-                }
-                if (lane == 0) cstart[ncol] = (unsigned short)base;
-            }
-            __syncthreads();
-            PROF(7);
-            PROF_COUNT(2, n_groups); PROF_COUNT(3, ncol); PROF_COUNT(1, n_active);
-
-            // (h) position iterations
-            const float inv_dt = 1.0f / prm.dt;
-            for (unsigned it = 0; it < prm.pos_iters; ++it) {
-                for (int col = 0; col < ncol; ++col) {
-                    const int ce = cstart[col + 1];
-                    for (int k = cstart[col] + (lane >> 1); k < ce; k += 32) {   // a lane pair per group
-                        const Group G = groups[order[k]];
-                        solve_group(ac, G.begin, G.end, G.a, G.b == kNoBody ? -1 : (int)G.b, lane & 1, wb, inv_dt, true, prm.plane_mu_s, prm.plane_mu_d);
-                    }
-                    __syncthreads();
-                }
-                for (int i = lane; i < nb; i += 64) solve_drive(bodies[i], wb[i], drv[i], prm, true);
-                __syncthreads();
-            }
-            PROF(8);
-
-            // (i) integrate poses
-            for (int i = lane; i < nb; i += 64) {
-                if (!wb[i].dynamic) continue;
-                const float lim = bodies[i].max_lin_vel;
-                const float vv = dot(wb[i].v, wb[i].v);
-                if (lim > 0.0f && vv > lim * lim) wb[i].v = scale(wb[i].v, lim / sqrtf(vv));
-                const float ww = dot(wb[i].w, wb[i].w);
-                const float wl = prm.max_angular_velocity;
-                if (ww > wl * wl) wb[i].w = scale(wb[i].w, wl / sqrtf(ww));
-                wb[i].x = madd(wb[i].x, wb[i].v, dt);
-                quat wq; wq.x = wb[i].w.x; wq.y = wb[i].w.y; wq.z = wb[i].w.z; wq.w = 0.0f;
-                const quat dq = quat_mul(wq, wb[i].q);
-                quat q;
-                q.x = fmaf(0.5f * dt, dq.x, wb[i].q.x); q.y = fmaf(0.5f * dt, dq.y, wb[i].q.y);
-                q.z = fmaf(0.5f * dt, dq.z, wb[i].q.z); q.w = fmaf(0.5f * dt, dq.w, wb[i].q.w);
-                wb[i].q = quat_normalize(q);
-            }
-            __syncthreads();
-            PROF(9);
-
-            // (j) velocity iterations
-            for (unsigned it = 0; it < prm.vel_iters; ++it) {
-                for (int col = 0; col < ncol; ++col) {
-                    const int ce = cstart[col + 1];
-                    for (int k = cstart[col] + (lane >> 1); k < ce; k += 32) {   // a lane pair per group
-                        const Group G = groups[order[k]];
-                        solve_group(ac, G.begin, G.end, G.a, G.b == kNoBody ? -1 : (int)G.b, lane & 1, wb, inv_dt, false, prm.plane_mu_s, prm.plane_mu_d);
-                    }
-                    __syncthreads();
-                }
-                for (int i = lane; i < nb; i += 64) solve_drive(bodies[i], wb[i], drv[i], prm, false);
-                __syncthreads();
-            }
-            PROF(10);
-
-            // (k) store + sleep bookkeeping
-            for (int i = lane; i < nb; i += 64) {
-                if (!wb[i].dynamic) continue;
-                quat_to_m3(wb[i].q, wb[i].R);
-                wb[i].t = sub(wb[i].x, m3_mul(wb[i].R, V(bodies[i].com[0], bodies[i].com[1], bodies[i].com[2])));
-                const float r = bodies[i].bsphere[3];
-                const float en = 0.5f * (dot(wb[i].v, wb[i].v) + r * r * dot(wb[i].w, wb[i].w));
-                if (en >= prm.sleep_threshold || (bodies[i].drive_flags & 1u)) bodies[i].wake_counter = prm.wake_time;
-                else {
-                    bodies[i].wake_counter -= dt;
-                    if (bodies[i].wake_counter <= 0.0f) {
-                        bodies[i].flags |= SLHIP_BODY_ASLEEP;
-                        wb[i].v = V(0, 0, 0);
-                        wb[i].w = V(0, 0, 0);
-                    }
-                }
-                store_body(bodies[i], wb[i]);
-            }
-            __threadfence_block();
-            __syncthreads();
-            PROF(11);
-        }
-        // redrop heuristic of simulateTableTopScene (scene.cpp:742-755), serial
-        if (prm.tabletop) {
-            if (lane == 0) {
-                for (int i = 0; i < nb; ++i) {
-                    if (bodies[i].flags & SLHIP_BODY_STATIC) continue;
-                    if (bodies[i].pose[11] < prm.redrop_z) redrop(bodies, nb, i, prm);
-                    else if (bodies[i].separation < prm.stuck_separation) {
-                        if (++bodies[i].stuck_counter > prm.stuck_frames) redrop(bodies, nb, i, prm);
-                    } else if (bodies[i].stuck_counter > 0) bodies[i].stuck_counter--;
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
-    }
-}
-
-#endif
 
 // boolean overlap (scene.cpp:355-385): one lane per body
 __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __restrict__ scenes,
@@ -2197,20 +1577,6 @@ extern "C" int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5
     return 0;
 }
 
-// Two implementations of the same step (same device functions, bit-identical results, both parity-tested):
-//   lockstep     slhip_settle_wide.inc: six launches per step over the whole batch, state in HBM / L2
-//   persistent   k_settle: one wave per scene for the whole settle, scene state in LDS
-// Which one runs is a matter of speed only (profiles/r02).  Large batches: lockstep -- a settle of 16384 C2
-// scenes takes 1.19 s against 1.59 s, and its short kernels share the GPU with the render stream where the persistent
-// workgroups (256 VGPRs, ~150 ms lifetime) make it wait.  Small batches: persistent -- up to ~1000 scenes everything is resident
-// at once and a step costs one pass through LDS instead of six launches through L2 (64 scenes 256 against 365 ms, 1024 scenes
-// 368 against 452 ms; 2048: 454 against 470; 4096: 738 against 515).  SLHIP_SETTLE_IMPL=lockstep / persistent overrides.
-static bool use_persistent_settle(uint32_t n_scenes)
-{
-    (void)n_scenes;
-    return false;
-}
-
 extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out)
 {
     if (!bytes_out) {
@@ -2240,7 +1606,7 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         slhip::set_error("slhip_settle: at most %d bodies per scene", SLHIP_MAX_BODIES);
         return -1;
     }
-    if (!use_persistent_settle(n_scenes)) {
+    {
         const int lhc = hint_lh_cap(params);
         if (n_scenes > 65535u) {
             slhip::set_error("slhip_settle: at most 65535 scenes per launch");
@@ -2300,8 +1666,29 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         SLHIP_LAUNCH_CHECK();
         return 0;
     }
-    slhip::set_error("slhip_settle: no implementation selected");
-    return -1;
+}
+
+// Cap saturation of the last slhip_settle call on this scratch: the number of (scene, step) pairs in which the pair groups offered
+// more contacts than SLHIP_MAX_ACTIVE_CONTACTS left room for (the fair cut of k_w_finish applied), and in which the broadphase found
+// more than SLHIP_MAX_HULL_PAIRS hull pairs (the rest were dropped).  The reference's PhysX has neither cap (scene.cpp:738-739).
+extern "C" int slhip_settle_caps(const void* d_scratch, uint32_t n_scenes, const slhip_settle_params* params,
+                                 uint64_t* contact_cap_steps, uint64_t* pair_cap_steps, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_scratch || !params || !contact_cap_steps || !pair_cap_steps) {
+        slhip::set_error("slhip_settle_caps: null argument");
+        return -1;
+    }
+    *contact_cap_steps = 0; *pair_cap_steps = 0;
+    if (n_scenes == 0) return 0;
+    const int nb_cap = hint_nb_cap(params);
+    const char* base = reinterpret_cast<const char*>(d_scratch) + settle_fixed_bytes(n_scenes) + settle_cache_bytes(n_scenes, params);
+    const WideBufs W = wide_carve(const_cast<char*>(base), n_scenes, nb_cap, hint_lh_cap(params));
+    std::vector<unsigned> h((size_t)n_scenes * 2);
+    SLHIP_CHECK(hipMemcpyAsync(h.data(), W.caps, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    SLHIP_CHECK(hipStreamSynchronize(stream));
+    for (uint32_t i = 0; i < n_scenes; ++i) { *contact_cap_steps += h[2 * i]; *pair_cap_steps += h[2 * i + 1]; }
+    return 0;
 }
 
 extern "C" int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_status, uint32_t* h_n_refused,

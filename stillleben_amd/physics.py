@@ -66,7 +66,36 @@ class SettleEngine:
             st = eng.L.slhip_settle_status(_abi_ptr(scratch), n_scenes, None, C.byref(bad), C.c_void_p(stream))
         _abi.check(st, "slhip_settle")
 
-    def run_device(self, srec, bodies, params, d_bodies=None):
+    def run_with_status(self, srec, bodies, params, **hints):
+        """run() with explicit sizing hints; returns (bodies, per-scene status words) instead of raising on refused scenes."""
+        d_bodies = self.run_device(srec, bodies, params, hints=hints)
+        eng = self.eng
+        stream = torch.cuda.current_stream(eng.device).cuda_stream
+        status = np.zeros(len(srec), np.uint32)
+        bad = C.c_uint32()
+        with torch.cuda.device(eng.device):
+            eng.L.slhip_settle_status(_abi_ptr(self._scratch[stream]), len(srec), C.c_void_p(status.ctypes.data), C.byref(bad),
+                                      C.c_void_p(stream))
+        return np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy(), status
+
+    def caps(self, n_scenes, stream=None):
+        """(contact-cap steps, pair-cap steps) of the last launch on `stream` (slhip_settle_caps)."""
+        eng = self.eng
+        if stream is None:
+            stream = torch.cuda.current_stream(eng.device).cuda_stream
+        a, b = C.c_uint64(), C.c_uint64()
+        prm = self._keep[stream][1]
+        with torch.cuda.device(eng.device):
+            st = eng.L.slhip_settle_caps(_abi_ptr(self._scratch[stream]), n_scenes, C.c_void_p(prm.ctypes.data), C.byref(a), C.byref(b),
+                                         C.c_void_p(stream))
+        _abi.check(st, "slhip_settle_caps")
+        return int(a.value), int(b.value)
+
+    def run_with_caps(self, srec, bodies, params):
+        out = self.run(srec, bodies, params)
+        return out, self.caps(len(srec))
+
+    def run_device(self, srec, bodies, params, d_bodies=None, hints=None):
         eng = self.eng
         d_hulls, d_verts = self.hulls_dev()
         d_s = eng.upload_records(srec)
@@ -75,7 +104,9 @@ class SettleEngine:
         stream = torch.cuda.current_stream(eng.device).cuda_stream
         if bodies is not None:
             params = SB.sizing_hints(params, srec, bodies, self.pool.arrays()[0])
-        prm = np.ascontiguousarray(params)
+        prm = np.ascontiguousarray(params).copy()
+        for k, v in (hints or {}).items():
+            prm[k] = v
         scratch = self.scratch(len(srec), stream, prm)
         with torch.cuda.device(eng.device):
             st = eng.L.slhip_settle(_abi_ptr(d_s), len(srec), _abi_ptr(d_bodies), _abi_ptr(d_hulls), _abi_ptr(d_verts),

@@ -74,12 +74,10 @@ def test_examples_ycb_call_sequence(slx):
     assert float(depth.max()) <= 3000.0
     # quirk q3: no light direction was chosen and there is no ambient light -> objects render black, like the reference
     assert int(rgb[inst[..., 0].cpu().numpy() > 0].max()) == 0
-    # settled: nothing below the table; like the reference's fixed-length simulation (scene.cpp:700-760) the call does not
-    # promise rest -- about 4 % of the objects of such heaps still move faster than 0.2 m/s (a can rolling, a re-dropped
-    # object still falling), and like the example the test does not seed the scene: at most two of the six (three or more
-    # happen once in ~800 runs)
+    # settled: nothing below the table, the heap at rest (like the example the test does not seed the scene: 97 % of the objects
+    # of such heaps are below 0.05 m/s after the 4 s, so one of the six may still roll)
     assert all(float(o.pose()[2, 3]) > 0.0 for o in scene.objects)
-    assert sum(float(o.linear_velocity.abs().max()) >= 0.2 for o in scene.objects) <= 2
+    assert sum(float(o.linear_velocity.abs().max()) >= 0.05 for o in scene.objects) <= 1
     # with a light the same frame shows the objects
     scene.choose_random_light_direction()
     lit = renderer.render(scene).rgb()[:, :, :3].cpu().numpy()

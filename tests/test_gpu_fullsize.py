@@ -3,8 +3,8 @@ through properties that do not need the CPU oracle to run 16384 settles (it woul
 
   * placement independence: a scene's random stream is keyed by its scene id, so scenes 7000..7063 of the big batch must
     come out bit for bit like a separate 64-scene batch staged at scene_id_base = 7000 -- other launch sizes, other
-    neighbours, other kernels (the small batch takes the persistent settle kernel, the big one the lockstep pipeline with its
-    cross-scene work lists, cost-ordered solver launch and two scenes per solver wave);
+    neighbours (cross-scene work lists of other lengths, another cost order of the solver launch, other partners in the solver
+    waves);
   * sanity of every body of every scene: finite, above the table, rotation orthonormal;
   * the oracle on a few of the scenes, bit for bit;
   * the rendered ground truth of a scene is the same bits whether it is rendered as slot 7000 - 6144 of a 1024-scene chunk
@@ -59,7 +59,8 @@ def test_full_step_is_placement_independent_and_sane(sl, oracle, table):
     R = pose[:, :3, :3].astype(np.float64)
     assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-4
     speed = np.linalg.norm(bb["lin_vel"][:, :3], axis=1)
-    assert 0.7 < np.mean(speed < 0.05) < 1.0                                 # most objects came to rest, not all (chaotic heaps)
+    assert np.mean(speed < 0.05) >= 0.95                                     # SURVEY 8c k6 on the full batch: the piles are at rest
+    assert np.mean((bb["flags"] & SB.BODY_ASLEEP) != 0) >= 0.85
     # the oracle on four of the scenes (full 400 steps)
     hulls, verts = big.se.pool.arrays()
     prm = np.array(big.settle_params)

@@ -222,9 +222,9 @@ def test_c2_bench_workload_full_launch(sl, oracle):
         a0, a1 = int(srec[i]["body_begin"]), int(srec[i]["body_end"])
         b0, b1 = int(srec[src]["body_begin"]), int(srec[src]["body_end"])
         assert_bodies_equal(gpu[a0:a1], gpu[b0:b1])
-    # the settle did something: most objects came to rest (a rolling can or a fresh redrop may still move)
-    speed = np.linalg.norm(gpu[:hi]["lin_vel"][:, :3], axis=1)
-    assert np.mean(speed < 0.05) > 0.7     # 0.82 over 96 such scenes (chaotic: 0.76-0.83 on these six)
+    # the piles are at rest (tests/test_oracle_k6.py holds the 64-scene figure: 97 %)
+    speed = np.linalg.norm(gpu["lin_vel"][:, :3], axis=1)
+    assert np.mean(speed < 0.05) >= 0.9
 
 
 def test_c2_soak_distinct_scenes(sl, oracle):
@@ -247,12 +247,10 @@ def test_c2_soak_distinct_scenes(sl, oracle):
     assert_bodies_equal(gpu, ref)
 
 
-@pytest.mark.parametrize("impl", ["lockstep", "persistent"])
-def test_physics_kat_scenarios_match_the_oracle(sl, oracle, impl, monkeypatch):
+def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
     """The scenarios of tests/test_oracle_physics_kat.py (tilted gravity, impacts above / below the bounce threshold,
     free spin, clamped spin, cube columns, head-on collision) through slhip_settle: bit-exact with the oracle, so the
     known answers checked there on the CPU hold for the HIP path as well."""
-    monkeypatch.setenv("SLHIP_SETTLE_IMPL", impl)     # small batches default to the persistent kernel: both are held to the oracle
     import math
 
     import test_oracle_physics_kat as K
@@ -265,7 +263,7 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle, impl, monkeypatch):
         (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015)]), dict(frames=100, gravity=(K.G * math.sin(th), 0.0, -K.G * math.cos(th)))),
         (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.05)], vel=[(0, 0, -3.9)]), dict(frames=40, dt=0.0025)),
         (K.build(sl, [K.at(0, 0, 1.0)], plane=False, vel=[(0.3, -0.2, 0.1)], ang=[(300.0, 0.0, 400.0)]), dict(frames=50, gravity=(0.0, 0.0, 0.0))),
-        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(5)]), dict(frames=300)),
+        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(6)]), dict(frames=400)),   # the column of six: warm start + persistent manifolds
         (K.build(sl, [K.at(-h - 0.02, 0, 1.0), K.at(h + 0.02, 0, 1.0)], plane=False, vel=[(1.5, 0, 0), (-1.5, 0, 0)]), dict(frames=30, dt=0.002, gravity=(0.0, 0.0, 0.0))),
     ]
     for (srec, bodies, hulls, verts), kw in cases:
@@ -284,25 +282,74 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle, impl, monkeypatch):
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
 
 
-def test_both_settle_implementations_are_bit_identical(sl, oracle, monkeypatch):
-    """The two implementations of the step -- the lockstep pipeline (default: six launches per step over the whole batch,
-    csrc/slhip_settle_wide.inc) and the persistent kernel (SLHIP_SETTLE_IMPL=persistent: one wave per scene for the whole
-    settle, optionally launched in segments of frames) -- give the oracle's bits: a batch of mixed scenes, tabletop settle."""
+def test_solver_wave_packing_and_odd_batches(sl, oracle, monkeypatch):
+    """The lockstep pipeline on a batch of mixed scenes (tabletop settle): two scenes per solver wave (default) and one give the
+    oracle's bits, also when the last solver wave holds a single scene."""
     cube = scaled(sl, S.CUBE, 0.15)
     bunny = scaled(sl, S.BUNNY, 0.2)
     scs = [heap(sl, 300 + i, 4 + 3 * i, cube, bunny) for i in range(6)]
-    monkeypatch.setenv("SLHIP_SETTLE_IMPL", "lockstep")
     gpu, ref = run_both(oracle, scs, frames=60)
     assert_bodies_equal(gpu, ref)
     gpu2, ref2 = run_both(oracle, scs + [heap(sl, 310, 9, cube, bunny)], frames=60)   # odd number: the last solver wave holds one scene
     assert_bodies_equal(gpu2, ref2)
-    monkeypatch.setenv("SLHIP_SOLVE_SPW", "1")        # the lockstep solver with one scene per wave instead of two
+    monkeypatch.setenv("SLHIP_SOLVE_SPW", "1")        # one scene per wave instead of two
     gpu1s, _ = run_both(oracle, scs, frames=60)
     assert_bodies_equal(gpu1s, ref)
-    monkeypatch.delenv("SLHIP_SOLVE_SPW")
-    monkeypatch.setenv("SLHIP_SETTLE_IMPL", "persistent")
-    gpu1, _ = run_both(oracle, scs, frames=60)
-    assert_bodies_equal(gpu1, ref)
-    monkeypatch.setenv("SLHIP_SETTLE_SEGMENTS", "4")
-    gpu4, _ = run_both(oracle, scs, frames=60)       # the persistent kernel launched in 4 segments of 15 frames
-    assert_bodies_equal(gpu4, ref)
+
+
+def test_refused_first_scene_leaves_the_others_exact(sl, oracle):
+    """A scene that exceeds the sizing hints is left untouched and reported -- also when it is scene 0, whose block clears the
+    per-step cost classes (round-2 advisor finding: the clear must not sit behind the refusal's early return)."""
+    from stillleben_amd import physics
+
+    cube = scaled(sl, S.CUBE, 0.15)
+    bunny = scaled(sl, S.BUNNY, 0.2)
+    scs = [heap(sl, 400, 6, cube, bunny)] + [heap(sl, 401 + i, 5, cube) for i in range(5)]   # scene 0 carries the many-hull bunny
+    se = physics.settle_engine()
+    srec, bodies = SB.build_settle_batch(scs, se.pool, [(True, TABLE)] * len(scs))
+    prm = SB.default_params(frames=30)
+    hulls, verts = se.pool.arrays()
+    n_h = (bodies["hull_end"] - bodies["hull_begin"]).astype(np.int64)
+    per_scene = [int(n_h[int(r["body_begin"]):int(r["body_end"])].sum()) for r in srec]
+    assert per_scene[0] > max(per_scene[1:])
+    status = se.run_with_status(srec, bodies.copy(), prm, max_hulls_per_scene=max(per_scene[1:]))
+    gpu, st = status
+    assert st[0] != 0 and (st[1:] == 0).all()
+    ref = bodies.copy()
+    oracle.settle(srec[1:], ref, hulls, verts, prm)      # scene 0 untouched on both sides
+    assert_bodies_equal(gpu, ref)
+
+
+def test_cap_saturation_is_counted(sl, oracle):
+    """slhip_settle_caps: the (scene, step) pairs whose contacts hit SLHIP_MAX_ACTIVE_CONTACTS / SLHIP_MAX_HULL_PAIRS, equal to the
+    oracle's count on the same batch (PhysX has no cap: the rate is reported, bench.py prints it)."""
+    import ctypes as C
+
+    from stillleben_amd import physics
+
+    cube = scaled(sl, S.CUBE, 0.12)
+    bunny = scaled(sl, S.BUNNY, 0.25)
+    scs = []
+    for i in range(4):                                    # bunnies (121 hulls each) dropped on each other: many hull pairs
+        scene = sl.Scene((320, 240), seed=500 + i)
+        for k in range(6):
+            scene.add_object(sl.Object(bunny if k < 4 else cube))
+        physics.prepare_tabletop(scene)
+        scs.append(scene)
+    se = physics.settle_engine()
+    srec, bodies = SB.build_settle_batch(scs, se.pool, [(True, TABLE)] * len(scs))
+    prm = SB.default_params(frames=40)
+    gpu, caps = se.run_with_caps(srec, bodies.copy(), prm)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    L = oracle.lib()
+    oc = np.zeros((len(scs), 4), np.uint32)
+    L.slref_settle_set_caps.argtypes = [C.c_void_p]
+    L.slref_settle_set_caps(C.c_void_p(oc.ctypes.data))
+    try:
+        oracle.settle(srec, ref, hulls, verts, prm)
+    finally:
+        L.slref_settle_set_caps(None)
+    assert_bodies_equal(gpu, ref)
+    assert caps == (int(oc[:, 0].sum()), int(oc[:, 1].sum()))
+    assert caps[0] > 0                                     # the case is exercised

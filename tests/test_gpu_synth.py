@@ -98,13 +98,11 @@ def _one_scene_records(batch, srec, drec, s):
     return rs, rd
 
 
-@pytest.mark.parametrize("impl", ["lockstep", "persistent"])
-def test_c3_shard_end_to_end_with_gather(sl, oracle, ycb_table, impl, monkeypatch):
+def test_c3_shard_end_to_end_with_gather(sl, oracle, ycb_table):
     """BASELINE config C3, one GPU's share: 64 scenes x 20 YCB-like objects, staged, settled (400 steps), placed and
     rendered at 640x480 (6-channel GT, shadows + SSAO) in two 32-scene chunks, gathered through the C-ABI
     all-gather (RCCL, one rank).  Oracle parity: the settle of 4 scenes bit-exact, the render of 4 scenes
     (integer outputs, coordinates / depth, normals bit-exact; rgb to the 8-bit bar)."""
-    monkeypatch.setenv("SLHIP_SETTLE_IMPL", impl)     # 64 scenes would take the persistent kernel by default: both are checked
     from stillleben_amd import parallel
     from stillleben_amd._engine import SHADOW_RES
 

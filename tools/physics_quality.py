@@ -46,14 +46,18 @@ def settle_range(args):
     frames = int(prm["frames"])
     sub = ss[lo:hi].copy()
     trace = np.zeros((hi - lo, frames, 4), np.float32)
+    caps = np.zeros((hi - lo, 4), np.uint32)
     L.slref_settle_set_trace.argtypes = [C.c_void_p]
+    L.slref_settle_set_caps.argtypes = [C.c_void_p]
     L.slref_settle_set_trace(C.c_void_p(trace.ctypes.data))
+    L.slref_settle_set_caps(C.c_void_p(caps.ctypes.data))
     try:
         oracle.settle(sub, bodies, hull_recs, hull_verts, prm)
     finally:
         L.slref_settle_set_trace(None)
+        L.slref_settle_set_caps(None)
     b0, b1 = int(ss[lo]["body_begin"]), int(ss[hi - 1]["body_end"])
-    return lo, hi, bodies[b0:b1].copy(), trace
+    return lo, hi, bodies[b0:b1].copy(), trace, caps
 
 
 def measure(n=64, seed0=900000, n_objects=20, threads=8, quiet=False):
@@ -70,10 +74,12 @@ def measure(n=64, seed0=900000, n_objects=20, threads=8, quiet=False):
         res = [settle_range(j) for j in jobs]
     frames = int(prm["frames"])
     trace = np.zeros((n, frames, 4), np.float32)
-    for lo, hi, b, t in res:
+    caps = np.zeros((n, 4), np.uint32)
+    for lo, hi, b, t, c in res:
         b0, b1 = int(ss[lo]["body_begin"]), int(ss[hi - 1]["body_end"])
         bodies[b0:b1] = b
         trace[lo:hi] = t
+        caps[lo:hi] = c
     from stillleben_amd import _settle_batch as SB
 
     speed = np.linalg.norm(bodies["lin_vel"][:, :3], axis=1)
@@ -92,6 +98,9 @@ def measure(n=64, seed0=900000, n_objects=20, threads=8, quiet=False):
         "stuck_bodies": int((bodies["stuck_counter"] > 0).sum()),
         "min_separation_p01": float(np.quantile(np.minimum(bodies["separation"], 1.0), 0.01)),
         "active_contacts_last": float(trace[:, -1, 2].mean()),
+        "contact_cap_hit_rate": float(caps[:, 0].sum() / max(1, caps[:, 3].sum())),      # share of scene-steps that dropped contacts
+        "pair_cap_hit_rate": float(caps[:, 1].sum() / max(1, caps[:, 3].sum())),
+        "max_contacts_offered": int(caps[:, 2].max()),
         "asleep_by_frame": [float(trace[:, f, 0].mean()) for f in (24, 49, 74, 99) if f < frames],
     }
     if not quiet:
