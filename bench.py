@@ -400,22 +400,59 @@ def main():
     pipe.eng.L.slhip_settle_timing_enable(0)
     for i, n in enumerate(settle_kernels):
         settle_kernels[n]["avg_ms_per_launch_alone"] = float(st_ms[i])
+    # cap saturation of that settle (the reference's PhysX has no caps): (scene, step) pairs at SLHIP_MAX_ACTIVE_CONTACTS /
+    # SLHIP_MAX_HULL_PAIRS over all scene-steps
+    cap_contacts, cap_pairs = b_last.settle_caps()
+    scene_steps = args.batch * int(b_last.settle_params["frames"]) * int(b_last.settle_params["substeps"])
+    caps = {"contact_cap_hit_rate": cap_contacts / scene_steps, "pair_cap_hit_rate": cap_pairs / scene_steps,
+            "max_active_contacts": 160, "max_hull_pairs": 512, "scene_steps": scene_steps,
+            "note": "share of (scene, step) pairs in which the body pairs offered more contacts than the cap left room for (every "
+                    "pair then keeps its first B contacts, B the largest that fits) / the broadphase found more hull pairs than "
+                    "the list holds; measured on one settle of the step's scenes after the timed region"}
+    # the exchange step alone: the same shard gathered synchronously after the timed region (inside it the collective runs
+    # beside the next chunks' render on its own stream)
+    exchange = None
+    if pipe.gatherer is not None and pipe.gather_scenes > 0 and pipe.buffers:
+        buf = pipe.buffers[0]
+        g = min(pipe.gather_scenes, buf.B)
+        shard = [t[:g] for t in (buf.rgb, buf.coord, buf.cls, buf.instance, buf.normals)]
+        nbytes = sum(t.numel() * t.element_size() for t in shard)
+        pipe.gatherer(shard)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        reps = 3
+        tx = time.perf_counter()
+        for _ in range(reps):
+            pipe.gatherer(shard)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - tx) / reps * 1e3
+        exchange = {"scenes": g, "bytes_per_rank": nbytes, "ms": ms, "GBps": (world - 1) * nbytes / (ms * 1e-3) / 1e9,
+                    "of_scenes_per_step": args.batch,
+                    "backend": "slhip_allgather_group (RCCL behind the C-ABI)" if comm is not None else "torch.distributed",
+                    "note": "all-gather of one rank's exchange shard (6-channel GT of `scenes` scenes) to every rank, synchronous, %d "
+                            "repetitions after the timed region; GBps = bytes received per rank / time" % reps}
+    out = None
     if rank == 0:
         out = report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso,
                      phases, iso, settle_kernels)
+        out["caps"] = caps
+        out["exchange"] = exchange
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(meshes, args.cpu_scenes, not args.no_ssao)
-        print(json.dumps(out))
     if comm is not None:
         comm.close()
     if dist is not None:
         dist.destroy_process_group()
+    if out is not None:      # rank 0's line is the LAST thing on stdout (library banners come earlier)
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)
 
 
 def load_counters():
     """SQ / HBM counters of the dominant kernels, collected by tools/collect_counters.py from separate rocprofv3 --pmc
     passes at the bench shape and committed under profiles/ (the latest round's file wins)."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "counters.json")
         if os.path.exists(path):
             with open(path) as f:
@@ -475,7 +512,7 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
     }
     roof_render["frac"] = roof_render["achieved"] / roof_render["peak"]
     # ---- the time-dominant kernel of the whole path: the solver of the settle ----
-    lockstep = settle_kernels["k_w_solve"]["timed_launches"] > 0          # SLHIP_SETTLE_IMPL=persistent runs k_settle instead
+    lockstep = True
     hulls_per_scene = float(np.mean(table.n_hulls)) * N_OBJECTS
     hverts_per_scene = float(np.mean(table.n_hull_verts)) * N_OBJECTS
     if lockstep:
@@ -542,7 +579,8 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
             "scenes_per_gpu_per_step": args.batch, "render_chunk": args.render_chunk, "resolution": list(RESOLUTION),
             "objects": N_OBJECTS,
             "parallelism": ("scenes sharded by rank, no data-path collective; exchange: RCCL all-gather of a %d-scene C3 shard per "
-                            "rank and step (%.0f MB per rank)" % (pipe.gather_scenes, pipe.gather_scenes * P * 40 / 1e6)) if world > 1 else "1 GPU",
+                            "rank and step (%.0f MB per rank) -- %d of the %d scenes a rank renders per step are exchanged"
+                            % (pipe.gather_scenes, pipe.gather_scenes * P * 40 / 1e6, pipe.gather_scenes, args.batch)) if world > 1 else "1 GPU",
         },
         "roofline": roofline,
         "roofline_render": roof_render,

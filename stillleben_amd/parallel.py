@@ -67,13 +67,19 @@ class SlhipComm:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if unique_id is None:
             buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()
+            if world > 1 and dist is None:
+                raise ValueError("SlhipComm: world > 1 needs `dist` (or a shared `unique_id`)")
+            box = [None]
             if rank == 0:
-                _abi.check(self.L.slhip_comm_unique_id(buf), "slhip_comm_unique_id")
-            box = [bytes(buf)]
+                # a failure here (librccl not loadable through the C-ABI) must still reach the broadcast below: the other ranks
+                # are already waiting in it, and all ranks have to raise together
+                st = self.L.slhip_comm_unique_id(buf)
+                box = [bytes(buf) if st == 0 else None]
+                err = self.L.slhip_last_error() if st != 0 else None
             if world > 1:
-                if dist is None:
-                    raise ValueError("SlhipComm: world > 1 needs `dist` (or a shared `unique_id`)")
                 dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
+                raise _abi.SlhipError("slhip_comm_unique_id failed on rank 0%s" % ((": " + err.decode()) if rank == 0 and err else ""))
             unique_id = box[0]
         idbuf = (C.c_uint8 * _abi.COMM_ID_BYTES).from_buffer_copy(unique_id)
         h = C.c_void_p()

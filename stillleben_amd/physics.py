@@ -78,13 +78,14 @@ class SettleEngine:
                                       C.c_void_p(stream))
         return np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy(), status
 
-    def caps(self, n_scenes, stream=None):
+    def caps(self, n_scenes, stream=None, prm=None):
         """(contact-cap steps, pair-cap steps) of the last launch on `stream` (slhip_settle_caps)."""
         eng = self.eng
         if stream is None:
             stream = torch.cuda.current_stream(eng.device).cuda_stream
         a, b = C.c_uint64(), C.c_uint64()
-        prm = self._keep[stream][1]
+        if prm is None:
+            prm = self._keep[stream][1]
         with torch.cuda.device(eng.device):
             st = eng.L.slhip_settle_caps(_abi_ptr(self._scratch[stream]), n_scenes, C.c_void_p(prm.ctypes.data), C.byref(a), C.byref(b),
                                          C.c_void_p(stream))

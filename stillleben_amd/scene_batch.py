@@ -237,6 +237,11 @@ class SceneBatch:
         """Synchronises the settle stream; raises if the kernel refused a scene (sizing hints)."""
         self.se.check_status(self.n_scenes, self._settle_stream)
 
+    def settle_caps(self):
+        """(contact-cap steps, pair-cap steps) of the last settle() -- (scene, step) pairs that hit SLHIP_MAX_ACTIVE_CONTACTS /
+        SLHIP_MAX_HULL_PAIRS (slhip_settle_caps; synchronises the settle stream)."""
+        return self.se.caps(self.n_scenes, self._settle_stream, self._settle_keep)
+
     def place(self):
         """Camera pose, light direction, shadow matrix and the render records of every scene."""
         d_assets, d_templates = self.table.device()
