@@ -1901,6 +1901,16 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     }
 
     if (g_timing) {
+        // a caller that enables timing and never reads it must not grow the list for ever: beyond kMaxTimedCalls the oldest
+        // records are dropped (their events destroyed, their durations lost)
+        constexpr size_t kMaxTimedCalls = 4096;
+        if (g_timed.size() >= kMaxTimedCalls) {
+            const size_t drop = g_timed.size() / 2;
+            for (size_t k = 0; k < drop; ++k)
+                for (int i = 0; i <= kNumPhases; ++i)
+                    if (g_timed[k].recorded[i]) (void)hipEventDestroy(g_timed[k].ev[i]);
+            g_timed.erase(g_timed.begin(), g_timed.begin() + (long)drop);
+        }
         g_timed.emplace_back();
         g_cur = &g_timed.back();
         for (int i = 0; i <= kNumPhases; ++i) g_cur->recorded[i] = false;

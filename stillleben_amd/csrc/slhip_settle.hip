@@ -1560,16 +1560,20 @@ extern "C" int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5
 {
     double acc[5] = {0, 0, 0, 0, 0};
     uint32_t n[5] = {0, 0, 0, 0, 0};
+    bool failed = false;
     for (auto& r : g_settle_timing.pending) {
-        SLHIP_CHECK(hipEventSynchronize(r.e1));
         float ms = 0.0f;
-        SLHIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        if (failed || hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { failed = true; continue; }
         acc[r.kernel] += ms;
         ++n[r.kernel];
     }
-    for (hipEvent_t e : g_settle_timing.events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g_settle_timing.events) (void)hipEventDestroy(e);   // on the error path as well
     g_settle_timing.events.clear();
     g_settle_timing.pending.clear();
+    if (failed) {
+        slhip::set_error("slhip_settle_timings: event readback failed");
+        return -1;
+    }
     for (int k = 0; k < 5; ++k) {
         if (avg_ms_out) avg_ms_out[k] = n[k] ? (float)(acc[k] / n[k]) : 0.0f;
         if (launches_out) launches_out[k] = n[k];
@@ -1637,10 +1641,17 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         uint32_t step = 0;
         for (uint32_t f = 0; f < params->frames; ++f)
             for (uint32_t sub = 0; sub < params->substeps; ++sub, ++step) {
-                const bool timed = g_settle_timing.on && step % 8u == 0u;
+                // (a caller that never reads the timings must not grow the lists for ever: sampling stops at kMaxTimedEvents)
+                constexpr size_t kMaxTimedEvents = 1u << 16;
+                bool timed = g_settle_timing.on && step % 8u == 0u && g_settle_timing.events.size() < kMaxTimedEvents;
                 hipEvent_t ev[6];
                 if (timed)
-                    for (int k = 0; k < 6; ++k) SLHIP_CHECK(hipEventCreate(&ev[k]));
+                    for (int k = 0; k < 6; ++k)
+                        if (hipEventCreate(&ev[k]) != hipSuccess) {
+                            for (int q = 0; q < k; ++q) (void)hipEventDestroy(ev[q]);
+                            timed = false;
+                            break;
+                        }
                 if (timed) (void)hipEventRecord(ev[0], stream);
                 k_w_begin<<<n_scenes, 64, BL.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, W, BL, drive_w, step + 1u);
                 if (timed) (void)hipEventRecord(ev[1], stream);

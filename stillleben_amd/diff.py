@@ -147,6 +147,25 @@ def backpropagate_gradient_to_poses_batch(scene, pose_hypotheses, grad_objective
         raise ValueError("grad_objective_wrt_rnd_img must be 3xHxW or Kx3xHxW")
     if K == 0 or n == 0:
         return torch.zeros(K, n, 6)
+    lds_all, lcs_all = scene._light_directions.numpy(), scene._light_colors.numpy()
+    if any(bool(np.any(lds_all[i])) and bool(np.any(lcs_all[i])) for i in (1, 2)):
+        # the replicated records carry light 0 only: scenes lit by several lights go hypothesis by hypothesis through RenderPass
+        from .render_pass import RenderPass
+
+        rp = RenderPass()
+        rp.ssao_enabled = ssao
+        saved = [o.pose() for o in objs]
+        out = torch.zeros(K, n, 6)
+        try:
+            for k in range(K):
+                for i, o in enumerate(objs):
+                    o.set_pose(torch.from_numpy(hyp[k, i]))
+                res_k = rp.render(scene)
+                out[k] = backpropagate_gradient_to_poses(scene, res_k, (g[k] if per_hyp_grad else g))
+        finally:
+            for o, p in zip(objs, saved):
+                o.set_pose(p)
+        return (out, None) if return_results else out
     t = FB.replicate(FB.prepare([scene], eng.pool), K)
     poses = hyp.reshape(K * n, 4, 4)
     cam = np.tile(scene._camera_pose[None], (K, 1, 1)).astype(np.float32)

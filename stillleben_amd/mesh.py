@@ -237,8 +237,9 @@ class Mesh:
         with np.errstate(all="ignore"):
             contrib = ((cr / area[:, None]).astype(np.float32) * area[:, None]).astype(np.float32)
         acc = np.zeros_like(p)
-        for k in range(3):                      # np.add.at accumulates in index order (unbuffered)
-            np.add.at(acc, idx[:, k], contrib)
+        # np.add.at accumulates in index order (unbuffered): face 0's corners, face 1's, ... -- every vertex sums its faces in
+        # face order, the reference's float32 summation order
+        np.add.at(acc, idx.reshape(-1), np.repeat(contrib, 3, axis=0))
         ln = np.sqrt((acc * acc).sum(axis=1, dtype=np.float32)).astype(np.float32)
         with np.errstate(all="ignore"):
             d.normals = (acc / ln[:, None]).astype(np.float32)

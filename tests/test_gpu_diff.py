@@ -269,3 +269,17 @@ def test_pose_hypothesis_batch_equals_the_loop(sl):
         assert float((got[k] - ref).abs().max()) <= 1e-4 * scale
     with pytest.raises(ValueError):
         sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps[:, :3], g)
+    # a second light: the batch form has to give the per-hypothesis answer as well (its replicated records carry light 0 only)
+    ld = scene.light_directions.clone()
+    ld[1] = torch.tensor([0.3, -0.2, -1.0])
+    scene.light_directions = ld
+    lc = scene.light_colors.clone()
+    lc[1] = torch.tensor([120.0, 100.0, 80.0])
+    scene.light_colors = lc
+    got2 = sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps, g)
+    for k in range(K):
+        for o, p in zip(scene.objects, hyps[k]):
+            o.set_pose(p)
+        ref = sl.diff.backpropagate_gradient_to_poses(scene, rp.render(scene), g)
+        scale = max(1e-9, float(ref.abs().max()))
+        assert float((got2[k] - ref).abs().max()) <= 1e-4 * scale

@@ -1,6 +1,8 @@
 """GPU parity tests of the render half: HIP path (through the C-ABI) vs the CPU oracle on the
-same seeded scenes.  Bar: integer outputs, depth and every geometric float output bit-exact;
-RGB within 1 LSB of the 8-bit output (>= the 1e-3 relative tolerance of the north star)."""
+same seeded scenes.  Bar: integer outputs, depth and every geometric float output bit-exact; colour: the HDR float image
+that enters the tone map within 1e-3 relative (the north star's bound, test_hdr_colour_within_1e3_relative), the 8-bit RGB
+within 1 LSB on all but 1e-4 of the values and never more than 2 (the tone map's ACES curve is steep near black: one HDR ulp
+can move a channel across two quantisation steps)."""
 import numpy as np
 import pytest
 import torch
@@ -70,6 +72,33 @@ def assert_rgb_close(bufs, ref):
     assert d.max() <= 2, "rgb max diff %d" % d.max()
     assert (d > 1).mean() < 1e-4
     assert (d > 0).mean() < 0.02
+
+
+@pytest.mark.parametrize("ssao", [False, True])
+def test_hdr_colour_within_1e3_relative(sl, oracle, eng, ssao):
+    """The north star's colour bound on the FLOAT image: what k_shade (+ k_ssao / k_ssao_apply) hand to the tone map against the
+    oracle's, 1e-3 relative per channel.  The kernels evaluate sRGB decode, Fresnel power, BRDF divisions and light / half
+    vector normalisation through the hardware's log2 / exp2 / rcp / rsq (1 ulp each); the oracle uses libm and IEEE division."""
+    from stillleben_amd import _engine
+
+    scene = S.clutter_scene(sl, 21, n_objects=8, size=(320, 240), with_bunny=True)
+    scene.manual_exposure = 1.0
+    W, H = scene.viewport
+    mask = _abi.OUT_ALL
+    bufs = eng.render([scene], mask, ssao=ssao, shadows=True)
+    torch.cuda.synchronize()
+    keep = bufs._keepalive[0]
+    hdr = keep["hdr"].view(torch.float32)[: 2 * H * W * 4].reshape(2, H, W, 4)[1 if ssao else 0].cpu().numpy()
+    pool = HostPool()
+    srec, drec, _ = build_batch([scene], pool, with_shadows=True)
+    flags = mask | (_abi.RENDER_SSAO if ssao else 0) | _abi.RENDER_SHADOWS
+    ref = oracle.render(pool.arrays(), srec, drec, W, H, flags, shadow_res=_engine.SHADOW_RES, want_hdr=True)
+    r = ref.hdr[0]
+    lit = r[..., :3].max(axis=-1) > 0
+    assert lit.mean() > 0.5                                   # the frame is lit (plane + objects)
+    err = np.abs(hdr[..., :3] - r[..., :3]) / np.maximum(np.abs(r[..., :3]), 1e-4)
+    assert err.max() <= 1e-3, "HDR colour off by %.2e relative" % err.max()
+    assert np.array_equal(hdr[..., 3], r[..., 3])             # alpha is exact
 
 
 def test_cube_lookat(sl, oracle, eng):
