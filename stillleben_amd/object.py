@@ -180,10 +180,18 @@ class Object:
 
     # ---- mass properties (object.cpp:215-257; PxRigidBodyExt::updateMassAndInertia) --------------
     def _props(self):
-        if self._mass_props is None or self._mass_props.key != self._mass_key():
-            from . import massprops
+        key = self._mass_key()
+        if self._mass_props is None or self._mass_props.key != key:
+            # the integrals depend on the mesh (and the density) only: objects of one mesh share them
+            cache = self._mesh.__dict__.setdefault("_mass_cache", {})
+            props = cache.get(key)
+            if props is None:
+                from . import massprops
 
-            self._mass_props = massprops.compute(self)
+                if len(cache) > 16:
+                    cache.clear()
+                props = cache[key] = massprops.compute(self)
+            self._mass_props = props
         return self._mass_props
 
     def _mass_key(self):
