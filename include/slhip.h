@@ -568,6 +568,56 @@ int slhip_synth_place(const slhip_synth_params* params, const slhip_asset* d_ass
                       slhip_scene* d_out_scenes, slhip_draw* d_out_draws, slhip_chunk* d_out_chunks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Host side of the per-object API (sl.Scene / sl.RenderPass): record assembly in C++, one call per batch.
+ * The reference does this work in C++ as well -- renderer.render(scene) (python/src/py_render_pass.cpp:252-258) runs
+ * RenderPass::render (src/render_pass.cpp:303-796), which computes the shadow matrices (:69-211) and uploads the
+ * per-drawable uniforms (:534-621; RenderShader::setTransformations / setMaterial, render_shader.cpp:233-265, :326-417).
+ * Inputs are flat HOST arrays; nothing here touches the device.
+ * ------------------------------------------------------------------------------------------- */
+/* An object of a scene: pose + what sl.Object overrides of its mesh's draw templates.        */
+typedef struct {
+    float pose[16];              /* object to world, row-major (Object::pose)                  */
+    float bbox_center[4];        /* mesh bbox centre (object frame); w = bbox diagonal / 2 (shadow fit, render_pass.cpp:87,180) */
+    float color[4];              /* Object options "color" ...                                 */
+    uint32_t force_color;        /* ... used instead of the material's base colour when set ("force_color") */
+    uint32_t tmpl_begin, tmpl_count;   /* the mesh's draw templates (one per sub-mesh) in `templates` */
+    uint32_t instance_index;
+    float metallic, roughness;   /* per-object override, < 0: the material's (render_shader.cpp:355-377) */
+    uint32_t casts_shadows;
+    uint32_t _pad;
+} slhip_host_object;             /* 128 bytes */
+
+/* A scene: camera, lights, background plane, its objects [obj_begin, obj_end).               */
+typedef struct {
+    float proj[16], proj_inv[16];    /* projection (Scene::projectionMatrix) and its inverse (float64 inverse rounded) */
+    float camera_pose[16];           /* camera to world                                        */
+    float light_dir[SLHIP_NUM_LIGHTS][4], light_color[SLHIP_NUM_LIGHTS][4];
+    float ambient[4];
+    float plane_pose[16];            /* background plane pose (scene.cpp:629-663)              */
+    float plane_size[2];
+    int32_t plane_template;          /* draw template of the background plane in `templates`, -1: no plane */
+    float manual_exposure;
+    uint32_t obj_begin, obj_end;
+    uint32_t light_map;
+    uint32_t bg_tex[3];
+} slhip_host_scene;                  /* 408 bytes */
+
+/* Shadow-map matrices of one scene (computeFrustumCorners + computeShadowMapMatrix, render_pass.cpp:69-211):
+ * out48 = NUM_LIGHTS row-major 4x4 (identity for inactive lights or a non-finite fit).      */
+int slhip_host_shadow_matrices(const slhip_host_scene* scene, const slhip_host_object* objects, float* out48);
+/* Matrix4::normalMatrix(): inverse transpose of the upper 3x3 of m16 (float64 cofactors), 3 rows padded to 4. */
+int slhip_host_normal_matrix(const float* m16, float* out12);
+/* Records a batch needs: draws (plane + one per object sub-mesh) and raster chunks (<= SLHIP_CHUNK_TRIS triangles each). */
+int slhip_records_count(const slhip_host_scene* scenes, uint32_t n_scenes, const slhip_host_object* objects,
+                        const slhip_draw* templates, uint32_t* n_draws, uint32_t* n_chunks);
+/* Fills srec[n_scenes], drec[<= draw_capacity], crec[<= chunk_capacity] in scene / object / sub-mesh order: the draw
+ * templates with scene, prim_base, clip_base, object_to_world, normal_to_world, the per-object overrides; the scene
+ * records with world_to_cam, cam_position, lights and (with_shadows) the shadow matrices.   */
+int slhip_records_build_render(const slhip_host_scene* scenes, uint32_t n_scenes, const slhip_host_object* objects,
+                               const slhip_draw* templates, uint32_t with_shadows, slhip_scene* srec, slhip_draw* drec,
+                               uint32_t draw_capacity, slhip_chunk* crec, uint32_t chunk_capacity);
+
+/* ---------------------------------------------------------------------------------------------
  * Multi-GPU exchange: scenes are independent, every rank (one process per GPU, as
  * the reference runs it: python/src/py_context.cpp:34-52) settles and renders its own shard; the one
  * exchange step is the all-gather of rendered batches, RCCL over xGMI.  RCCL is bound at run time

@@ -138,6 +138,20 @@ CHUNK_DTYPE = np.dtype(
     [("scene", np.uint32), ("draw", np.uint32), ("first_tri", np.uint32), ("count", np.uint32)]
 )
 
+# slhip_host_object / slhip_host_scene (include/slhip.h): flat descriptors for the C++ record assembly
+HOST_OBJECT_DTYPE = np.dtype([
+    ("pose", np.float32, (16,)), ("bbox_center", np.float32, (4,)), ("color", np.float32, (4,)), ("force_color", np.uint32),
+    ("tmpl_begin", np.uint32), ("tmpl_count", np.uint32), ("instance_index", np.uint32), ("metallic", np.float32),
+    ("roughness", np.float32), ("casts_shadows", np.uint32), ("_pad", np.uint32)])
+assert HOST_OBJECT_DTYPE.itemsize == 128
+HOST_SCENE_DTYPE = np.dtype([
+    ("proj", np.float32, (16,)), ("proj_inv", np.float32, (16,)), ("camera_pose", np.float32, (16,)),
+    ("light_dir", np.float32, (NUM_LIGHTS, 4)), ("light_color", np.float32, (NUM_LIGHTS, 4)), ("ambient", np.float32, (4,)),
+    ("plane_pose", np.float32, (16,)), ("plane_size", np.float32, (2,)), ("plane_template", np.int32),
+    ("manual_exposure", np.float32), ("obj_begin", np.uint32), ("obj_end", np.uint32), ("light_map", np.uint32),
+    ("bg_tex", np.uint32, (3,))])
+assert HOST_SCENE_DTYPE.itemsize == 408
+
 
 class RenderOut(C.Structure):
     _fields_ = [
@@ -248,6 +262,11 @@ def lib():
     L.slhip_settle.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint64, C.c_void_p]
     L.slhip_settle_status.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]
+    L.slhip_host_shadow_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slhip_host_normal_matrix.argtypes = [C.c_void_p, C.c_void_p]
+    L.slhip_records_count.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.slhip_records_build_render.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                             C.c_uint32, C.c_void_p, C.c_uint32]
     L.slhip_settle_caps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]
     L.slhip_settle_timing_enable.argtypes = [C.c_int]
     L.slhip_settle_timings.argtypes = [C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32 * 5)]

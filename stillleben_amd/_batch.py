@@ -171,30 +171,21 @@ def scene_record(scene, rec, shadow_mats=None):
             rec["shadow_mat"][i] = shadow_mats[i].reshape(-1)
 
 
-def object_draws(obj, pool):
-    """One slhip_draw per sub-mesh of the object: what RenderShader::setTransformations / setMaterial /
-    setClassIndex / setInstanceIndex upload for it (render_pass.cpp:583-621, render_shader.cpp:233-265,
-    :326-417).  `scene` and `prim_base` are left to the caller."""
+def mesh_draw_templates(mesh, slot):
+    """One slhip_draw per sub-mesh with everything the MESH and its materials determine (RenderShader::setMaterial,
+    render_shader.cpp:326-417); scene, prim_base, clip_base, the object's pose and its overrides are filled in per use."""
     out = []
-    mesh = obj._mesh
-    slot = pool.register(mesh)
     m2o = mesh._pretransform
-    o2w = obj._pose
-    nm = np.zeros((3, 4), np.float32)
-    nm[:, :3] = M.normal_matrix((o2w @ m2o).astype(np.float32))
     for sm in mesh._data.submeshes:
         mat = mesh._data.materials[sm.material]
         d = np.zeros((), dtype=_abi.DRAW_DTYPE)
         d["mesh_to_object"] = m2o.reshape(-1)
-        d["object_to_world"] = o2w.reshape(-1)
-        d["normal_to_world"] = nm.reshape(-1)
-        d["base_color"] = mat.base_color if obj._color is None or not obj._force_color else obj._color
+        d["base_color"] = mat.base_color
         d["emissive"][:3] = mat.emissive
         d["alpha_cutoff"] = 0.5  # render_shader.cpp:382
-        d["metallic"], d["roughness"] = _effective_material(mat, obj)
+        d["metallic"], d["roughness"] = _effective_material(mat, None)
         d["class_index"] = mesh._class_index
-        d["instance_index"] = obj._instance_index
-        flags = _abi.DRAW_CASTS_SHADOW if obj._casts_shadows else 0
+        flags = 0
         if mat.base_texture is not None:
             flags |= _abi.DRAW_HAS_BASE_TEX
             if slot.tex_alpha[mat.base_texture]:
@@ -211,6 +202,55 @@ def object_draws(obj, pool):
                 flags |= bit
                 d[field] = (slot.tex_offsets[ti],) + tuple(slot.tex_sizes[ti])
                 d["tex_sampler"][k + 1] = slot.tex_samplers[ti]
+        d["flags"] = flags
+        d["vtx_base"] = slot.vtx_base
+        d["idx_base"] = slot.idx_base + sm.first_index
+        d["n_tris"] = sm.n_indices // 3
+        d["n_verts"] = slot.n_vertices
+        out.append(d)
+    return out
+
+
+def plane_draw_template(pool, tex):
+    """The background plane's draw (render_pass.cpp:545-582) without its pose."""
+    d = np.zeros((), dtype=_abi.DRAW_DTYPE)
+    flags = _abi.DRAW_NO_VERTEX_ID
+    if tex is not None:
+        off, w, h = pool.add_texture(tex._rgba)
+        d["base_color"] = (1.0, 1.0, 1.0, 1.0)
+        d["tex_offset"], d["tex_w"], d["tex_h"] = off, w, h
+        d["tex_sampler"][0] = _abi.SAMPLER_DEFAULT
+        flags |= _abi.DRAW_HAS_BASE_TEX
+    else:
+        d["base_color"] = (0.0, 0.8, 0.0, 1.0)
+    d["alpha_cutoff"] = 0.5
+    d["metallic"], d["roughness"] = 0.04, 0.5
+    d["flags"] = flags
+    d["vtx_base"], d["idx_base"], d["n_tris"] = 0, 0, 2
+    d["n_verts"] = 4
+    return d
+
+
+def object_draws(obj, pool):
+    """One slhip_draw per sub-mesh of the object: what RenderShader::setTransformations / setMaterial /
+    setClassIndex / setInstanceIndex upload for it (render_pass.cpp:583-621, render_shader.cpp:233-265,
+    :326-417).  `scene` and `prim_base` are left to the caller."""
+    out = []
+    mesh = obj._mesh
+    slot = pool.register(mesh)
+    m2o = mesh._pretransform
+    o2w = obj._pose
+    nm = np.zeros((3, 4), np.float32)
+    nm[:, :3] = M.normal_matrix(M.mul44(o2w, m2o))
+    for d, sm in zip(mesh_draw_templates(mesh, slot), mesh._data.submeshes):
+        mat = mesh._data.materials[sm.material]
+        d["object_to_world"] = o2w.reshape(-1)
+        d["normal_to_world"] = nm.reshape(-1)
+        if obj._color is not None and obj._force_color:
+            d["base_color"] = obj._color
+        d["metallic"], d["roughness"] = _effective_material(mat, obj)
+        d["instance_index"] = obj._instance_index
+        flags = int(d["flags"]) | (_abi.DRAW_CASTS_SHADOW if obj._casts_shadows else 0)
         st = obj._sticker_texture
         if st is not None and obj._sticker_range is not None:
             # render_pass.cpp:601-606: projection + range per object, the rectangle texture if one is set
@@ -221,16 +261,22 @@ def object_draws(obj, pool):
             r = np.asarray(obj._sticker_range, dtype=np.float32)   # min.x, min.y, max.x, max.y
             d["sticker_range"] = (r[0], r[1], max(f32(1e-6), r[2] - r[0]), max(f32(1e-6), r[3] - r[1]))
         d["flags"] = flags
-        d["vtx_base"] = slot.vtx_base
-        d["idx_base"] = slot.idx_base + sm.first_index
-        d["n_tris"] = sm.n_indices // 3
-        d["n_verts"] = slot.n_vertices
         out.append(d)
     return out
 
 
 def build_batch(scenes, pool, predicate=None, with_shadows=True):
-    """Returns (scene_records, draw_records, chunk_records) as numpy structured arrays."""
+    """Returns (scene_records, draw_records, chunk_records) as numpy structured arrays.  Batches without a predicate, sticker
+    decals or background images are assembled by the C++ host layer in one call (_host_records.build); the per-scene numpy
+    path below covers the rest and produces the same bits (tests/test_host_records.py)."""
+    from . import _host_records
+
+    if len(scenes) and _host_records.eligible(scenes, predicate):
+        return _host_records.build(scenes, pool, with_shadows)
+    return build_batch_per_scene(scenes, pool, predicate, with_shadows)
+
+
+def build_batch_per_scene(scenes, pool, predicate=None, with_shadows=True):
     from . import _shadow
 
     n_scenes = len(scenes)
@@ -250,7 +296,7 @@ def build_batch(scenes, pool, predicate=None, with_shadows=True):
         if float(np.dot(sz, sz)) > 0:
             d = np.zeros((), dtype=_abi.DRAW_DTYPE)
             scaling = np.diag([sz[0] / f32(2.0), sz[1] / f32(2.0), f32(1.0), f32(1.0)]).astype(np.float32)
-            o2w = (scene._background_plane_pose @ scaling).astype(np.float32)
+            o2w = M.mul44(scene._background_plane_pose, scaling)
             d["mesh_to_object"] = np.eye(4, dtype=np.float32).reshape(-1)
             d["object_to_world"] = o2w.reshape(-1)
             nm = np.zeros((3, 4), np.float32)

@@ -28,16 +28,43 @@ def as_vec(x, n):
 
 def inverted_rigid(m):
     """Matrix4::invertedRigid: [R^T | -R^T t]."""
-    r = m[:3, :3]
+    r = m[:3, :3].astype(np.float32)
+    t = m[:3, 3].astype(np.float32)
     out = np.eye(4, dtype=np.float32)
     out[:3, :3] = r.T
-    out[:3, 3] = -(r.T @ m[:3, 3])
+    # k-ordered products and sums (csrc/slhip_records.cpp inverted_rigid): numpy's matmul leaves the order to its BLAS
+    s = r.T[:, 0] * t[0]
+    s = s + r.T[:, 1] * t[1]
+    s = s + r.T[:, 2] * t[2]
+    out[:3, 3] = -s
     return out
 
 
 def normal_matrix(m):
-    """Matrix4::normalMatrix(): inverse-transpose of the upper-left 3x3."""
-    return np.linalg.inv(m[:3, :3].astype(np.float64)).T.astype(np.float32)
+    """Matrix4::normalMatrix(): inverse-transpose of the upper-left 3x3 -- cofactors over the determinant in float64, in the
+    operation order of normal_matrix() in csrc/slhip_records.cpp (the batch path): both give the same bits."""
+    a = m[:3, :3].astype(np.float64)
+    m00, m01, m02 = float(a[0, 0]), float(a[0, 1]), float(a[0, 2])
+    m10, m11, m12 = float(a[1, 0]), float(a[1, 1]), float(a[1, 2])
+    m20, m21, m22 = float(a[2, 0]), float(a[2, 1]), float(a[2, 2])
+    c = [m11 * m22 - m12 * m21, m12 * m20 - m10 * m22, m10 * m21 - m11 * m20,
+         m02 * m21 - m01 * m22, m00 * m22 - m02 * m20, m01 * m20 - m00 * m21,
+         m01 * m12 - m02 * m11, m02 * m10 - m00 * m12, m00 * m11 - m01 * m10]
+    det = m00 * c[0] + m01 * c[1] + m02 * c[2]
+    with np.errstate(all="ignore"):
+        return (np.array(c, np.float64) / det).astype(np.float32).reshape(3, 3)
+
+
+def mul44(a, b):
+    """4x4 product in float32 with the k-ordered sums of mul() in csrc/slhip_records.cpp (numpy's matmul leaves the order to
+    its BLAS): the per-scene and the batch path of the record assembly multiply pose by pretransform the same way."""
+    a = a.astype(np.float32)
+    b = b.astype(np.float32)
+    s = a[:, 0:1] * b[0:1, :]
+    s = s + a[:, 1:2] * b[1:2, :]
+    s = s + a[:, 2:3] * b[2:3, :]
+    s = s + a[:, 3:4] * b[3:4, :]
+    return s.astype(np.float32)
 
 
 def transform_point(m, p):

@@ -148,22 +148,58 @@ def body_record(obj, pool, rec):
         rec["drive_params"][:3] = (drv["stiffness"], drv["damping"], drv["force_limit"])
 
 
+def _body_template(obj, pool):
+    """slhip_body with everything the mesh, the density and the object's material determine -- shared by the objects of one
+    mesh with default settings; pose, velocities and per-step state are patched in per use."""
+    rec = np.zeros((), dtype=BODY_DTYPE)
+    body_record(obj, pool, rec)
+    return rec
+
+
 def build_settle_batch(scenes, pool, with_plane):
-    """with_plane: list of (has_plane, plane_z) per scene."""
-    n_bodies = sum(len(s._objects) for s in scenes)
-    bodies = np.zeros(n_bodies, dtype=BODY_DTYPE)
-    srec = np.zeros(len(scenes), dtype=SETTLE_SCENE_DTYPE)
-    k = 0
-    for si, scene in enumerate(scenes):
+    """with_plane: list of (has_plane, plane_z) per scene.  Bodies of driven objects (ManipulationSim) are filled one by one;
+    all others start from a per-(mesh, density, material) template and get pose, velocities and step state in array sweeps."""
+    for scene in scenes:
         if len(scene._objects) > MAX_BODIES:
             raise RuntimeError("at most %d objects per scene are supported by the settle kernel" % MAX_BODIES)
-        srec[si]["body_begin"] = k
-        for obj in scene._objects:
-            body_record(obj, pool, bodies[k])
-            k += 1
-        srec[si]["body_end"] = k
-        srec[si]["has_plane"] = 1 if with_plane[si][0] else 0
-        srec[si]["plane_z"] = with_plane[si][1]
+    objs = [o for s in scenes for o in s._objects]
+    n = len(objs)
+    counts = np.fromiter((len(s._objects) for s in scenes), np.int64, len(scenes))
+    srec = np.zeros(len(scenes), dtype=SETTLE_SCENE_DTYPE)
+    ends = np.cumsum(counts)
+    srec["body_end"] = ends
+    srec["body_begin"] = ends - counts
+    srec["has_plane"] = np.fromiter((1 if p[0] else 0 for p in with_plane), np.uint32, len(scenes))
+    srec["plane_z"] = np.fromiter((p[1] for p in with_plane), np.float32, len(scenes))
+    if n == 0:
+        return srec, np.zeros(0, dtype=BODY_DTYPE)
+    cache = pool.__dict__.setdefault("_body_templates", {})
+    rows, tidx = [], np.empty(n, np.int64)
+    local = {}
+    slow = []
+    for k, o in enumerate(objs):
+        if getattr(o, "_drive", None) is not None:
+            slow.append(k)
+        key = (id(o._mesh), o._mesh._version, float(o._mesh._scale), o._mesh._pretransform_rigid.tobytes(), float(o._density),
+               bool(o._static), float(o._static_friction), float(o._dynamic_friction), float(o._restitution), float(o._linear_velocity_limit))
+        j = local.get(key)
+        if j is None:
+            t = cache.get(key)
+            if t is None:
+                if len(cache) > 4096:
+                    cache.clear()
+                t = cache[key] = (_body_template(o, pool), o._mesh)     # (the mesh is kept alive with its id)
+            j = local[key] = len(rows)
+            rows.append(t[0])
+        tidx[k] = j
+    bodies = np.array(rows, dtype=BODY_DTYPE)[tidx]
+    bodies["pose"] = np.stack([o._pose for o in objs]).reshape(n, 16)
+    bodies["lin_vel"][:, :3] = np.stack([o._linear_velocity for o in objs])
+    bodies["ang_vel"][:, :3] = np.stack([o._angular_velocity for o in objs])
+    bodies["separation"] = np.fromiter((o._separation for o in objs), np.float32, n)
+    bodies["stuck_counter"] = np.fromiter((o._stuck_counter for o in objs), np.int32, n)
+    for k in slow:
+        body_record(objs[k], pool, bodies[k])
     return srec, bodies
 
 
@@ -187,15 +223,20 @@ def sizing_hints(params, srec, bodies, hulls):
 
 
 def write_back(scenes, bodies):
+    poses = np.ascontiguousarray(bodies["pose"]).reshape(-1, 4, 4).astype(np.float32)
+    lv = np.ascontiguousarray(bodies["lin_vel"][:, :3])
+    av = np.ascontiguousarray(bodies["ang_vel"][:, :3])
+    sep = bodies["separation"].astype(np.float32)
+    stuck = bodies["stuck_counter"].tolist()
     k = 0
     for scene in scenes:
         for obj in scene._objects:
-            b = bodies[k]
+            i = k
             k += 1
             if obj._static:
                 continue
-            obj._pose = b["pose"].reshape(4, 4).astype(np.float32).copy()
-            obj._linear_velocity = b["lin_vel"][:3].copy()
-            obj._angular_velocity = b["ang_vel"][:3].copy()
-            obj._separation = f32(b["separation"])
-            obj._stuck_counter = int(b["stuck_counter"])
+            obj._pose = poses[i].copy()
+            obj._linear_velocity = lv[i].copy()
+            obj._angular_velocity = av[i].copy()
+            obj._separation = sep[i]
+            obj._stuck_counter = stuck[i]

@@ -77,6 +77,15 @@ def shadow_matrix(scene, corners, light_direction):  # render_pass.cpp:131-211
 
 
 def shadow_matrices(scene):
+    """The shadow matrices the renderer uses: computed by the C++ host layer (csrc/slhip_records.cpp, the same functions the
+    batch path runs: one source of the bits).  frustum_corners / shadow_matrix above are the float32 numpy statement of the same
+    reference code, kept as the readable mirror and compared in tests/test_host_records.py."""
+    from . import _host_records
+
+    return _host_records.shadow_matrices(scene)
+
+
+def shadow_matrices_numpy(scene):
     from ._batch import effective_lights
 
     ld, lc, _ = effective_lights(scene)

@@ -171,32 +171,107 @@ def smoke_check(sl, checker):
 
 
 # ------------------------------------------------------------------------------------------
-def prepare_tabletop(scene):
-    """Host part of simulateTableTopScene before the loop (scene.cpp:612-718): plane decision,
-    background-plane pose, initial stack of randomly oriented objects.  Returns (has_plane, z)."""
-    scene.load_physics()
-    dynamic = [o for o in scene._objects if not o._static]
-    has_plane = len(dynamic) == len(scene._objects)
-    z = f32(0.4)
-    rng = scene._rng
-    if has_plane:
-        yaw = f32(rng.uniform(-math.pi, math.pi))
-        scene._background_plane_pose = (M.rotation_z(yaw) @ M.translation([0.0, 0.0, PLANE_HALF_Z])).astype(np.float32)
-        z = f32(PLANE_HALF_Z)
-    for obj in dynamic:
-        bbox = obj._mesh.bbox
-        diameter = bbox.np_diagonal()
-        z = f32(z + diameter / f32(2.0))
-        pos = np.array([0.0, 0.0, z], dtype=np.float32)
-        z = f32(z + diameter / f32(2.0))
-        q = pose_sampling.random_quaternion(rng)
-        pose = M.from_rt(M.quat_to_matrix(q), pos) @ M.translation(-bbox.np_center())
-        obj._pose = pose.astype(np.float32)
-        obj._linear_velocity = np.zeros(3, np.float32)
-        obj._angular_velocity = np.zeros(3, np.float32)
-        obj._stuck_counter = 0
-        obj._separation = f32(np.inf)
+def prepare_tabletop_batch(scenes):
+    """Host part of simulateTableTopScene before the loop (scene.cpp:612-718) for a list of scenes: plane decision,
+    background-plane pose, initial stack of randomly oriented objects -- the arithmetic over all objects at once (numpy), the
+    random draws scene by scene from the scene's own stream in the reference's order (plane yaw, then one quaternion per dynamic
+    object).  Returns has_plane per scene."""
+    has_plane = []
+    dyn, z_pos, quats = [], [], []
+    bbox_of = {}
+    for scene in scenes:
+        scene.load_physics()
+        d = [o for o in scene._objects if not o._static]
+        hp = len(d) == len(scene._objects)
+        has_plane.append(hp)
+        rng = scene._rng
+        z0 = f32(0.4)
+        if hp:
+            yaw = f32(rng.uniform(-math.pi, math.pi))
+            scene._background_plane_pose = (M.rotation_z(yaw) @ M.translation([0.0, 0.0, PLANE_HALF_Z])).astype(np.float32)
+            z0 = f32(PLANE_HALF_Z)
+        if not d:
+            continue
+        half = np.empty(2 * len(d) + 1, np.float32)
+        half[0] = z0
+        for k, o in enumerate(d):
+            m = o._mesh
+            b = bbox_of.get(id(m))
+            if b is None:
+                bb = m.bbox
+                b = bbox_of[id(m)] = (bb.np_diagonal() / f32(2.0), bb.np_center())
+            half[2 * k + 1] = half[2 * k + 2] = b[0]
+        z_pos.append(np.cumsum(half, dtype=np.float32)[1::2])          # z + d/2, then + d/2 again for the next one (float32, in order)
+        quats.append(np.stack([rng.standard_normal(4) for _ in d]).astype(np.float32))   # one 4-draw per object, in order
+        dyn.extend(d)
+    if dyn:
+        q = np.concatenate(quats)
+        q = (q / np.sqrt((q * q).sum(axis=1, dtype=np.float32)).astype(np.float32)[:, None]).astype(np.float32)
+        x, y, z, w = (q[:, k].astype(np.float64) for k in range(4))
+        n = np.sqrt(x * x + y * y + z * z + w * w)
+        x, y, z, w = x / n, y / n, z / n, w / n
+        poses = np.zeros((len(dyn), 4, 4), np.float32)
+        poses[:, 0, 0] = 1 - 2 * (y * y + z * z); poses[:, 0, 1] = 2 * (x * y - z * w); poses[:, 0, 2] = 2 * (x * z + y * w)
+        poses[:, 1, 0] = 2 * (x * y + z * w); poses[:, 1, 1] = 1 - 2 * (x * x + z * z); poses[:, 1, 2] = 2 * (y * z - x * w)
+        poses[:, 2, 0] = 2 * (x * z - y * w); poses[:, 2, 1] = 2 * (y * z + x * w); poses[:, 2, 2] = 1 - 2 * (x * x + y * y)
+        poses[:, 3, 3] = 1.0
+        c = -np.stack([bbox_of[id(o._mesh)][1] for o in dyn]).astype(np.float32)
+        R = poses[:, :3, :3]
+        t = R[:, :, 0] * c[:, 0:1]                                      # T(q, pos) . T(-bbox centre)
+        t = t + R[:, :, 1] * c[:, 1:2]
+        t = t + R[:, :, 2] * c[:, 2:3]
+        t[:, 2] = t[:, 2] + np.concatenate(z_pos)
+        poses[:, :3, 3] = t
+        inf = f32(np.inf)
+        for k, obj in enumerate(dyn):
+            obj._pose = poses[k].copy()
+            obj._linear_velocity = np.zeros(3, np.float32)
+            obj._angular_velocity = np.zeros(3, np.float32)
+            obj._stuck_counter = 0
+            obj._separation = inf
     return has_plane
+
+
+def prepare_tabletop(scene):
+    """prepare_tabletop_batch of one scene; returns has_plane."""
+    return prepare_tabletop_batch([scene])[0]
+
+
+def choose_camera_poses_batch(scenes):
+    """Scene::chooseRandomCameraPose (scene.cpp:472-610) for a list of scenes: azimuth and elevation from each scene's stream,
+    the frustum fit over all scenes at once (_fast_batch.camera_poses)."""
+    from . import _fast_batch as FB
+
+    with_objs = [s for s in scenes if s._objects]
+    for s in scenes:
+        if not s._objects:
+            s.choose_random_camera_pose()
+    if not with_objs:
+        return
+    az = np.empty(len(with_objs), np.float32)
+    el = np.empty(len(with_objs), np.float32)
+    for i, s in enumerate(with_objs):
+        az[i] = s._rng.uniform(-math.pi, math.pi)
+        el[i] = s._rng.uniform(math.radians(30.0), math.pi / 2.0 - math.radians(30.0))
+    t = FB.BatchTemplate()
+    objs = [o for s in with_objs for o in s._objects]
+    counts = np.array([len(s._objects) for s in with_objs], np.int64)
+    t.n_scenes, t.n_obj, t.max_objs = len(with_objs), len(objs), int(counts.max())
+    t.obj_scene = np.repeat(np.arange(len(with_objs), dtype=np.int64), counts)
+    t.obj_base = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    corners = {}
+    cs = []
+    for o in objs:
+        c = corners.get(id(o._mesh))
+        if c is None:
+            c = corners[id(o._mesh)] = o._mesh.bbox.corners()
+        cs.append(c)
+    t.bbox_corners = np.stack(cs).astype(np.float32)
+    t.proj = np.stack([s._projection for s in with_objs]).astype(np.float32)
+    poses = np.stack([o._pose for o in objs]).astype(np.float32)
+    cam = FB.camera_poses(t, poses, az, el)
+    for s, c in zip(with_objs, cam):
+        s._camera_pose = c.copy()
 
 
 def simulate_tabletop_scene(scene, vis_cb=None):
@@ -218,13 +293,12 @@ def simulate_tabletop_scene(scene, vis_cb=None):
 
 def settle_batch(scenes, frames=None):
     """Additive batch API (the GPU counterpart of JobQueue): settles many scenes in one launch."""
-    planes = [(prepare_tabletop(s), PLANE_HALF_Z) for s in scenes]
+    planes = [(hp, PLANE_HALF_Z) for hp in prepare_tabletop_batch(scenes)]
     se = settle_engine()
     srec, bodies = SB.build_settle_batch(scenes, se.pool, planes)
     bodies = se.run(srec, bodies, SB.default_params(tabletop=True, frames=frames))
     SB.write_back(scenes, bodies)
-    for s in scenes:
-        s.choose_random_camera_pose()
+    choose_camera_poses_batch(scenes)
 
 
 def simulate(scene, dt):
