@@ -407,6 +407,14 @@ int slhip_diff_pose_backward(const uint8_t* d_rgb, const float* d_coord, const i
                              const float* d_grad_img, const float* h_proj, const float* d_poses,
                              const int32_t* d_obj_inst, int n_obj, int H, int W, uint8_t* d_valid,
                              double* d_acc, float* d_out, void* stream);
+/* The same for K pose hypotheses of one scene in ONE launch sequence (BASELINE config C5): d_rgb / d_coord / d_inst are the
+ * [K,H,W,..] targets of the hypotheses' renders, d_poses f32 [K,n_obj,16], d_grad_img one image for all (grad_stride_floats
+ * = 0) or one per hypothesis (= 3 * H * W); scratch d_valid u8 [K,H,W], d_acc f64 [K,n_obj,6]; d_out f32 [K,n_obj,6].
+ * The reference loops hypothesis by hypothesis through its renderer and python/stillleben/diff.py:355-523.       */
+int slhip_diff_pose_backward_batch(const uint8_t* d_rgb, const float* d_coord, const int16_t* d_inst,
+                                   const float* d_grad_img, uint64_t grad_stride_floats, const float* h_proj,
+                                   const float* d_poses, const int32_t* d_obj_inst, int n_obj, int n_hyp, int H, int W,
+                                   uint8_t* d_valid, double* d_acc, float* d_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Image-based lighting precompute (replaces LightMap::load's GL passes, light_map.cpp:360-606, and

@@ -258,6 +258,7 @@ def lib():
     L.slhip_diff_dilate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.slhip_diff_image_gradients.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.slhip_diff_pose_backward.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
+    L.slhip_diff_pose_backward_batch.argtypes = [C.c_void_p] * 4 + [C.c_uint64] + [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p] * 4
     L.slhip_diff_vertex_backward.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     L.slhip_settle.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint64, C.c_void_p]

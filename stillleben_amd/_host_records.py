@@ -149,8 +149,14 @@ def describe(scenes, pool):
 
 def build(scenes, pool, with_shadows=True):
     """(srec, drec, crec) of the batch: what _batch.build_batch returns, assembled in C++."""
-    L = _abi.lib()
     hs, ho, tmpl = describe(scenes, pool)
+    return build_from(hs, ho, tmpl, with_shadows)
+
+
+def build_from(hs, ho, tmpl, with_shadows=True):
+    """slhip_records_build_render on prepared descriptors (slhip_host_scene / slhip_host_object arrays + draw templates)."""
+    L = _abi.lib()
+    hs, ho = np.ascontiguousarray(hs), np.ascontiguousarray(ho)
     nd, nc = C.c_uint32(), C.c_uint32()
     _abi.check(L.slhip_records_count(_ptr(hs), len(hs), _ptr(ho), _ptr(tmpl), C.byref(nd), C.byref(nc)), "slhip_records_count")
     srec = np.empty(len(hs), dtype=_abi.SCENE_DTYPE)

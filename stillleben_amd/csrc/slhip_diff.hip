@@ -15,6 +15,10 @@ __global__ __launch_bounds__(256) void k_sobel_valid(const int16_t* __restrict__
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= H * W) return;
+    {   // blockIdx.y = image of a batch (pose hypotheses): [K, H, W] planes one after the other
+        const size_t img = (size_t)blockIdx.y * H * W;
+        inst += img; depth += img * dstride; valid += img;
+    }
     const int h = p / W, w = p % W;
     uint8_t v = 1;
     if (h >= 1 && h < H - 1 && w >= 1 && w < W - 1) {
@@ -108,8 +112,14 @@ __global__ __launch_bounds__(256) void k_pose_backward(const uint8_t* __restrict
                                                        const int16_t* __restrict__ inst, const uint8_t* __restrict__ valid,
                                                        const float* __restrict__ grad_img, Mat4 P,
                                                        const float* __restrict__ poses, const int* __restrict__ obj_inst,
-                                                       int n_obj, int H, int W, double* __restrict__ acc)
+                                                       int n_obj, int H, int W, double* __restrict__ acc, size_t grad_stride)
 {
+    {   // blockIdx.y = pose hypothesis of a batch: its G-buffer, its poses, its accumulators; the gradient image is shared
+        // (grad_stride 0) or per hypothesis
+        const size_t k = blockIdx.y, img = k * (size_t)H * W;
+        rgb += 4 * img; coord += 4 * img; inst += img; valid += img;
+        grad_img += k * grad_stride; poses += k * 16 * (size_t)n_obj; acc += k * 6 * (size_t)n_obj;
+    }
     __shared__ double s_acc[kMaxDiffObjects * 6];
     __shared__ int s_touched[kMaxDiffObjects];
     for (int i = threadIdx.x; i < n_obj * 6; i += 256) s_acc[i] = 0.0;
@@ -309,8 +319,38 @@ extern "C" int slhip_diff_pose_backward(const uint8_t* d_rgb, const float* d_coo
     const int blocks = (H * W + 255) / 256;
     k_sobel_valid<<<blocks, 256, 0, stream>>>(d_inst, d_coord + 3, 4, H, W, d_valid);
     SLHIP_CHECK(hipMemsetAsync(d_acc, 0, sizeof(double) * 6 * n_obj, stream));
-    k_pose_backward<<<blocks, 256, 0, stream>>>(d_rgb, d_coord, d_inst, d_valid, d_grad_img, P, d_poses, d_obj_inst, n_obj, H, W, d_acc);
+    k_pose_backward<<<blocks, 256, 0, stream>>>(d_rgb, d_coord, d_inst, d_valid, d_grad_img, P, d_poses, d_obj_inst, n_obj, H, W, d_acc, 0);
     k_acc_to_float<<<(6 * n_obj + 63) / 64, 64, 0, stream>>>(d_acc, d_out, 6 * n_obj);
+    SLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// K pose hypotheses of one scene in ONE launch sequence (BASELINE config C5: 64 objects x 32 hypotheses): the G-buffers
+// [K,H,W,..] of the hypotheses' renders, their poses [K,n_obj,16], one gradient image for all (grad_stride_floats = 0) or one
+// per hypothesis (3 * H * W); three launches whatever K is -- the hypothesis is a grid dimension.  Row k of d_out [K,n_obj,6] is
+// what slhip_diff_pose_backward returns for hypothesis k (the same kernels, the same arithmetic).
+extern "C" int slhip_diff_pose_backward_batch(const uint8_t* d_rgb, const float* d_coord, const int16_t* d_inst,
+                                              const float* d_grad_img, uint64_t grad_stride_floats, const float* h_proj,
+                                              const float* d_poses, const int32_t* d_obj_inst, int n_obj, int n_hyp, int H, int W,
+                                              uint8_t* d_valid, double* d_acc, float* d_out, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_rgb || !d_coord || !d_inst || !d_grad_img || !h_proj || !d_poses || !d_obj_inst || !d_valid || !d_acc || !d_out) {
+        slhip::set_error("slhip_diff_pose_backward_batch: null argument");
+        return -1;
+    }
+    if (n_obj <= 0 || n_hyp <= 0) return 0;
+    if (n_obj > kMaxDiffObjects) { slhip::set_error("slhip_diff_pose_backward_batch: at most %d objects", kMaxDiffObjects); return -1; }
+    if (n_hyp > 65535) { slhip::set_error("slhip_diff_pose_backward_batch: at most 65535 hypotheses per call"); return -1; }
+    Mat4 P;
+    for (int i = 0; i < 16; ++i) P.m[i] = h_proj[i];
+    const dim3 grid((unsigned)((H * W + 255) / 256), (unsigned)n_hyp);
+    k_sobel_valid<<<grid, 256, 0, stream>>>(d_inst, d_coord + 3, 4, H, W, d_valid);
+    SLHIP_CHECK(hipMemsetAsync(d_acc, 0, sizeof(double) * 6 * (size_t)n_obj * n_hyp, stream));
+    k_pose_backward<<<grid, 256, 0, stream>>>(d_rgb, d_coord, d_inst, d_valid, d_grad_img, P, d_poses, d_obj_inst, n_obj, H, W, d_acc,
+                                              (size_t)grad_stride_floats);
+    const int total = 6 * n_obj * n_hyp;
+    k_acc_to_float<<<(total + 255) / 256, 256, 0, stream>>>(d_acc, d_out, total);
     SLHIP_LAUNCH_CHECK();
     return 0;
 }

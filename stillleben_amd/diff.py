@@ -130,8 +130,6 @@ def backpropagate_gradient_to_poses_batch(scene, pose_hypotheses, grad_objective
     float[K,3,H,W] for one gradient image per hypothesis) through each of them.  Returns float[K, N, 6]: row k equals
     `backpropagate_gradient_to_poses` after `set_pose(pose_hypotheses[k, i])` on every object and `RenderPass().render`.
     The reference has no batch form: it loops hypothesis by hypothesis through the GL renderer (diff.py:355-523)."""
-    from . import _fast_batch as FB
-
     eng = engine()
     objs = scene.objects
     n = len(objs)
@@ -147,9 +145,12 @@ def backpropagate_gradient_to_poses_batch(scene, pose_hypotheses, grad_objective
         raise ValueError("grad_objective_wrt_rnd_img must be 3xHxW or Kx3xHxW")
     if K == 0 or n == 0:
         return torch.zeros(K, n, 6)
-    lds_all, lcs_all = scene._light_directions.numpy(), scene._light_colors.numpy()
-    if any(bool(np.any(lds_all[i])) and bool(np.any(lcs_all[i])) for i in (1, 2)):
-        # the replicated records carry light 0 only: scenes lit by several lights go hypothesis by hypothesis through RenderPass
+    # K copies of the scene's descriptors with the hypotheses' poses: the C++ host layer assembles the records of all of them
+    # (shadow matrices of every active light included) in one call
+    from . import _host_records as HR
+
+    if not HR.eligible([scene], None):
+        # sticker decals / a background image: hypothesis by hypothesis through RenderPass
         from .render_pass import RenderPass
 
         rp = RenderPass()
@@ -160,36 +161,47 @@ def backpropagate_gradient_to_poses_batch(scene, pose_hypotheses, grad_objective
             for k in range(K):
                 for i, o in enumerate(objs):
                     o.set_pose(torch.from_numpy(hyp[k, i]))
-                res_k = rp.render(scene)
-                out[k] = backpropagate_gradient_to_poses(scene, res_k, (g[k] if per_hyp_grad else g))
+                out[k] = backpropagate_gradient_to_poses(scene, rp.render(scene), (g[k] if per_hyp_grad else g))
         finally:
             for o, p in zip(objs, saved):
                 o.set_pose(p)
         return (out, None) if return_results else out
-    t = FB.replicate(FB.prepare([scene], eng.pool), K)
-    poses = hyp.reshape(K * n, 4, 4)
-    cam = np.tile(scene._camera_pose[None], (K, 1, 1)).astype(np.float32)
-    ld = np.tile(scene._light_directions.numpy()[0][None].astype(np.float32), (K, 1))
-    lit = bool(np.any(ld)) and bool(scene._light_colors[0].any())
-    srec, drec = FB.update(t, poses, cam, ld, np.tile(scene._background_plane_pose[None], (K, 1, 1)).astype(np.float32), with_shadows=lit)
-    srec["ambient"][:, :3] = np.asarray(scene._ambient_light, np.float32)
-    srec["manual_exposure"] = scene._manual_exposure
+    hs, ho, tmpl = HR.describe([scene], eng.pool)
+    hsK = np.repeat(hs, K)
+    hsK["obj_begin"] = np.arange(K, dtype=np.uint32) * n
+    hsK["obj_end"] = hsK["obj_begin"] + n
+    hoK = np.tile(ho, K)
+    hoK["pose"] = hyp.reshape(K * n, 16)
+    lit = any(bool(np.any(hs[0]["light_dir"][i])) and bool(np.any(hs[0]["light_color"][i])) for i in range(_abi.NUM_LIGHTS))
+    srec, drec, crec = HR.build_from(hsK, hoK, tmpl, with_shadows=lit)
     mask = _abi.OUT_RGB | _abi.OUT_COORD | _abi.OUT_INSTANCE
-    buf = eng.render_records(srec, drec, t.crec, W, H, mask, ssao=ssao, shadows=lit)
-    d_poses = torch.from_numpy(hyp).to(eng.device)
-    ids = torch.tensor([o.instance_index for o in objs], dtype=torch.int32, device=eng.device)
-    P = np.ascontiguousarray(scene.projection_matrix().numpy(), dtype=np.float32)
-    valid = torch.empty((H, W), dtype=torch.uint8, device=eng.device)
-    acc = torch.empty(6 * n, dtype=torch.float64, device=eng.device)
-    res = torch.empty((K, n, 6), dtype=torch.float32, device=eng.device)
-    with torch.cuda.device(eng.device):
-        for k in range(K):
-            st = eng.L.slhip_diff_pose_backward(_p(buf.rgb[k]), _p(buf.coord[k]), _p(buf.instance[k]), _p(g[k] if per_hyp_grad else g),
-                                                C.c_void_p(P.ctypes.data), _p(d_poses[k]), _p(ids), n, H, W, _p(valid), _p(acc),
-                                                _p(res[k]), _stream(eng))
-            _abi.check(st, "slhip_diff_pose_backward")
+    buf = eng.render_records(srec, drec, crec, W, H, mask, ssao=ssao, shadows=lit)
+    res = pose_backward_batch_on_buffers(scene, buf, hyp, g)
     out = res.cpu()
     return (out, buf) if return_results else out
+
+
+def pose_backward_batch_on_buffers(scene, buf, hyp, g):
+    """The backward half of backpropagate_gradient_to_poses_batch on render targets that are already there: `buf` the [K,H,W,..]
+    buffers of the K hypotheses' renders, `hyp` float32[K,N,4,4] (numpy), `g` the gradient image(s) on the device.  ONE launch
+    sequence (slhip_diff_pose_backward_batch: the hypothesis is a grid dimension).  Returns float32[K,N,6] on the device."""
+    eng = engine()
+    objs = scene.objects
+    n, K = len(objs), hyp.shape[0]
+    W, H = scene.viewport
+    per_hyp_grad = g.dim() == 4
+    d_poses = torch.from_numpy(np.ascontiguousarray(hyp, dtype=np.float32)).to(eng.device)
+    ids = torch.tensor([o.instance_index for o in objs], dtype=torch.int32, device=eng.device)
+    P = np.ascontiguousarray(scene.projection_matrix().numpy(), dtype=np.float32)
+    valid = torch.empty((K, H, W), dtype=torch.uint8, device=eng.device)
+    acc = torch.empty(K * 6 * n, dtype=torch.float64, device=eng.device)
+    res = torch.empty((K, n, 6), dtype=torch.float32, device=eng.device)
+    with torch.cuda.device(eng.device):
+        st = eng.L.slhip_diff_pose_backward_batch(_p(buf.rgb), _p(buf.coord), _p(buf.instance), _p(g), 3 * H * W if per_hyp_grad else 0,
+                                                  C.c_void_p(P.ctypes.data), _p(d_poses), _p(ids), n, K, H, W, _p(valid), _p(acc),
+                                                  _p(res), _stream(eng))
+    _abi.check(st, "slhip_diff_pose_backward_batch")
+    return res
 
 
 def bp_to_vertices_and_colors(scene, render_result, grad_objective_wrt_rnd_img, visualize_grad=False):

@@ -44,11 +44,10 @@ def emit(name, **kw):
     print(json.dumps(dict(config=name, **kw)))
 
 
-def c1():
+def c1(B=256):
     m = sl.Mesh(S.CUBE)
     m.center_bbox()
     m.scale_to_bbox_diagonal(0.2)
-    B = 256
     scs = []
     for i in range(B):
         s = sl.Scene((320, 240), seed=i)
@@ -163,13 +162,16 @@ def c5():
     total = time.perf_counter() - t0
     # the batch form: all 32 hypotheses in one render launch sequence + 32 backward launches
     hyps = torch.stack([torch.stack([sl.diff.apply_pose_delta(base[k], deltas[h, k]) for k in range(64)]) for h in range(32)])
-    db = sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps, grad)
+    db, buf32 = sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps, grad, return_results=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
         db = sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps, grad)
     torch.cuda.synchronize()
     total_batch = (time.perf_counter() - t0) / 3
+    # the backward half alone, all 32 hypotheses in one launch sequence (3 launches)
+    hyp_np = hyps.numpy()
+    ms_bb = timed(lambda: sl.diff.pose_backward_batch_on_buffers(scene, buf32, hyp_np, grad), reps=10)
     agree = float((db[31] - d).abs().max() / max(1e-12, float(d.abs().max())))
     res = rp.render(scene)
     ms_b = timed(lambda: sl.diff.backpropagate_gradient_to_poses(scene, res, grad), reps=10)
@@ -177,14 +179,15 @@ def c5():
     emit("C5 sl.diff 64 objects x 32 hypotheses", s_total_32_hypotheses=total, ms_per_hypothesis_render_plus_backward=total / 32 * 1e3,
          s_total_32_hypotheses_batch_api=total_batch, ms_per_hypothesis_batch_api=total_batch / 32 * 1e3,
          batch_vs_loop_max_rel_diff=agree,
-         backward_ms=ms_b, grad_shape=list(d.shape),
-         roofline={"bound": "hbm", "kernel": "diff backward (4 launches)", "algorithmic_bytes": alg, "achieved": alg / (ms_b * 1e-3) / 1e9,
-                   "peak": PEAK, "unit": "GB/s", "frac": alg / (ms_b * 1e-3) / 1e9 / PEAK,
-                   "note": "10.8 MB per hypothesis: launch-latency bound at this size"})
+         backward_ms_single_hypothesis=ms_b, backward_ms_32_hypotheses_one_sequence=ms_bb, grad_shape=list(d.shape),
+         roofline={"bound": "hbm", "kernel": "diff backward, 32 hypotheses in one launch sequence (3 launches)",
+                   "algorithmic_bytes": 32 * alg, "achieved": 32 * alg / (ms_bb * 1e-3) / 1e9,
+                   "peak": PEAK, "unit": "GB/s", "frac": 32 * alg / (ms_bb * 1e-3) / 1e9 / PEAK,
+                   "note": "10.8 MB per hypothesis; one hypothesis alone (4 launches) is launch-latency bound: %.3f ms" % ms_b})
 
 
 if __name__ == "__main__":
     sl.init_cuda(0)
-    which = sys.argv[1:] or ["c1", "c3", "c4", "c5"]
+    which = sys.argv[1:] or ["c1", "c1big", "c3", "c4", "c5"]
     for w in which:
-        {"c1": c1, "c3": c3, "c4": c4, "c5": c5}[w]()
+        {"c1": c1, "c1big": lambda: c1(4096), "c3": c3, "c4": c4, "c5": c5}[w]()
