@@ -6,11 +6,11 @@ set -e
 cd "$(dirname "$0")/.."
 cp oracle/settle_ref.c /tmp/settle_ref.current.c
 trap 'cp /tmp/settle_ref.current.c oracle/settle_ref.c; python -c "import oracle; oracle.build(True)" >/dev/null 2>&1' EXIT
-for rev in 91c1c2e^ 91c1c2e 290ddf3^ 290ddf3 d531545^ d531545 HEAD; do
+for rev in 91c1c2e^ 91c1c2e 290ddf3^ 290ddf3 d531545^ d531545 574f050 fa62546 HEAD; do   # 574f050 = end of round 2, fa62546 = persistent manifolds
     if [ "$rev" = HEAD ]; then cp /tmp/settle_ref.current.c oracle/settle_ref.c; else git show "$rev:oracle/settle_ref.c" > oracle/settle_ref.c; fi
     # the trace hook of the current tests is not in the old files: harmless (unused by these tests)
     if python -c "import oracle; oracle.build(True)" >/dev/null 2>&1; then
-        r=$(python -m pytest tests/test_oracle_settle.py tests/test_oracle_physics_kat.py -q -p no:cacheprovider 2>&1 | tail -1)
+        r=$(python -m pytest tests/test_oracle_settle.py tests/test_oracle_physics_kat.py -q -p no:cacheprovider 2>&1 | tail -1); f=$(python -m pytest tests/test_oracle_settle.py tests/test_oracle_physics_kat.py -q -p no:cacheprovider 2>&1 | grep "^FAILED" | sed "s/.*:://" | tr "\n" " "); r="$r $f"
     else
         r="does not build against the current headers"
     fi
