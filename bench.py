@@ -43,9 +43,13 @@ def parse():
     ap.add_argument("--render-chunk", type=int, default=None,
                     help="scenes per render launch sequence (fewer, larger sequences: every kernel boundary is a chance for "
                          "queued settle workgroups to take the freed SIMDs); default 1024")
-    ap.add_argument("--settle-streams", type=int, default=2,
-                    help="settle launches kept in flight: scenes settle in very different times, and a second "
-                         "launch on its own stream back-fills the CUs the tail of the first one leaves idle")
+    ap.add_argument("--settle-streams", type=int, default=1,
+                    help="settle launches kept in flight on streams of their own (the render of the previous step always "
+                         "overlaps the settle of the next one)")
+    ap.add_argument("--render-streams", type=int, default=2,
+                    help="render streams the chunks of a step alternate between, each with its own scratch (60 GB per 1024-scene "
+                         "chunk, shadow maps included).  Round 3 on one MI355X, 6 steps: settle/render streams 2/1 -> 8 310, "
+                         "1/1 -> 8 410, 1/2 -> 8 555, 2/2 with 512-scene chunks -> 7 350 scenes/s (2/2 with 1024 does not fit 288 GB)")
     ap.add_argument("--gather-scenes", type=int, default=64,
                     help="N > 1: scenes per rank and step whose ground truth is all-gathered to every rank (BASELINE config C3: "
                          "512 scenes = 64 per GPU x 8); 0 = no exchange")
@@ -77,7 +81,7 @@ class Pipeline:
     the slhip_render launch sequences of the step's chunks on the render stream; `ring` SceneBatch record sets are
     recycled.  The host only enqueues: nothing is read back, no host thread sits between settle and render."""
 
-    def __init__(self, sl, table, batch, render_chunk, ssao, settle_streams, seed, rank):
+    def __init__(self, sl, table, batch, render_chunk, ssao, settle_streams, seed, rank, render_streams=1):
         from stillleben_amd import _abi
         from stillleben_amd._context import engine
 
@@ -97,6 +101,8 @@ class Pipeline:
         ps, pr = (int(x) for x in os.environ.get("SLHIP_BENCH_PRIO", "0,0").split(","))
         self.s_settle = [torch.cuda.Stream(device=dev, priority=ps) for _ in range(settle_streams)]
         self.s_render = torch.cuda.Stream(device=dev, priority=pr)
+        n_rs = max(1, int(render_streams))
+        self.s_render_all = [self.s_render] + [torch.cuda.Stream(device=dev, priority=pr) for _ in range(n_rs - 1)]
         self.free = [None] * self.ring        # event: the set's previous render finished (its records may be rewritten)
         self.buffers = []                     # ring of render-target sets: a chunk's ground truth stays in HBM until TARGET_RING
                                               # further chunks have been rendered (50 GB of the last 4096 scenes at the defaults)
@@ -127,9 +133,12 @@ class Pipeline:
             rec["placed"] = torch.cuda.Event(enable_timing=True)
             rec["placed"].record()
         revs = []
-        with torch.cuda.stream(self.s_render):
-            self.s_render.wait_event(rec["placed"])
-            for ci in range(b.n_render_chunks()):
+        for sr in self.s_render_all:
+            sr.wait_event(rec["placed"])
+        for ci in range(b.n_render_chunks()):
+            # (the chunks alternate between the render streams, every stream with its own scratch; a chunk and its target slot's
+            # previous user share a stream because TARGET_RING is a multiple of the stream count)
+            with torch.cuda.stream(self.s_render_all[ci % len(self.s_render_all)]):
                 slot = ci % TARGET_RING
                 if slot == 0:
                     for w in self.pending:
@@ -147,6 +156,11 @@ class Pipeline:
                     _, works = self.gatherer([t[:g] for t in (buf.rgb, buf.coord, buf.cls, buf.instance, buf.normals)],
                                              async_op=True)
                     self.pending = works
+        with torch.cuda.stream(self.s_render):
+            for sr in self.s_render_all[1:]:
+                ev = torch.cuda.Event()
+                ev.record(sr)
+                self.s_render.wait_event(ev)
             done = torch.cuda.Event()
             done.record()
             self.free[k % self.ring] = done
@@ -289,7 +303,8 @@ def main():
     if args.render_chunk is None:
         args.render_chunk = 1024
     args.render_chunk = min(args.render_chunk, args.batch)
-    pipe = Pipeline(sl, table, args.batch, args.render_chunk, not args.no_ssao, max(1, args.settle_streams), seed=20260929, rank=rank)
+    pipe = Pipeline(sl, table, args.batch, args.render_chunk, not args.no_ssao, max(1, args.settle_streams), seed=20260929, rank=rank,
+                    render_streams=min(max(1, args.render_streams), 2))
     pipe.eng.L.slhip_timing_enable(1)
     pipe.eng.L.slhip_settle_timing_enable(1)
     table.device()
@@ -577,7 +592,7 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
                         "matrix) and rendered at 640x480 (rgb, coord+depth, class, instance, normals; shadows on, SSAO %s) -- "
                         "all four stages inside the timed region" % (args.batch, "off" if args.no_ssao else "on"),
             "scenes_per_gpu_per_step": args.batch, "render_chunk": args.render_chunk, "resolution": list(RESOLUTION),
-            "objects": N_OBJECTS,
+            "objects": N_OBJECTS, "settle_streams": len(pipe.s_settle), "render_streams": len(pipe.s_render_all),
             "parallelism": ("scenes sharded by rank, no data-path collective; exchange: RCCL all-gather of a %d-scene C3 shard per "
                             "rank and step (%.0f MB per rank) -- %d of the %d scenes a rank renders per step are exchanged"
                             % (pipe.gather_scenes, pipe.gather_scenes * P * 40 / 1e6, pipe.gather_scenes, args.batch)) if world > 1 else "1 GPU",

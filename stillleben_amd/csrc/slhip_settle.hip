@@ -1358,12 +1358,12 @@ __device__ void update_world_inertia(const slhip_body& b, WBody& w)
 
 // mass-normalised kinetic energy of the sleep test (oracle step_scene (k)): 0.5 (v.v + w.(I w) / m), I = inverse of inv_inertia
 // in object axes by cofactors
-__device__ __forceinline__ float kinetic_energy(const slhip_body& b, const WBody& w)
+// (L: the 3x3 of the body record's inv_inertia rows, L[3 r + c] = inv_inertia[4 r + c])
+__device__ __forceinline__ float kinetic_energy(const float (&L)[9], const WBody& w)
 {
-    const float* L = b.inv_inertia;
     const v3 wl = m3_tmul(w.R, w.w);
-    const float c00 = L[5] * L[10] - L[6] * L[9], c01 = L[6] * L[8] - L[4] * L[10], c02 = L[4] * L[9] - L[5] * L[8];
-    const float c11 = L[0] * L[10] - L[2] * L[8], c12 = L[1] * L[8] - L[0] * L[9], c22 = L[0] * L[5] - L[1] * L[4];
+    const float c00 = L[4] * L[8] - L[5] * L[7], c01 = L[5] * L[6] - L[3] * L[8], c02 = L[3] * L[7] - L[4] * L[6];
+    const float c11 = L[0] * L[8] - L[2] * L[6], c12 = L[1] * L[6] - L[0] * L[7], c22 = L[0] * L[4] - L[1] * L[3];
     const float det = fmaf(L[2], c02, fmaf(L[1], c01, L[0] * c00));
     const v3 iw = V(fmaf(c02, wl.z, fmaf(c01, wl.y, c00 * wl.x)), fmaf(c12, wl.z, fmaf(c11, wl.y, c01 * wl.x)),
                     fmaf(c22, wl.z, fmaf(c12, wl.y, c02 * wl.x)));
