@@ -191,6 +191,8 @@ typedef struct {
                                             shadow texel is 1.0 and every tile bit 0 -- a render marks the 64x64-texel
                                             tiles its casters may touch and resets exactly those after shading, instead
                                             of clearing 16.8 MB per scene and light on every call                     */
+#define SLHIP_RENDER_KEEP_HDR 0x800u /* with SLHIP_RENDER_SSAO: also store the float image the tone map consumes (AO applied) in the
+                                        second half of scratch d_hdr -- the fused apply + tone-map pass otherwise never writes it */
 
 /* Result buffers, batch-major [B][H][W][C] -- the 8 colour attachments of
  * RenderPass::Result (reference include/stillleben/render_pass.h:48-78, formats

@@ -38,6 +38,7 @@ OUT_GT6 = 0x1F
 RENDER_SSAO = 0x100
 RENDER_SHADOWS = 0x200
 RENDER_SHADOW_RESET = 0x400
+RENDER_KEEP_HDR = 0x800
 ABI_VERSION = 2
 COMM_ID_BYTES = 128
 

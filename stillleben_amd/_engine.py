@@ -119,27 +119,27 @@ class Engine:
         return torch.from_numpy(raw.copy()).to(self.device)
 
     def render(self, scenes, mask=_abi.OUT_ALL, ssao=True, shadows=True, depth_peel=None, predicate=None,
-               buffers=None):
+               buffers=None, keep_hdr=False):
         W, H = scenes[0]._viewport
         for s in scenes:
             if s._viewport != (W, H):
                 raise ValueError("all scenes of a batch must share one viewport")
         want_rgb = bool(mask & _abi.OUT_RGB)
         srec, drec, crec = build_batch(scenes, self.pool, predicate, with_shadows=shadows and want_rgb)
-        return self.render_records(srec, drec, crec, W, H, mask, ssao, shadows, depth_peel, buffers)
+        return self.render_records(srec, drec, crec, W, H, mask, ssao, shadows, depth_peel, buffers, keep_hdr)
 
     def render_records(self, srec, drec, crec, W, H, mask=_abi.OUT_ALL, ssao=True, shadows=True, depth_peel=None,
-                       buffers=None):
+                       buffers=None, keep_hdr=False):
         """Renders a batch described by prebuilt slhip_scene / slhip_draw / slhip_chunk records (host arrays)."""
         d_s, d_d, d_c = self.upload_records(srec), self.upload_records(drec), self.upload_records(crec)
         n_clip = int(drec["n_verts"].sum()) if len(drec) else 0
         buffers = self.render_device(d_s, d_d, d_c, len(srec), len(drec), len(crec), n_clip, W, H, mask, ssao, shadows,
-                                     depth_peel, buffers)
+                                     depth_peel, buffers, keep_hdr)
         buffers._keepalive += (d_s, d_d, d_c)   # alive until the stream has consumed them
         return buffers
 
     def render_device(self, d_s, d_d, d_c, B, n_draws, n_chunks, n_clip, W, H, mask=_abi.OUT_ALL, ssao=True, shadows=True,
-                      depth_peel=None, buffers=None):
+                      depth_peel=None, buffers=None, keep_hdr=False):
         """slhip_render on records that already live in HBM (device tensors or raw device addresses):
         `n_clip` = clip-position slots the draws' clip_base + n_verts ranges span."""
         want_rgb = bool(mask & _abi.OUT_RGB)
@@ -161,6 +161,8 @@ class Engine:
         scratch.d_clip = _ptr(clips[stream])
         scratch.n_clip_verts = n_clip
         flags = mask | (_abi.RENDER_SSAO if ssao else 0) | (_abi.RENDER_SHADOWS if shadows else 0)
+        if keep_hdr:
+            flags |= _abi.RENDER_KEEP_HDR      # (tests: the float image behind the fused SSAO-apply + tone-map pass)
         if shadows and not keep["shadow_ready"]:
             flags |= _abi.RENDER_SHADOW_RESET
         keep["shadow_ready"] = False      # stays False if the call below raises: the next one resets again

@@ -1651,9 +1651,13 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
     ao[gp] = 1.0f - occlusion / 64.0f;
 }
 
-__global__ __launch_bounds__(256) void k_ssao_apply(unsigned n_scenes, int W, int H, const float* __restrict__ hdr_in,
-                                                    const float* __restrict__ ao, const float* __restrict__ zplane,
-                                                    float* __restrict__ hdr_out)
+// ... and the tone map of the result in the same pass (tone_map_shader.frag after ssao_apply_shader.frag): the blurred-AO colour
+// goes straight into tone_map_px, the float image is stored only on request (SLHIP_RENDER_KEEP_HDR).  `lum_scene`: the scene's
+// exposure luminance from k_lum_reduce (auto exposure), one float per scene at a stride of 4 * blocks_per_scene.
+__global__ __launch_bounds__(256) void k_ssao_apply(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
+                                                    const float* __restrict__ hdr_in, const float* __restrict__ ao,
+                                                    const float* __restrict__ zplane, float* __restrict__ hdr_out,
+                                                    const float* __restrict__ lum_scene, uint8_t* __restrict__ rgb)
 {
     const size_t P = (size_t)W * H;
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
@@ -1706,11 +1710,49 @@ __global__ __launch_bounds__(256) void k_ssao_apply(unsigned n_scenes, int W, in
         }
     const float a = result / wt;
     const float4 h = reinterpret_cast<const float4*>(hdr_in)[gp];
-    reinterpret_cast<float4*>(hdr_out)[gp] = make_float4(h.x * a, h.y * a, h.z * a, h.w);
+    const float c4[4] = {h.x * a, h.y * a, h.z * a, h.w};
+    if (hdr_out) reinterpret_cast<float4*>(hdr_out)[gp] = make_float4(c4[0], c4[1], c4[2], c4[3]);
+    if (rgb) {
+        const float manual = scenes[scene].manual_exposure;
+        const float lum = (manual >= 0.0f) ? 0.0f : lum_scene[(size_t)scene * blocks_per_scene * 4];
+        reinterpret_cast<uchar4*>(rgb)[gp] = tone_map_px(c4, manual, lum);
+    }
 }
 
+// Auto exposure (tone_map_shader.frag: the 1x1 mip of the HDR target): ONE block per scene adds the per-block sums k_shade left, in
+// a fixed order, and leaves the exposure luminance in the first float of the scene's partials (they are spent by then).  Every
+// block of the tone map used to repeat this reduction for itself: 1200 blocks x 19 KB of L2 reads per scene.
+__global__ __launch_bounds__(256) void k_lum_reduce(const slhip_scene* __restrict__ scenes, unsigned blocks_per_scene, size_t P,
+                                                    float* __restrict__ lum_part)
+{
+    const unsigned scene = blockIdx.x;
+    if (scenes[scene].manual_exposure >= 0.0f) return;
+    __shared__ float red[4][256];
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float* part = lum_part + (size_t)scene * blocks_per_scene * 4;
+    for (unsigned b = threadIdx.x; b < blocks_per_scene; b += 256)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += part[4 * b + c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = acc[c];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float inv = 1.0f / (float)P;
+        const float a0 = red[0][0] * inv, a1 = red[1][0] * inv, a2 = red[2][0] * inv, a3 = red[3][0] * inv;
+        part[0] = 0.1f * (0.2125f * (a0 / a3) + 0.7154f * (a1 / a3) + 0.0721f * (a2 / a3));
+    }
+}
+
+// tone map of the shaded image when no SSAO pass precedes it (with SSAO: k_ssao_apply)
 __global__ __launch_bounds__(256) void k_tonemap(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
-                                                 const float* __restrict__ hdr, const float* __restrict__ lum_part,
+                                                 const float* __restrict__ hdr, const float* __restrict__ lum_scene,
                                                  uint8_t* __restrict__ rgb)
 {
     const size_t P = (size_t)W * H;
@@ -1718,38 +1760,13 @@ __global__ __launch_bounds__(256) void k_tonemap(const slhip_scene* __restrict__
     unsigned scene, blk;
     if (!scene_block(blocks_per_scene, n_scenes, scene, blk)) return;
     const unsigned pix = blk * 256 + threadIdx.x;
-    const float manual = scenes[scene].manual_exposure;
-    __shared__ float s_lum;
-    if (!(manual >= 0.0f)) {
-        // every block re-reduces the scene's per-block partial sums in the same fixed order
-        __shared__ float red[4][256];
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float* part = lum_part + (size_t)scene * blocks_per_scene * 4;
-        for (unsigned b = threadIdx.x; b < blocks_per_scene; b += 256)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] += part[4 * b + c];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = acc[c];
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (threadIdx.x < s) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + s];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const float inv = 1.0f / (float)P;
-            const float a0 = red[0][0] * inv, a1 = red[1][0] * inv, a2 = red[2][0] * inv, a3 = red[3][0] * inv;
-            s_lum = 0.1f * (0.2125f * (a0 / a3) + 0.7154f * (a1 / a3) + 0.0721f * (a2 / a3));
-        }
-        __syncthreads();
-    }
     if (pix >= P) return;
+    const float manual = scenes[scene].manual_exposure;
+    const float lum = (manual >= 0.0f) ? 0.0f : lum_scene[(size_t)scene * blocks_per_scene * 4];
     const size_t gp = (size_t)scene * P + pix;
     const float4 h = reinterpret_cast<const float4*>(hdr)[gp];
     const float c[4] = {h.x, h.y, h.z, h.w};
-    reinterpret_cast<uchar4*>(rgb)[gp] = tone_map_px(c, manual, (manual >= 0.0f) ? 0.0f : s_lum);
+    reinterpret_cast<uchar4*>(rgb)[gp] = tone_map_px(c, manual, lum);
 }
 
 // clears the shadow maps of the ACTIVE lights only (blockIdx.y = scene * NUM_LIGHTS + light)
@@ -1979,7 +1996,7 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     }
 
     if (want_rgb) {
-        const float* tm_in = hdr0;
+        k_lum_reduce<<<n_scenes, 256, 0, stream>>>(d_scenes, (unsigned)((P + 255) / 256), P, scratch->d_lum);
         if (ssao) {
             mark(5, stream);
             const float* zpl = scratch->d_ao + (size_t)n_scenes * P;   // second half of d_ao
@@ -1988,11 +2005,13 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
             k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, out->d_cam_coord, out->d_normals, zpl, scratch->d_ao,
                                                    d_kernel_table);
             mark(6, stream);
-            k_ssao_apply<<<pix_blocks, 256, 0, stream>>>(n_scenes, W, H, hdr0, scratch->d_ao, zpl, hdr1);
-            tm_in = hdr1;
+            k_ssao_apply<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, hdr0, scratch->d_ao, zpl,
+                                                         (flags & SLHIP_RENDER_KEEP_HDR) ? hdr1 : nullptr, scratch->d_lum, out->d_rgb);
+            mark(7, stream);
+        } else {
+            mark(7, stream);
+            k_tonemap<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, hdr0, scratch->d_lum, out->d_rgb);
         }
-        mark(7, stream);
-        k_tonemap<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, tm_in, scratch->d_lum, out->d_rgb);
         SLHIP_LAUNCH_CHECK();
     }
     mark(kNumPhases, stream);

@@ -85,7 +85,7 @@ def test_hdr_colour_within_1e3_relative(sl, oracle, eng, ssao):
     scene.manual_exposure = 1.0
     W, H = scene.viewport
     mask = _abi.OUT_ALL
-    bufs = eng.render([scene], mask, ssao=ssao, shadows=True)
+    bufs = eng.render([scene], mask, ssao=ssao, shadows=True, keep_hdr=True)
     torch.cuda.synchronize()
     keep = bufs._keepalive[0]
     hdr = keep["hdr"].view(torch.float32)[: 2 * H * W * 4].reshape(2, H, W, 4)[1 if ssao else 0].cpu().numpy()
