@@ -23,7 +23,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = ["python", os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"]
-PMC_SHAPE = ["--steps", "1", "--warmup", "0", "--settle-streams", "1"]   # one step: every kernel of the path once, serialised
+PMC_SHAPE = ["--steps", "1", "--warmup", "0", "--settle-streams", "1", "--render-streams", "1"]   # one step: every kernel of the path once, serialised
 N_CAL = 1 << 31
 
 
