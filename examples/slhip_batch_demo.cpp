@@ -124,7 +124,7 @@ int main(int argc, char** argv)
     const uint32_t S_RES = 2048, QCAP = 1u << 20;
     uint64_t sz[7];
     SL_OK(slhip_render_scratch_bytes(n, W, H, S_RES, QCAP, sz));
-    slhip_render_scratch scr;
+    slhip_render_scratch scr = {};
     std::memset(&scr, 0, sizeof(scr));
     void* p[7];
     for (int i = 0; i < 7; ++i) HIP_OK(hipMalloc(&p[i], sz[i] > 16 ? sz[i] : 16));
@@ -132,7 +132,8 @@ int main(int argc, char** argv)
     scr.d_queue = (uint32_t*)p[4]; scr.d_lum = (float*)p[5]; scr.d_shadow_tiles = (uint32_t*)p[6];
     scr.queue_capacity = QCAP; scr.shadow_res = S_RES;
     scr.n_clip_verts = n * sp.max_clip_verts_per_scene;
-    HIP_OK(hipMalloc((void**)&scr.d_clip, (size_t)scr.n_clip_verts * 4 * 16));
+    HIP_OK(hipMalloc((void**)&scr.d_clip, (size_t)scr.n_clip_verts * 9 * 16));   // 4 clip planes + 80 B per vertex of vertex cache
+    scr.d_vattr = scr.d_clip + (size_t)scr.n_clip_verts * 4 * 4;
     const size_t P = (size_t)W * H;
     slhip_render_out out;
     std::memset(&out, 0, sizeof(out));

@@ -223,7 +223,14 @@ typedef struct {
     uint32_t  queue_capacity; /* number of (prim,tile) pairs that fit                        */
     uint32_t  shadow_res;     /* S (reference: 2048, render_pass.cpp:271)                    */
     uint32_t  n_clip_verts;   /* sum of n_verts over the draws of the batch                  */
-    uint32_t  _pad;
+    uint32_t  shadow_lights;  /* light maps per scene in d_shadow: 0 = SLHIP_NUM_LIGHTS; 1 or 2 = d_shadow is
+                                 [B, shadow_lights, S, S] (lights beyond the count cast no shadow)  */
+    float*    d_vattr;        /* n_clip_verts x 80 B, 64-byte aligned: the rest of the vertex stage
+                                 (render_shader.vert:57-95) once per vertex -- [n_clip_verts] records of 64 B: (object xyz,
+                                 camera z), (world xyz, camera x), (world normal, camera y), window coordinates (x, y in
+                                 1/256 px as i32, depth, 1/w; x = INT_MIN behind the near plane) -- followed by the window
+                                 coordinates once more as a dense [n_clip_verts] x 16 B plane.  (The light planes of d_clip
+                                 end up holding window coordinates of the shadow map instead of clip positions.)        */
 } slhip_render_scratch;
 
 /* Renders a batch of scenes.  Replaces RenderPass::render (src/render_pass.cpp:303-796):

@@ -180,7 +180,8 @@ class RenderScratch(C.Structure):
         ("queue_capacity", C.c_uint32),
         ("shadow_res", C.c_uint32),
         ("n_clip_verts", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("shadow_lights", C.c_uint32),
+        ("d_vattr", C.c_void_p),
     ]
 
 

@@ -85,8 +85,10 @@ class Engine:
         return p
 
     # ---- scratch ---------------------------------------------------------------------------
-    def scratch(self, B, H, W, want_rgb, ssao, shadows, stream=0):
-        key = (B, H, W, want_rgb, ssao, shadows, stream)   # per stream: launches on different streams may overlap
+    def scratch(self, B, H, W, want_rgb, ssao, shadows, stream=0, shadow_lights=_abi.NUM_LIGHTS, keep_hdr=False):
+        # per stream: launches on different streams may overlap.  `shadow_lights`: shadow maps per scene (a batch whose scenes
+        # only use the first lights need not carry 16.8 MB per scene for every unused one)
+        key = (B, H, W, want_rgb, ssao, shadows, stream, shadow_lights, keep_hdr)
         s = self._scratch.get(key)
         if s is None:
             sizes = (C.c_uint64 * 7)()
@@ -97,8 +99,9 @@ class Engine:
                 return torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device) if need else None
 
             s = {
-                "vis": buf(sizes[0]), "hdr": buf(sizes[1], want_rgb), "ao": buf(sizes[2], ssao),
-                "shadow": buf(sizes[3], shadows), "queue": buf(sizes[4]), "lum": buf(sizes[5], want_rgb),
+                # (the second half of d_hdr is only written under RENDER_KEEP_HDR)
+                "vis": buf(sizes[0]), "hdr": buf(sizes[1] if keep_hdr else sizes[1] // 2, want_rgb), "ao": buf(sizes[2], ssao),
+                "shadow": buf(sizes[3] // _abi.NUM_LIGHTS * shadow_lights, shadows), "queue": buf(sizes[4]), "lum": buf(sizes[5], want_rgb),
                 "tiles": buf(sizes[6], shadows), "qcap": qcap,
                 "shadow_ready": False,    # the shadow maps / tile bits are garbage until the first call has reset them
             }
@@ -111,6 +114,7 @@ class Engine:
         a.d_shadow_tiles = _ptr(s["tiles"])
         a.queue_capacity = s["qcap"]
         a.shadow_res = SHADOW_RES
+        a.shadow_lights = shadow_lights
         return a, s
 
     # ---- render ----------------------------------------------------------------------------
@@ -133,15 +137,19 @@ class Engine:
         """Renders a batch described by prebuilt slhip_scene / slhip_draw / slhip_chunk records (host arrays)."""
         d_s, d_d, d_c = self.upload_records(srec), self.upload_records(drec), self.upload_records(crec)
         n_clip = int(drec["n_verts"].sum()) if len(drec) else 0
+        # shadow maps for the lights the batch uses (a light with zero colour or direction is off: light_active() of the kernels)
+        on = (np.abs(srec["light_color"][:, :, :3]).sum(axis=2) > 0) & (np.abs(srec["light_dir"][:, :, :3]).sum(axis=2) > 0)
+        lights = max(1, int(np.max(np.nonzero(on.any(axis=0))[0]) + 1)) if on.any() else 1
         buffers = self.render_device(d_s, d_d, d_c, len(srec), len(drec), len(crec), n_clip, W, H, mask, ssao, shadows,
-                                     depth_peel, buffers, keep_hdr)
+                                     depth_peel, buffers, keep_hdr, shadow_lights=lights)
         buffers._keepalive += (d_s, d_d, d_c)   # alive until the stream has consumed them
         return buffers
 
     def render_device(self, d_s, d_d, d_c, B, n_draws, n_chunks, n_clip, W, H, mask=_abi.OUT_ALL, ssao=True, shadows=True,
-                      depth_peel=None, buffers=None, keep_hdr=False):
+                      depth_peel=None, buffers=None, keep_hdr=False, shadow_lights=_abi.NUM_LIGHTS):
         """slhip_render on records that already live in HBM (device tensors or raw device addresses):
-        `n_clip` = clip-position slots the draws' clip_base + n_verts ranges span."""
+        `n_clip` = clip-position slots the draws' clip_base + n_verts ranges span; `shadow_lights` = shadow maps per scene
+        (lights with a higher index cast no shadow)."""
         want_rgb = bool(mask & _abi.OUT_RGB)
         ssao = ssao and want_rgb
         shadows = shadows and want_rgb
@@ -152,14 +160,18 @@ class Engine:
             buffers = RenderBuffers(self.device, B, H, W, mask)
         out = buffers.abi()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        scratch, keep = self.scratch(B, H, W, want_rgb, ssao, shadows, stream)
+        scratch, keep = self.scratch(B, H, W, want_rgb, ssao, shadows, stream, shadow_lights if shadows else _abi.NUM_LIGHTS, keep_hdr)
         planes = 1 + (_abi.NUM_LIGHTS if shadows else 0)
-        need = max(16, n_clip * planes * 16)
+        # + 80 B per vertex: the post-transform vertex cache of the raster and shading passes (64-byte records = cache lines,
+        # then a dense plane of window coordinates)
+        voff = (n_clip * planes * 16 + 63) & ~63
+        need = max(16, voff + n_clip * 80)
         clips = self.__dict__.setdefault("_clips", {})
         if clips.get(stream) is None or clips[stream].numel() < need:
             clips[stream] = torch.empty(need, dtype=torch.uint8, device=self.device)
         scratch.d_clip = _ptr(clips[stream])
         scratch.n_clip_verts = n_clip
+        scratch.d_vattr = C.c_void_p(clips[stream].data_ptr() + voff)
         flags = mask | (_abi.RENDER_SSAO if ssao else 0) | (_abi.RENDER_SHADOWS if shadows else 0)
         if keep_hdr:
             flags |= _abi.RENDER_KEEP_HDR      # (tests: the float image behind the fused SSAO-apply + tone-map pass)

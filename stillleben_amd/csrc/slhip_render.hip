@@ -118,21 +118,20 @@ __device__ __forceinline__ int snap(float w)
     return (int)s;
 }
 
-// c0..c2: clip-space positions.  Returns false if degenerate or outside the W x H target.
-__device__ __forceinline__ bool setup_tri(const float* c0, const float* c1, const float* c2, int W,
-                                          int H, Setup& t)
+// window coordinates of one clip-space position: 1/256-px snapped x / y, depth in [0, 1], 1 / w
+__device__ __forceinline__ void screen_vertex(const float* c, float hw, float hh, int& X, int& Y, float& z, float& invw)
 {
-    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
-    const float* cs[3] = {c0, c1, c2};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float* c = cs[i];
-        float xn = c[0] / c[3], yn = c[1] / c[3], zn = c[2] / c[3];
-        t.X[i] = snap(fmaf(xn, hw, hw));
-        t.Y[i] = snap(fmaf(yn, hh, hh));
-        t.z[i] = fmaf(zn, 0.5f, 0.5f);
-        t.invw[i] = 1.0f / c[3];
-    }
+    const float xn = c[0] / c[3], yn = c[1] / c[3], zn = c[2] / c[3];
+    X = snap(fmaf(xn, hw, hw));
+    Y = snap(fmaf(yn, hh, hh));
+    z = fmaf(zn, 0.5f, 0.5f);
+    invw = 1.0f / c[3];
+}
+
+// X / Y / z / invw are filled in: signed area, ownership of the edges, pixel box.  Returns false if degenerate or outside
+// the W x H target.
+__device__ __forceinline__ bool setup_finish(int W, int H, Setup& t)
+{
     long long area2 = (long long)(t.X[1] - t.X[0]) * (long long)(t.Y[2] - t.Y[0]) -
                       (long long)(t.Y[1] - t.Y[0]) * (long long)(t.X[2] - t.X[0]);
     if (area2 == 0) return false;
@@ -155,6 +154,33 @@ __device__ __forceinline__ bool setup_tri(const float* c0, const float* c1, cons
     if (x0 > x1 || y0 > y1) return false;
     t.xmin = x0; t.xmax = x1; t.ymin = y0; t.ymax = y1;
     return true;
+}
+
+// c0..c2: clip-space positions.  Returns false if degenerate or outside the W x H target.
+__device__ __forceinline__ bool setup_tri(const float* c0, const float* c1, const float* c2, int W,
+                                          int H, Setup& t)
+{
+    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    const float* cs[3] = {c0, c1, c2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) screen_vertex(cs[i], hw, hh, t.X[i], t.Y[i], t.z[i], t.invw[i]);
+    return setup_finish(W, H, t);
+}
+
+// The vertex pass (k_vertex_attr) stores screen_vertex() of every vertex in front of the near plane as one float4 (X and Y
+// as integer bit patterns); a vertex behind the plane gets kScreenClipped in X -- snap() never returns it -- and its triangles
+// take the clip-space path.  A triangle whose three corners are stored is set up without a single division.
+constexpr int kScreenClipped = (int)0x80000000;
+__device__ __forceinline__ bool setup_from_screen(const uint4& s0, const uint4& s1, const uint4& s2, int W, int H, Setup& t)
+{
+    t.X[0] = (int)s0.x; t.Y[0] = (int)s0.y; t.z[0] = __uint_as_float(s0.z); t.invw[0] = __uint_as_float(s0.w);
+    t.X[1] = (int)s1.x; t.Y[1] = (int)s1.y; t.z[1] = __uint_as_float(s1.z); t.invw[1] = __uint_as_float(s1.w);
+    t.X[2] = (int)s2.x; t.Y[2] = (int)s2.y; t.z[2] = __uint_as_float(s2.z); t.invw[2] = __uint_as_float(s2.w);
+    return setup_finish(W, H, t);
+}
+__device__ __forceinline__ bool screen_all_inside(const uint4& s0, const uint4& s1, const uint4& s2)
+{
+    return (int)s0.x != kScreenClipped && (int)s1.x != kScreenClipped && (int)s2.x != kScreenClipped;
 }
 
 // coverage + screen-space barycentrics at pixel (px,py) (R4, R5)
@@ -359,12 +385,63 @@ __global__ __launch_bounds__(256) void k_vertex_xform(slhip_mesh_pool pool, cons
     }
 }
 
+// k_vertex_attr: the REST of the vertex stage once per vertex (thread = vertex) -- a post-transform vertex cache.  Per vertex
+// one 64-byte record: (object xyz, camera z), (world xyz, camera x), (world normal, camera y) = vertex_full(), and the window
+// coordinates screen_vertex() of the clip position k_vertex_xform wrote (kScreenClipped behind the near plane); the window
+// coordinates also as a dense plane behind the records.  The shading pass then fetches one cache line per corner instead of
+// re-running three matrix products, nine divisions and a normalisation per corner of every PIXEL and twelve more divisions
+// per triangle set-up (160 k vertices per C2 scene against 3 x 307 k pixel corners); the raster pass sets its triangles up
+// from the dense plane.  Same functions, same inputs, same bits as the per-pixel evaluation they replace.
+__global__ __launch_bounds__(256) void k_vertex_attr(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+                                                     const slhip_draw* __restrict__ draws, float4* __restrict__ clip,
+                                                     unsigned n_clip_verts, float4* __restrict__ vattr, int W, int H,
+                                                     int with_lights, int S)
+{
+    const slhip_draw* dr = draws + blockIdx.x;
+    const unsigned nv = dr->n_verts;
+    if (blockIdx.y * 256 >= nv) return;
+    const slhip_scene* sc = scenes + dr->scene;
+    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H, hs = 0.5f * (float)S;
+    for (unsigned v = blockIdx.y * 256 + threadIdx.x; v < nv; v += gridDim.y * 256) {
+        // the light clip positions (planes 1..3) become window coordinates of the S x S map IN PLACE: the shadow pass clips
+        // nothing, so its set-up never needs the clip position itself
+        if (with_lights)
+            for (int l = 0; l < SLHIP_NUM_LIGHTS; ++l) {
+                if (!light_active(sc, l)) continue;
+                float4* slot = clip + (size_t)(1 + l) * n_clip_verts + dr->clip_base + v;
+                const float4 l4 = *slot;
+                const float lc[4] = {l4.x, l4.y, l4.z, l4.w};
+                int X, Y;
+                float z, invw;
+                screen_vertex(lc, hs, hs, X, Y, z, invw);
+                *reinterpret_cast<uint4*>(slot) = make_uint4((unsigned)X, (unsigned)Y, __float_as_uint(z), __float_as_uint(invw));
+            }
+        VsOut o;
+        vertex_full(pool, sc, dr, dr->vtx_base + v, o);
+        const float4 c4 = clip[dr->clip_base + v];
+        const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+        int X = kScreenClipped, Y = 0;
+        float z = 0.0f, invw = 0.0f;
+        if (c[2] >= -c[3]) screen_vertex(c, hw, hh, X, Y, z, invw);   // the inside test of clip_near()
+        // one 64-byte record per vertex for the shading pass (one cache line per pixel corner) ...
+        float4* dst = vattr + 4 * (size_t)(dr->clip_base + v);
+        const uint4 scr = make_uint4((unsigned)X, (unsigned)Y, __float_as_uint(z), __float_as_uint(invw));
+        dst[0] = make_float4(o.objc[0], o.objc[1], o.objc[2], o.cam[2]);
+        dst[1] = make_float4(o.world[0], o.world[1], o.world[2], o.cam[0]);
+        dst[2] = make_float4(o.nrm[0], o.nrm[1], o.nrm[2], o.cam[1]);
+        reinterpret_cast<uint4*>(dst)[3] = scr;
+        // ... and the window coordinates once more as a dense plane for the raster pass (16 B per vertex, like the clip plane)
+        reinterpret_cast<uint4*>(vattr)[4 * (size_t)n_clip_verts + dr->clip_base + v] = scr;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // texture fetch: bilinear, mip 0, repeat
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wrapi(int i, int n)
 {
-    int m = i % n;
+    if ((n & (n - 1)) == 0) return i & (n - 1);   // power of two: the low bits of a two's-complement i ARE the non-negative remainder
+    int m = i % n;                                // (an integer division is ~40 instructions on this machine)
     return m < 0 ? m + n : m;
 }
 
@@ -452,8 +529,7 @@ __device__ __forceinline__ void tex_sample(const uint8_t* __restrict__ tex, int 
         tex_level(tex, w, h, sampler, (sampler & (magnify ? SLHIP_SAMPLER_MAG_LINEAR : SLHIP_SAMPLER_MIN_LINEAR)) != 0u, u, v, out);
         return;
     }
-    int top = 0;
-    for (int m = max(w, h); m > 1; m >>= 1) ++top;  // last level = floor(log2(max(w, h)))
+    const int top = 31 - __clz(max(max(w, h), 1));  // last level = floor(log2(max(w, h)))
     const float lambda = fminf(det_log2(rho), (float)top);
     const bool lin = (sampler & SLHIP_SAMPLER_MIN_LINEAR) != 0u;
     int lw, lh;
@@ -473,7 +549,8 @@ __device__ __forceinline__ void tex_sample(const uint8_t* __restrict__ tex, int 
         for (int c = 0; c < 4; ++c) out[c] = a[c];
         return;
     }
-    const uint8_t* p1 = tex_level_ptr(tex, w, h, l1, lw, lh);
+    const uint8_t* p1 = p0 + 4 * (size_t)lw * lh;   // l1 == l0 + 1: the next level follows level l0
+    lw = max(1, lw >> 1); lh = max(1, lh >> 1);
     tex_level(p1, lw, lh, sampler, lin, u, v, b);
 #pragma unroll
     for (int c = 0; c < 4; ++c) out[c] = fmaf(f, b[c] - a[c], a[c]);
@@ -690,87 +767,117 @@ __device__ __forceinline__ void raster_or_enqueue(const Setup& t, const Target& 
 // ---------------------------------------------------------------------------------------------
 // k_raster: main pass, one thread per triangle
 // ---------------------------------------------------------------------------------------------
+// Two instantiations over the same chunk list; a chunk (block) belongs to exactly one of them, the other returns at once:
+//   kAttr = false: plain triangles -- depth and primitive id only.  No texture sampling, no per-vertex attributes: a fraction
+//                  of the registers of the general form (the kernel's time follows its waves per SIMD), and triangles
+//                  entirely in front of the near plane are set up from the window coordinates k_vertex_attr stored per
+//                  vertex (`screen`), without a division;
+//   kAttr = true:  chunks whose fragments may be discarded before the depth write (alpha test against the base texture,
+//                  depth peeling): barycentrics, texture coordinates and camera z per fragment.
+template <bool kAttr>
 __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                 const slhip_draw* __restrict__ draws,
                                                 const slhip_chunk* __restrict__ chunks, int W, int H,
                                                 const float* __restrict__ depth_peel,
                                                 unsigned long long* __restrict__ vis, unsigned* queue,
-                                                unsigned capacity, const float4* __restrict__ clipbuf)
+                                                unsigned capacity, const float4* __restrict__ clipbuf,
+                                                const uint4* __restrict__ screen)
 {
     const slhip_chunk ch = chunks[blockIdx.x];
     if (threadIdx.x >= ch.count) return;
     const slhip_scene* sc = scenes + ch.scene;
     const slhip_draw* dr = draws + ch.draw;
+    const bool alpha_test = (dr->flags & SLHIP_DRAW_ALPHA_TEST) && (dr->flags & SLHIP_DRAW_HAS_BASE_TEX);
+    if ((alpha_test || depth_peel != nullptr) != kAttr) return;      // block-uniform: the chunk is the other instantiation's
     const unsigned tri = ch.first_tri + threadIdx.x;
     const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
     const unsigned vi[3] = {ip[0], ip[1], ip[2]};
-
-    ClipVert cv[3];
-    float camz[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float4 c4 = clipbuf[dr->clip_base + vi[k]];   // written by k_vertex_xform (MFMA)
-        cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
-        if (depth_peel) {  // camera z of the vertex (shader chain) for the depth-peel test
-            float unused[4];
-            vertex_clip(pool, sc, dr, dr->vtx_base + vi[k], unused, camz[k]);
-        }
-        cv[k].bary[0] = k == 0 ? 1.0f : 0.0f;
-        cv[k].bary[1] = k == 1 ? 1.0f : 0.0f;
-        cv[k].bary[2] = k == 2 ? 1.0f : 0.0f;
-    }
-    ClipVert poly[4];
-    const int n = clip_near(cv, poly);
-    if (n == 0) return;
-
     const size_t P = (size_t)W * H;
     MainTarget tgt;
     tgt.vis = vis + (size_t)ch.scene * P;
-    tgt.peel = depth_peel ? depth_peel + 4 * (size_t)ch.scene * P : nullptr;
     tgt.W = W;
     tgt.prim = dr->prim_base + tri;
-    const bool alpha_test = (dr->flags & SLHIP_DRAW_ALPHA_TEST) && (dr->flags & SLHIP_DRAW_HAS_BASE_TEX);
-    tgt.need_attr = alpha_test || tgt.peel != nullptr;
-    float uvs[6] = {0, 0, 0, 0, 0, 0};
+    tgt.need_attr = kAttr;
+    tgt.peel = nullptr;
     tgt.tex = nullptr;
-    if (alpha_test) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float2 uv = reinterpret_cast<const float2*>(pool.d_uv)[dr->vtx_base + vi[k]];
-            uvs[2 * k] = uv.x; uvs[2 * k + 1] = uv.y;
-        }
-        tgt.tex = pool.d_tex + dr->tex_offset;
-        tgt.tex_w = (int)dr->tex_w; tgt.tex_h = (int)dr->tex_h;
-        tgt.tex_sampler = dr->tex_sampler[0];
-    }
-    tgt.camz = camz;
-    tgt.uv = uvs;
-    tgt.base_alpha = dr->base_color[3];
-    tgt.alpha_cutoff = dr->alpha_cutoff;
 
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {   // n <= 4: at most two sub-triangles; unrolled so that poly[] keeps static indices
-        if (sub >= n - 2) break;
-        Setup t;
-        if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
-        float bary[9];
+    if constexpr (!kAttr) {
+        tgt.camz = nullptr; tgt.uv = nullptr; tgt.bary = nullptr;
+        const uint4 s0 = screen[dr->clip_base + vi[0]], s1 = screen[dr->clip_base + vi[1]], s2 = screen[dr->clip_base + vi[2]];
+        if (screen_all_inside(s0, s1, s2)) {     // clip_near() would hand the triangle through
+            Setup t;
+            if (setup_from_screen(s0, s1, s2, W, H, t)) raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene);
+            return;
+        }
+        ClipVert cv[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            bary[k] = poly[0].bary[k];
-            bary[3 + k] = poly[sub + 1].bary[k];
-            bary[6 + k] = poly[sub + 2].bary[k];
+            const float4 c4 = clipbuf[dr->clip_base + vi[k]];   // written by k_vertex_xform (MFMA)
+            cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
+            cv[k].bary[0] = cv[k].bary[1] = cv[k].bary[2] = 0.0f;   // (not needed here)
         }
-        tgt.bary = bary;
-        // the discard tests need per-vertex data that only this thread holds: keep such
-        // triangles in place
-        if (tgt.need_attr) {
+        ClipVert poly[4];
+        const int n = clip_near(cv, poly);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {   // n <= 4: at most two sub-triangles; unrolled so that poly[] keeps static indices
+            if (sub >= n - 2) break;
+            Setup t;
+            if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
+            raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri | ((unsigned)sub << 31), ch.scene);
+        }
+    } else {
+        ClipVert cv[3];
+        float camz[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 c4 = clipbuf[dr->clip_base + vi[k]];   // written by k_vertex_xform (MFMA)
+            cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
+            if (depth_peel) {  // camera z of the vertex (shader chain) for the depth-peel test
+                float unused[4];
+                vertex_clip(pool, sc, dr, dr->vtx_base + vi[k], unused, camz[k]);
+            }
+            cv[k].bary[0] = k == 0 ? 1.0f : 0.0f;
+            cv[k].bary[1] = k == 1 ? 1.0f : 0.0f;
+            cv[k].bary[2] = k == 2 ? 1.0f : 0.0f;
+        }
+        ClipVert poly[4];
+        const int n = clip_near(cv, poly);
+        if (n == 0) return;
+        tgt.peel = depth_peel ? depth_peel + 4 * (size_t)ch.scene * P : nullptr;
+        float uvs[6] = {0, 0, 0, 0, 0, 0};
+        if (alpha_test) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float2 uv = reinterpret_cast<const float2*>(pool.d_uv)[dr->vtx_base + vi[k]];
+                uvs[2 * k] = uv.x; uvs[2 * k + 1] = uv.y;
+            }
+            tgt.tex = pool.d_tex + dr->tex_offset;
+            tgt.tex_w = (int)dr->tex_w; tgt.tex_h = (int)dr->tex_h;
+            tgt.tex_sampler = dr->tex_sampler[0];
+        }
+        tgt.camz = camz;
+        tgt.uv = uvs;
+        tgt.base_alpha = dr->base_color[3];
+        tgt.alpha_cutoff = dr->alpha_cutoff;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (sub >= n - 2) break;
+            Setup t;
+            if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
+            float bary[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                bary[k] = poly[0].bary[k];
+                bary[3 + k] = poly[sub + 1].bary[k];
+                bary[6 + k] = poly[sub + 2].bary[k];
+            }
+            tgt.bary = bary;
+            // the discard tests need per-vertex data that only this thread holds: such triangles stay in place
             for (int py = t.ymin; py <= t.ymax; ++py)
                 for (int px = t.xmin; px <= t.xmax; ++px) {
                     float l[3];
                     if (coverage(t, px, py, l)) tgt.emit(t, px, py, l);
                 }
-        } else {
-            raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri | ((unsigned)sub << 31), ch.scene);
         }
     }
 }
@@ -782,7 +889,7 @@ __global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip
                                                const slhip_draw* __restrict__ draws, int W, int H,
                                                unsigned long long* __restrict__ vis,
                                                const unsigned* __restrict__ queue, unsigned capacity,
-                                               const float4* __restrict__ clipbuf)
+                                               const float4* __restrict__ clipbuf, const uint4* __restrict__ screen)
 {
     const unsigned count = min(queue[0], capacity);
     const QItem* items = reinterpret_cast<const QItem*>(queue + 4);
@@ -805,18 +912,23 @@ __global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip
             const int sub = (int)(it.tri_sub >> 31);
             const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
             ClipVert cv[3];
+            const uint4 s0 = screen[dr->clip_base + ip[0]], s1 = screen[dr->clip_base + ip[1]], s2 = screen[dr->clip_base + ip[2]];
+            const bool cached = screen_all_inside(s0, s1, s2);
+            if (cached && (sub != 0 || !setup_from_screen(s0, s1, s2, W, H, t))) continue;
+            if (!cached) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float4 c4 = clipbuf[dr->clip_base + ip[k]];
-                cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
-                cv[k].bary[0] = cv[k].bary[1] = cv[k].bary[2] = 0.0f;
+                for (int k = 0; k < 3; ++k) {
+                    const float4 c4 = clipbuf[dr->clip_base + ip[k]];
+                    cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
+                    cv[k].bary[0] = cv[k].bary[1] = cv[k].bary[2] = 0.0f;
+                }
+                ClipVert poly[4];
+                const int n = clip_near(cv, poly);
+                if (sub > n - 3) continue;
+                const ClipVert& pb = sub == 0 ? poly[1] : poly[2];
+                const ClipVert& pc = sub == 0 ? poly[2] : poly[3];
+                if (!setup_tri(poly[0].clip, pb.clip, pc.clip, W, H, t)) continue;
             }
-            ClipVert poly[4];
-            const int n = clip_near(cv, poly);
-            if (sub > n - 3) continue;
-            const ClipVert& pb = sub == 0 ? poly[1] : poly[2];
-            const ClipVert& pc = sub == 0 ? poly[2] : poly[3];
-            if (!setup_tri(poly[0].clip, pb.clip, pc.clip, W, H, t)) continue;
             prim = dr->prim_base + tri;
             ok = true;
         }
@@ -869,7 +981,7 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
                                                        const slhip_chunk* __restrict__ chunks, int S,
                                                        unsigned* __restrict__ shadow, unsigned* queue,
                                                        unsigned capacity, const float4* __restrict__ clipbuf,
-                                                       unsigned n_clip_verts, unsigned* __restrict__ tile_bits)
+                                                       unsigned n_clip_verts, unsigned* __restrict__ tile_bits, int nl)
 {
     __shared__ unsigned bm[SLHIP_NUM_LIGHTS][kShadowMaxWords];   // the chunk's touched tiles, ORed into the scene's bits at the end
     const slhip_chunk ch = chunks[blockIdx.x];
@@ -886,14 +998,13 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
     const unsigned i0 = ip[0], i1 = ip[1], i2 = ip[2];
     // one block per chunk, the (few) active lights in a loop: the index fetch is shared and no
     // workgroups are launched for lights that are off
-    for (int light = 0; light < SLHIP_NUM_LIGHTS; ++light) {
+    for (int light = 0; light < nl; ++light) {    // (lights beyond the nl maps the caller provided cast no shadow)
         if (!light_active(sc, light)) continue;
         if (!have_tri) continue;
         const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
-        const float4 a4 = plane[i0], b4 = plane[i1], c4 = plane[i2];
-        const float c0[4] = {a4.x, a4.y, a4.z, a4.w}, c1[4] = {b4.x, b4.y, b4.z, b4.w}, c2[4] = {c4.x, c4.y, c4.z, c4.w};
         Setup t;
-        if (!setup_tri(c0, c1, c2, S, S, t)) continue;
+        const uint4* sp = reinterpret_cast<const uint4*>(plane);   // k_vertex_attr turned the light's clip positions into window coordinates
+        if (!setup_from_screen(sp[i0], sp[i1], sp[i2], S, S, t)) continue;
         if (t.flipped) continue;  // front face culled
         // tiles of the triangle's pixel box (a 16k-triangle object: almost always one tile, at most a handful)
         if (words <= kShadowMaxWords) {
@@ -905,14 +1016,14 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
                 }
         }
         ShadowTarget tgt;
-        tgt.sm = shadow + ((size_t)ch.scene * SLHIP_NUM_LIGHTS + light) * S * S;
+        tgt.sm = shadow + ((size_t)ch.scene * nl + light) * S * S;
         tgt.W = S;
         raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene | ((unsigned)light << 24));
     }
     __syncthreads();
     for (int k = (int)threadIdx.x; k < SLHIP_NUM_LIGHTS * words; k += 256) {
         const int light = k / words, w = k % words;
-        if (!light_active(sc, light)) continue;
+        if (light >= nl || !light_active(sc, light)) continue;
         // maps with more tiles than the LDS bitmap holds (shadow_res > 2048) are marked wholesale
         const unsigned m = words <= kShadowMaxWords ? bm[light][w] : 0xFFFFFFFFu;
         if (m) atomicOr(tile_bits + ((size_t)ch.scene * SLHIP_NUM_LIGHTS + light) * words + w, m);
@@ -921,15 +1032,17 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
 
 // after the shading pass: every marked tile back to 1.0, its bit cleared (one block per 32-tile word)
 __global__ __launch_bounds__(256) void k_shadow_restore(unsigned* __restrict__ shadow, unsigned* __restrict__ tile_bits, int S,
-                                                        unsigned n_words_total)
+                                                        unsigned n_words_total, int nl)
 {
     const unsigned wi = blockIdx.x;
     if (wi >= n_words_total) return;
     unsigned m = tile_bits[wi];
     if (m == 0u) return;
     const int words = shadow_tile_words(S), tx_n = shadow_tiles_x(S);
-    const unsigned map = wi / (unsigned)words, w = wi % (unsigned)words;
-    unsigned* base = shadow + (size_t)map * S * S;
+    const unsigned map = wi / (unsigned)words, w = wi % (unsigned)words;       // tile bits: [scene][SLHIP_NUM_LIGHTS][words]
+    const unsigned m_scene = map / SLHIP_NUM_LIGHTS, m_light = map % SLHIP_NUM_LIGHTS;
+    if ((int)m_light >= nl) return;                                            // maps: [scene][nl]
+    unsigned* base = shadow + ((size_t)m_scene * nl + m_light) * S * S;
     const uint4 one = make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u);
     while (m) {
         const int b = __ffs((int)m) - 1;
@@ -950,7 +1063,7 @@ __global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, cons
                                                       const slhip_draw* __restrict__ draws, int S,
                                                       unsigned* __restrict__ shadow,
                                                       const unsigned* __restrict__ queue, unsigned capacity,
-                                                      const float4* __restrict__ clipbuf, unsigned n_clip_verts)
+                                                      const float4* __restrict__ clipbuf, unsigned n_clip_verts, int nl)
 {
     const unsigned count = min(queue[0], capacity);
     const QItem* items = reinterpret_cast<const QItem*>(queue + 4);
@@ -973,14 +1086,9 @@ __global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, cons
             ok = false;
             const slhip_draw* dr = draws + it.draw;
             const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)it.tri_sub;
-            float c[3][4];
             const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float4 c4 = plane[ip[k]];
-                c[k][0] = c4.x; c[k][1] = c4.y; c[k][2] = c4.z; c[k][3] = c4.w;
-            }
-            if (!setup_tri(c[0], c[1], c[2], S, S, t)) continue;
+            const uint4* sp = reinterpret_cast<const uint4*>(plane);
+            if (!setup_from_screen(sp[ip[0]], sp[ip[1]], sp[ip[2]], S, S, t)) continue;
             ok = true;
         }
         if (!ok) continue;
@@ -990,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, cons
         float l[3];
         if (!coverage(t, px, py, l)) continue;
         ShadowTarget tgt;
-        tgt.sm = shadow + ((size_t)scene * SLHIP_NUM_LIGHTS + light) * S * S;
+        tgt.sm = shadow + ((size_t)scene * nl + light) * S * S;
         tgt.W = S;
         tgt.emit(t, px, py, l);
     }
@@ -1103,7 +1211,7 @@ __device__ __forceinline__ float pow22(float x) { return __builtin_amdgcn_exp2f(
 
 __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ sc, const slhip_draw* __restrict__ dr,
                                                const float* base, const float* world, const float* nrm_in,
-                                               bool front_facing, const float* __restrict__ shadow, int S,
+                                               bool front_facing, const float* __restrict__ shadow, int S, int shadow_lights,
                                                const slhip_light_map* __restrict__ lm, float roughness_in, float metallic_in,
                                                float occlusion, const float* emissive, float* color, float* normal_out)
 {
@@ -1134,7 +1242,7 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
         const float* lc = sc->light_color[i];
         const float* ld = sc->light_dir[i];
         float inverse_shadow = 1.0f;
-        if (shadow) {
+        if (shadow && i < shadow_lights) {
             const float w4[4] = {world[0], world[1], world[2], 1.0f};
             float pc[4];
             mv4(sc->shadow_mat[i], w4, pc);
@@ -1260,21 +1368,50 @@ __device__ __forceinline__ bool scene_block(unsigned blocks_per_scene, unsigned 
     return scene < n_scenes;
 }
 
+// The shading pass's geometry resolve of one pixel against one set-up (sub-)triangle whose corners carry the barycentrics
+// q0..q2 of the ORIGINAL triangle: perspective-correct barycentrics b, facing, and -- where a texture will be sampled -- the
+// barycentrics one pixel to the right / below (the texture footprint).  Returns false if the pixel is not covered.
+struct PixelBary {
+    float b[3], bx[3], by[3];
+    bool front;
+};
+__device__ __forceinline__ bool resolve_pixel(const Setup& t, const float (&q0)[3], const float (&q1)[3], const float (&q2)[3],
+                                              int px, int py, bool textured, PixelBary& r)
+{
+    float l[3];
+    if (px < t.xmin || px > t.xmax || py < t.ymin || py > t.ymax) return false;
+    if (!coverage(t, px, py, l)) return false;
+    const float pw0 = l[0] * t.invw[0], pw1 = l[1] * t.invw[1], pw2 = l[2] * t.invw[2];
+    const float sw = (pw0 + pw1) + pw2;
+    const float bs[3] = {pw0 * (1.0f / sw), pw1 * (1.0f / sw), pw2 * (1.0f / sw)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r.b[k] = fmaf(bs[2], q2[k], fmaf(bs[1], q1[k], bs[0] * q0[k]));
+    r.front = t.flipped;
+    if (textured) {
+        bary_at(t, q0, q1, q2, px + 1, py, r.bx);
+        bary_at(t, q0, q1, q2, px, py + 1, r.by);
+    }
+    return true;
+}
+
 struct ShadeParams {
     int W, H;
     unsigned n_scenes;
     unsigned flags;
     int S;
+    int shadow_lights;   // light maps per scene in `shadow`
     int inline_tonemap;  // 1: no SSAO and manual exposure -> write rgb directly
     int want_lum;        // 1: write per-block HDR sums for auto exposure
 };
 
+// The corners' vertex-stage outputs and window coordinates come from the records k_vertex_attr wrote (`vattr`).
 __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                const slhip_draw* __restrict__ draws, ShadeParams prm,
                                                const unsigned long long* __restrict__ vis,
                                                slhip_render_out out, float* __restrict__ hdr,
                                                const float* __restrict__ shadow, float* __restrict__ lum_part,
-                                               const float4* __restrict__ clipbuf, float* __restrict__ zplane)
+                                               const float4* __restrict__ clipbuf, float* __restrict__ zplane,
+                                               const float4* __restrict__ vattr)
 {
     const int W = prm.W, H = prm.H;
     const size_t P = (size_t)W * H;
@@ -1317,42 +1454,58 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
             const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
             const unsigned vi[3] = {ip[0], ip[1], ip[2]};
             VsOut vo[3];
-            ClipVert cv[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                vertex_full(pool, sc, dr, dr->vtx_base + vi[k], vo[k]);
-                const float4 c4 = clipbuf[dr->clip_base + vi[k]];   // identical to what the raster used
-                cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
-                cv[k].bary[0] = k == 0 ? 1.0f : 0.0f;
-                cv[k].bary[1] = k == 1 ? 1.0f : 0.0f;
-                cv[k].bary[2] = k == 2 ? 1.0f : 0.0f;
-            }
-            ClipVert poly[4];
-            const int n = clip_near(cv, poly);
             const int px = (int)(pix % (unsigned)W), py = (int)(pix / (unsigned)W);
             float b[3] = {0.0f, 0.0f, 0.0f}, bx[3] = {0.0f, 0.0f, 0.0f}, by[3] = {0.0f, 0.0f, 0.0f};
             bool found = false, front = false;
+            uint4 sv[3] = {};
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {   // unrolled: static indices into poly[]
-                if (sub >= n - 2 || found) break;
-                Setup t;
-                if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
-                float l[3];
-                if (px < t.xmin || px > t.xmax || py < t.ymin || py > t.ymax) continue;
-                if (!coverage(t, px, py, l)) continue;
-                const float pw0 = l[0] * t.invw[0], pw1 = l[1] * t.invw[1], pw2 = l[2] * t.invw[2];
-                const float sw = (pw0 + pw1) + pw2;
-                const float bs[3] = {pw0 * (1.0f / sw), pw1 * (1.0f / sw), pw2 * (1.0f / sw)};
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    b[k] = fmaf(bs[2], poly[sub + 2].bary[k],
-                                fmaf(bs[1], poly[sub + 1].bary[k], bs[0] * poly[0].bary[k]));
-                front = t.flipped;
-                found = true;
-                // texture footprint: the same plane one pixel to the right / below
-                bary_at(t, poly[0].bary, poly[sub + 1].bary, poly[sub + 2].bary, px + 1, py, bx);
-                bary_at(t, poly[0].bary, poly[sub + 1].bary, poly[sub + 2].bary, px, py + 1, by);
+            for (int k = 0; k < 3; ++k) {
+                const float4* va = vattr + 4 * (size_t)(dr->clip_base + vi[k]);   // the corner's 64-byte record
+                const float4 a0 = va[0], a1 = va[1], a2 = va[2];
+                sv[k] = reinterpret_cast<const uint4*>(va)[3];
+                const float2 uv = reinterpret_cast<const float2*>(pool.d_uv)[dr->vtx_base + vi[k]];
+                vo[k].objc[0] = a0.x; vo[k].objc[1] = a0.y; vo[k].objc[2] = a0.z; vo[k].objc[3] = a0.w;
+                vo[k].world[0] = a1.x; vo[k].world[1] = a1.y; vo[k].world[2] = a1.z;
+                vo[k].cam[0] = a1.w; vo[k].cam[1] = a2.w; vo[k].cam[2] = a0.w;
+                vo[k].nrm[0] = a2.x; vo[k].nrm[1] = a2.y; vo[k].nrm[2] = a2.z;
+                vo[k].uv[0] = uv.x; vo[k].uv[1] = uv.y;
             }
+            // the texture footprint (barycentrics one pixel to the right / below) only where a texture will be sampled
+            const bool textured = (dr->flags & (SLHIP_DRAW_HAS_BASE_TEX | SLHIP_DRAW_HAS_NORMAL_TEX | SLHIP_DRAW_HAS_MR_TEX |
+                                                SLHIP_DRAW_HAS_OCCLUSION_TEX | SLHIP_DRAW_HAS_EMISSIVE_TEX)) != 0u;
+            PixelBary pb;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pb.b[k] = pb.bx[k] = pb.by[k] = 0.0f;
+            pb.front = false;
+            if (screen_all_inside(sv[0], sv[1], sv[2])) {
+                // all three corners in front of the near plane (clip_near() would hand the triangle through): set-up from the
+                // per-vertex window coordinates, no clip positions needed, the corners' barycentrics are the unit vectors
+                const float e0[3] = {1.0f, 0.0f, 0.0f}, e1[3] = {0.0f, 1.0f, 0.0f}, e2[3] = {0.0f, 0.0f, 1.0f};
+                Setup t;
+                if (setup_from_screen(sv[0], sv[1], sv[2], W, H, t)) found = resolve_pixel(t, e0, e1, e2, px, py, textured, pb);
+            } else {
+                ClipVert cv[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float4 c4 = clipbuf[dr->clip_base + vi[k]];   // identical to what the raster used
+                    cv[k].clip[0] = c4.x; cv[k].clip[1] = c4.y; cv[k].clip[2] = c4.z; cv[k].clip[3] = c4.w;
+                    cv[k].bary[0] = k == 0 ? 1.0f : 0.0f;
+                    cv[k].bary[1] = k == 1 ? 1.0f : 0.0f;
+                    cv[k].bary[2] = k == 2 ? 1.0f : 0.0f;
+                }
+                ClipVert poly[4];
+                const int n = clip_near(cv, poly);
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {   // unrolled: static indices into poly[]
+                    if (sub >= n - 2 || found) break;
+                    Setup t;
+                    if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
+                    found = resolve_pixel(t, poly[0].bary, poly[sub + 1].bary, poly[sub + 2].bary, px, py, textured, pb);
+                }
+            }
+            front = pb.front;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { b[k] = pb.b[k]; bx[k] = pb.bx[k]; by[k] = pb.by[k]; }
             if (found) {
                 const float camz = interp(b, vo[0].objc[3], vo[1].objc[3], vo[2].objc[3]);
                 float base[4] = {dr->base_color[0], dr->base_color[1], dr->base_color[2], dr->base_color[3]};
@@ -1448,9 +1601,9 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                     for (int c = 0; c < 3; ++c) emissive[c] *= pow22(tc[c]);
                 }
                 const float* sm = (prm.flags & SLHIP_RENDER_SHADOWS) && shadow
-                                      ? shadow + (size_t)scene * SLHIP_NUM_LIGHTS * prm.S * prm.S
+                                      ? shadow + (size_t)scene * prm.shadow_lights * prm.S * prm.S
                                       : nullptr;
-                shade_fragment(sc, dr, base, world, nrm, front, sm, prm.S, lm, roughness, metallic, occlusion, emissive, color, nout);
+                shade_fragment(sc, dr, base, world, nrm, front, sm, prm.S, prm.shadow_lights, lm, roughness, metallic, occlusion, emissive, color, nout);
                 cls = dr->class_index & 0xFFFFu;
                 inst = dr->instance_index & 0xFFFFu;
                 if (!(dr->flags & SLHIP_DRAW_NO_VERTEX_ID)) { vidx[0] = vi[0] + 1; vidx[1] = vi[1] + 1; vidx[2] = vi[2] + 1; }
@@ -1899,11 +2052,21 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
     const unsigned pix_blocks = blocks_per_scene * 8u * ((n_scenes + 7u) / 8u);   // see scene_block()
     const int S = (int)scratch->shadow_res;
+    // light maps per scene in d_shadow: 0 = all SLHIP_NUM_LIGHTS; a caller whose scenes only use the first lights saves
+    // 4 S^2 bytes per scene and unused light (lights beyond the count cast no shadow)
+    const int NL = scratch->shadow_lights == 0u ? SLHIP_NUM_LIGHTS : (int)min(scratch->shadow_lights, (uint32_t)SLHIP_NUM_LIGHTS);
     if (n_chunks > 0 && (!scratch->d_clip || scratch->n_clip_verts == 0)) {
         slhip::set_error("slhip_render: d_clip scratch (n_clip_verts x 16 B x planes) is required");
         return -1;
     }
+    if (n_chunks > 0 && !scratch->d_vattr) {
+        slhip::set_error("slhip_render: d_vattr scratch (n_clip_verts x 80 B) is required");
+        return -1;
+    }
     const float4* clipbuf = reinterpret_cast<const float4*>(scratch->d_clip);
+    // post-transform vertex cache: 64-byte records, then the dense plane of window coordinates
+    float4* vattr = reinterpret_cast<float4*>(scratch->d_vattr);
+    const uint4* screen = reinterpret_cast<const uint4*>(vattr) + 4 * (size_t)scratch->n_clip_verts;
 
     if (ssao) {
         int dev = 0;
@@ -1937,13 +2100,15 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
         k_vertex_xform<<<dim3(n_draws, 32), 256, 0, stream>>>(*pool, d_scenes, d_draws,
                                                                       reinterpret_cast<float4*>(scratch->d_clip),
                                                                       scratch->n_clip_verts, shadows ? 1 : 0);
+        k_vertex_attr<<<dim3(n_draws, 32), 256, 0, stream>>>(*pool, d_scenes, d_draws, reinterpret_cast<float4*>(scratch->d_clip),
+                                                                 scratch->n_clip_verts, vattr, W, H, shadows ? 1 : 0, S);
         SLHIP_LAUNCH_CHECK();
     }
     // shadow pass (maps clean on entry, see k_shadow_raster)
     const unsigned n_tile_words = shadows ? n_scenes * SLHIP_NUM_LIGHTS * (unsigned)shadow_tile_words(S) : 0u;
     if (shadows && (flags & SLHIP_RENDER_SHADOW_RESET)) {
         k_clear_shadow<<<4096, 256, 0, stream>>>(reinterpret_cast<unsigned*>(scratch->d_shadow),
-                                                 (size_t)n_scenes * SLHIP_NUM_LIGHTS * S * S / 4);
+                                                 (size_t)n_scenes * NL * S * S / 4);
         SLHIP_CHECK(hipMemsetAsync(scratch->d_shadow_tiles, 0, (size_t)n_tile_words * 4, stream));
     }
     if (shadows && n_chunks > 0) {
@@ -1951,11 +2116,11 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
         SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
         k_shadow_raster<<<n_chunks, 256, 0, stream>>>(
             *pool, d_scenes, d_draws, d_chunks, S, reinterpret_cast<unsigned*>(scratch->d_shadow),
-            scratch->d_queue, scratch->queue_capacity, clipbuf, scratch->n_clip_verts, scratch->d_shadow_tiles);
+            scratch->d_queue, scratch->queue_capacity, clipbuf, scratch->n_clip_verts, scratch->d_shadow_tiles, NL);
         mark(1, stream);
         k_shadow_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, S,
                                                  reinterpret_cast<unsigned*>(scratch->d_shadow), scratch->d_queue,
-                                                 scratch->queue_capacity, clipbuf, scratch->n_clip_verts);
+                                                 scratch->queue_capacity, clipbuf, scratch->n_clip_verts, NL);
         SLHIP_LAUNCH_CHECK();
     }
 
@@ -1964,13 +2129,16 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     SLHIP_CHECK(hipMemsetAsync(scratch->d_vis, 0xFF, (size_t)n_scenes * P * 8, stream));
     SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
     if (n_chunks > 0) {
-        k_raster<<<n_chunks, 256, 0, stream>>>(*pool, d_scenes, d_draws, d_chunks, W, H, d_depth_peel,
-                                               reinterpret_cast<unsigned long long*>(scratch->d_vis),
-                                               scratch->d_queue, scratch->queue_capacity, clipbuf);
+        k_raster<false><<<n_chunks, 256, 0, stream>>>(*pool, d_scenes, d_draws, d_chunks, W, H, d_depth_peel,
+                                                      reinterpret_cast<unsigned long long*>(scratch->d_vis),
+                                                      scratch->d_queue, scratch->queue_capacity, clipbuf, screen);
+        k_raster<true><<<n_chunks, 256, 0, stream>>>(*pool, d_scenes, d_draws, d_chunks, W, H, d_depth_peel,
+                                                     reinterpret_cast<unsigned long long*>(scratch->d_vis),
+                                                     scratch->d_queue, scratch->queue_capacity, clipbuf, screen);
         mark(3, stream);
         k_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, W, H,
                                           reinterpret_cast<unsigned long long*>(scratch->d_vis), scratch->d_queue,
-                                          scratch->queue_capacity, clipbuf);
+                                          scratch->queue_capacity, clipbuf, screen);
         SLHIP_LAUNCH_CHECK();
     }
 
@@ -1978,7 +2146,7 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     // knows whether ANY post pass is needed, so inline tone mapping is used only when the
     // caller guarantees manual exposure through the flag below.
     ShadeParams prm;
-    prm.W = W; prm.H = H; prm.n_scenes = n_scenes; prm.flags = flags; prm.S = S;
+    prm.W = W; prm.H = H; prm.n_scenes = n_scenes; prm.flags = flags; prm.S = S; prm.shadow_lights = NL;
     prm.inline_tonemap = 0;
     prm.want_lum = want_rgb ? 1 : 0;
     float* hdr0 = want_rgb ? scratch->d_hdr : nullptr;
@@ -1987,11 +2155,11 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     k_shade<<<pix_blocks, 256, 0, stream>>>(*pool, d_scenes, d_draws, prm,
                                             reinterpret_cast<const unsigned long long*>(scratch->d_vis), *out, hdr0,
                                             shadows ? scratch->d_shadow : nullptr, scratch->d_lum, clipbuf,
-                                            ssao ? scratch->d_ao + (size_t)n_scenes * P : nullptr);
+                                            ssao ? scratch->d_ao + (size_t)n_scenes * P : nullptr, vattr);
     SLHIP_LAUNCH_CHECK();
     if (shadows && n_chunks > 0) {   // the maps were read for the last time: marked tiles back to 1.0
         k_shadow_restore<<<n_tile_words, 256, 0, stream>>>(reinterpret_cast<unsigned*>(scratch->d_shadow), scratch->d_shadow_tiles,
-                                                          S, n_tile_words);
+                                                          S, n_tile_words, NL);
         SLHIP_LAUNCH_CHECK();
     }
 

@@ -273,7 +273,8 @@ class SceneBatch:
             self.d_srec.data_ptr() + s0 * _abi.SCENE_DTYPE.itemsize,
             self.d_drec.data_ptr() + s0 * md * _abi.DRAW_DTYPE.itemsize,
             self.d_crec.data_ptr() + s0 * mk * _abi.CHUNK_DTYPE.itemsize,
-            B, B * md, B * mk, B * mv, W, H, mask, ssao=ssao, shadows=self.shadows, buffers=buffers)
+            B, B * md, B * mk, B * mv, W, H, mask, ssao=ssao, shadows=self.shadows, buffers=buffers,
+            shadow_lights=1)       # the synthesised scenes have one light (k_synth_place)
 
     def render_chunks(self, mask=_abi.OUT_GT6, ssao=True):
         for c in range(self.n_render_chunks()):

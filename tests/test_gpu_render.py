@@ -267,3 +267,4 @@ def test_watertight_sheet_on_the_gpu(sl, oracle, eng):
 
     for n_points, seed, tilt in ((600, 1, 0.0), (15000, 2, 0.0), (90000, 3, 0.0), (60000, 5, 50.0)):
         check_watertight(render, sl, n_points, seed, tilt)
+
