@@ -9,7 +9,7 @@ from . import _abi
 from ._batch import HostPool, build_batch
 
 SHADOW_RES = 2048  # render_pass.cpp:271
-QUEUE_ITEMS_PER_SCENE = 1 << 14  # (triangle, 8x8 tile) work items; 4800 tiles cover 640x480 once
+QUEUE_ITEMS_PER_SCENE = int(__import__('os').environ.get('SLHIP_QUEUE_ITEMS', 1 << 14))  # (triangle, 8x8 tile) work items; 4800 tiles cover 640x480 once
 
 
 def _ptr(t):

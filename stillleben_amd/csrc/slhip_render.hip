@@ -33,7 +33,7 @@ static_assert(sizeof(slhip_chunk) == 16, "slhip_chunk layout");
 constexpr float kInvalid = 3000.0f;  // render_pass.cpp:316
 constexpr float kPi = 3.141592653589793f;
 constexpr unsigned long long kVisEmpty = ~0ull;
-constexpr int kSmallArea = 128;  // bbox pixels a single thread rasterises itself (larger boxes: tile queue)
+constexpr int kSmallArea = 256;  // bbox pixels a single thread rasterises itself (larger boxes: tile queue); 128 / 256 / 1024 measured: shadow pass 17.2 / 16.7 / 16.4 ms
 
 // ---------------------------------------------------------------------------------------------
 // fixed-order arithmetic (R1)
@@ -456,19 +456,23 @@ __device__ __forceinline__ int wrap_coord(int i, int n, unsigned mode)
     return wrapi(i, n);                                       // repeat
 }
 
-__device__ __forceinline__ void texel_rgba(const uint8_t* __restrict__ lvl, int w, int x, int y, float* out)
+// Textures are addressed as (texel pool base, 32-bit byte offset): the pool pointer is a kernel argument, so a fetch needs ONE
+// address register per texel (scalar base + vector offset) instead of a 64-bit pointer pair, and one integer add instead of
+// an add-with-carry chain -- eight texels of a trilinear fetch are in flight at once.  (The texel pool is < 4 GB: n_tex_bytes is
+// a uint32_t.)
+__device__ __forceinline__ void texel_rgba(const uint8_t* __restrict__ pool_tex, unsigned lvl, int w, int x, int y, float* out)
 {
-    const uchar4 t = reinterpret_cast<const uchar4*>(lvl)[(size_t)y * w + x];
+    const uchar4 t = *reinterpret_cast<const uchar4*>(pool_tex + (lvl + 4u * ((unsigned)y * (unsigned)w + (unsigned)x)));
     out[0] = slhip::unorm8(t.x); out[1] = slhip::unorm8(t.y); out[2] = slhip::unorm8(t.z); out[3] = slhip::unorm8(t.w);
 }
 
 // one level, nearest or bilinear
-__device__ __forceinline__ void tex_level(const uint8_t* __restrict__ lvl, int w, int h, unsigned sampler, bool linear, float u,
-                                          float v, float* out)
+__device__ __forceinline__ void tex_level(const uint8_t* __restrict__ pool_tex, unsigned lvl, int w, int h, unsigned sampler,
+                                          bool linear, float u, float v, float* out)
 {
     const unsigned ws = SLHIP_SAMPLER_WRAP_S(sampler), wt = SLHIP_SAMPLER_WRAP_T(sampler);
     if (!linear) {
-        texel_rgba(lvl, w, wrap_coord((int)floorf(u * (float)w), w, ws), wrap_coord((int)floorf(v * (float)h), h, wt), out);
+        texel_rgba(pool_tex, lvl, w, wrap_coord((int)floorf(u * (float)w), w, ws), wrap_coord((int)floorf(v * (float)h), h, wt), out);
         return;
     }
     const float x = fmaf(u, (float)w, -0.5f), y = fmaf(v, (float)h, -0.5f);
@@ -477,8 +481,8 @@ __device__ __forceinline__ void tex_level(const uint8_t* __restrict__ lvl, int w
     const int x0 = wrap_coord((int)fx, w, ws), y0 = wrap_coord((int)fy, h, wt);
     const int x1 = wrap_coord((int)fx + 1, w, ws), y1 = wrap_coord((int)fy + 1, h, wt);
     float c00[4], c10[4], c01[4], c11[4];
-    texel_rgba(lvl, w, x0, y0, c00); texel_rgba(lvl, w, x1, y0, c10);
-    texel_rgba(lvl, w, x0, y1, c01); texel_rgba(lvl, w, x1, y1, c11);
+    texel_rgba(pool_tex, lvl, w, x0, y0, c00); texel_rgba(pool_tex, lvl, w, x1, y0, c10);
+    texel_rgba(pool_tex, lvl, w, x0, y1, c01); texel_rgba(pool_tex, lvl, w, x1, y1, c11);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float top = fmaf(ax, c10[c] - c00[c], c00[c]), bot = fmaf(ax, c11[c] - c01[c], c01[c]);
@@ -486,16 +490,16 @@ __device__ __forceinline__ void tex_level(const uint8_t* __restrict__ lvl, int w
     }
 }
 
-// level l of a texture whose level 0 is w0 x h0 at `tex`: pointer and size
-__device__ __forceinline__ const uint8_t* tex_level_ptr(const uint8_t* __restrict__ tex, int w0, int h0, int l, int& w, int& h)
+// level l of a texture whose level 0 is w0 x h0 at byte offset `tex` of the pool: offset and size
+__device__ __forceinline__ unsigned tex_level_off(unsigned tex, int w0, int h0, int l, int& w, int& h)
 {
-    size_t off = 0;
+    unsigned off = tex;
     w = w0; h = h0;
     for (int k = 0; k < l; ++k) {
-        off += 4 * (size_t)w * h;
+        off += 4u * (unsigned)w * (unsigned)h;
         w = max(1, w >> 1); h = max(1, h >> 1);
     }
-    return tex + off;
+    return off;
 }
 
 // log2 of a positive normal float from exponent + a degree-6 polynomial in fmaf form (max error 1.4e-6): the
@@ -517,8 +521,8 @@ __device__ __forceinline__ float det_log2(float x)
 }
 
 // texture2D() of the fragment shader: (du, dv) to the +x and +y pixel neighbours select the level
-__device__ __forceinline__ void tex_sample(const uint8_t* __restrict__ tex, int w, int h, unsigned sampler, float u, float v,
-                                           float dudx, float dvdx, float dudy, float dvdy, float* out)
+__device__ __forceinline__ void tex_sample(const uint8_t* __restrict__ pool_tex, unsigned tex, int w, int h, unsigned sampler, float u,
+                                           float v, float dudx, float dvdx, float dudy, float dvdy, float* out)
 {
     const unsigned mip = SLHIP_SAMPLER_MIP(sampler);
     const float ax = dudx * (float)w, bx = dvdx * (float)h, ay = dudy * (float)w, by = dvdy * (float)h;
@@ -526,7 +530,7 @@ __device__ __forceinline__ void tex_sample(const uint8_t* __restrict__ tex, int 
     const float rho = fmaxf(rx, ry);
     const bool magnify = !(rho > 1.0f);            // lambda <= 0 (or a degenerate footprint)
     if (magnify || mip == 0u) {
-        tex_level(tex, w, h, sampler, (sampler & (magnify ? SLHIP_SAMPLER_MAG_LINEAR : SLHIP_SAMPLER_MIN_LINEAR)) != 0u, u, v, out);
+        tex_level(pool_tex, tex, w, h, sampler, (sampler & (magnify ? SLHIP_SAMPLER_MAG_LINEAR : SLHIP_SAMPLER_MIN_LINEAR)) != 0u, u, v, out);
         return;
     }
     const int top = 31 - __clz(max(max(w, h), 1));  // last level = floor(log2(max(w, h)))
@@ -535,23 +539,23 @@ __device__ __forceinline__ void tex_sample(const uint8_t* __restrict__ tex, int 
     int lw, lh;
     if (mip == 1u) {                                // nearest level: round half up (section 8.14.3)
         const int l = min((int)ceilf(lambda + 0.5f) - 1, top);
-        const uint8_t* p = tex_level_ptr(tex, w, h, max(l, 0), lw, lh);
-        tex_level(p, lw, lh, sampler, lin, u, v, out);
+        const unsigned p = tex_level_off(tex, w, h, max(l, 0), lw, lh);
+        tex_level(pool_tex, p, lw, lh, sampler, lin, u, v, out);
         return;
     }
     const int l0 = min((int)floorf(lambda), top), l1 = min(l0 + 1, top);
     const float f = lambda - (float)l0;
     float a[4], b[4];
-    const uint8_t* p0 = tex_level_ptr(tex, w, h, l0, lw, lh);
-    tex_level(p0, lw, lh, sampler, lin, u, v, a);
+    const unsigned p0 = tex_level_off(tex, w, h, l0, lw, lh);
+    tex_level(pool_tex, p0, lw, lh, sampler, lin, u, v, a);
     if (l1 == l0 || f == 0.0f) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = a[c];
         return;
     }
-    const uint8_t* p1 = p0 + 4 * (size_t)lw * lh;   // l1 == l0 + 1: the next level follows level l0
+    const unsigned p1 = p0 + 4u * (unsigned)lw * (unsigned)lh;   // l1 == l0 + 1: the next level follows level l0
     lw = max(1, lw >> 1); lh = max(1, lh >> 1);
-    tex_level(p1, lw, lh, sampler, lin, u, v, b);
+    tex_level(pool_tex, p1, lw, lh, sampler, lin, u, v, b);
 #pragma unroll
     for (int c = 0; c < 4; ++c) out[c] = fmaf(f, b[c] - a[c], a[c]);
 }
@@ -614,7 +618,8 @@ struct MainTarget {
     const float* camz;   // [3] camera z of the ORIGINAL vertices
     const float* bary;   // [3][3] barycentrics of the sub-triangle vertices w.r.t. the original
     const float* uv;     // [3][2]
-    const uint8_t* tex;
+    const uint8_t* pool_tex;   // texel pool, nullptr = no alpha test
+    unsigned tex;              // byte offset of the base-colour texture in the pool
     int tex_w, tex_h;
     unsigned tex_sampler;
     float base_alpha, alpha_cutoff;
@@ -643,14 +648,14 @@ struct MainTarget {
                 const float cz = interp(b, camz[0], camz[1], camz[2]);
                 if (cz - 0.00001f <= peel[4 * ((size_t)py * W + px) + 3]) return;
             }
-            if (tex) {
+            if (pool_tex) {
                 const float u = interp(b, uv[0], uv[2], uv[4]);
                 const float v = interp(b, uv[1], uv[3], uv[5]);
                 float bx[3], by[3];
                 bary_at(t, bary, bary + 3, bary + 6, px + 1, py, bx);
                 bary_at(t, bary, bary + 3, bary + 6, px, py + 1, by);
                 float tc[4];
-                tex_sample(tex, tex_w, tex_h, tex_sampler, u, v, interp(bx, uv[0], uv[2], uv[4]) - u, interp(bx, uv[1], uv[3], uv[5]) - v,
+                tex_sample(pool_tex, tex, tex_w, tex_h, tex_sampler, u, v, interp(bx, uv[0], uv[2], uv[4]) - u, interp(bx, uv[1], uv[3], uv[5]) - v,
                            interp(by, uv[0], uv[2], uv[4]) - u, interp(by, uv[1], uv[3], uv[5]) - v, tc);
                 if (base_alpha * tc[3] < alpha_cutoff) return;
             }
@@ -731,10 +736,10 @@ __device__ __forceinline__ void raster_bbox(const Setup& t, const Target& tgt)
 template <class Target>
 __device__ __forceinline__ void raster_or_enqueue(const Setup& t, const Target& tgt, unsigned* queue,
                                                   unsigned capacity, unsigned draw, unsigned tri_sub,
-                                                  unsigned scene_aux)
+                                                  unsigned scene_aux, int small_area)
 {
     const int bw = t.xmax - t.xmin + 1, bh = t.ymax - t.ymin + 1;
-    bool in_place = bw * bh <= kSmallArea;
+    bool in_place = bw * bh <= small_area;
     if (!in_place) {
         const int tx0 = t.xmin >> 3, tx1 = t.xmax >> 3, ty0 = t.ymin >> 3, ty1 = t.ymax >> 3;
         const unsigned n = (unsigned)((tx1 - tx0 + 1) * (ty1 - ty0 + 1));
@@ -781,7 +786,7 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
                                                 const float* __restrict__ depth_peel,
                                                 unsigned long long* __restrict__ vis, unsigned* queue,
                                                 unsigned capacity, const float4* __restrict__ clipbuf,
-                                                const uint4* __restrict__ screen)
+                                                const uint4* __restrict__ screen, int small_area)
 {
     const slhip_chunk ch = chunks[blockIdx.x];
     if (threadIdx.x >= ch.count) return;
@@ -799,14 +804,14 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
     tgt.prim = dr->prim_base + tri;
     tgt.need_attr = kAttr;
     tgt.peel = nullptr;
-    tgt.tex = nullptr;
+    tgt.pool_tex = nullptr;
 
     if constexpr (!kAttr) {
         tgt.camz = nullptr; tgt.uv = nullptr; tgt.bary = nullptr;
         const uint4 s0 = screen[dr->clip_base + vi[0]], s1 = screen[dr->clip_base + vi[1]], s2 = screen[dr->clip_base + vi[2]];
         if (screen_all_inside(s0, s1, s2)) {     // clip_near() would hand the triangle through
             Setup t;
-            if (setup_from_screen(s0, s1, s2, W, H, t)) raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene);
+            if (setup_from_screen(s0, s1, s2, W, H, t)) raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene, small_area);
             return;
         }
         ClipVert cv[3];
@@ -823,7 +828,7 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
             if (sub >= n - 2) break;
             Setup t;
             if (!setup_tri(poly[0].clip, poly[sub + 1].clip, poly[sub + 2].clip, W, H, t)) continue;
-            raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri | ((unsigned)sub << 31), ch.scene);
+            raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri | ((unsigned)sub << 31), ch.scene, small_area);
         }
     } else {
         ClipVert cv[3];
@@ -851,7 +856,7 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
                 const float2 uv = reinterpret_cast<const float2*>(pool.d_uv)[dr->vtx_base + vi[k]];
                 uvs[2 * k] = uv.x; uvs[2 * k + 1] = uv.y;
             }
-            tgt.tex = pool.d_tex + dr->tex_offset;
+            tgt.pool_tex = pool.d_tex; tgt.tex = dr->tex_offset;
             tgt.tex_w = (int)dr->tex_w; tgt.tex_h = (int)dr->tex_h;
             tgt.tex_sampler = dr->tex_sampler[0];
         }
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip
         tgt.W = W;
         tgt.prim = prim;
         tgt.need_attr = false;
-        tgt.tex = nullptr;
+        tgt.pool_tex = nullptr;
         tgt.emit(t, px, py, l);
     }
 }
@@ -981,7 +986,8 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
                                                        const slhip_chunk* __restrict__ chunks, int S,
                                                        unsigned* __restrict__ shadow, unsigned* queue,
                                                        unsigned capacity, const float4* __restrict__ clipbuf,
-                                                       unsigned n_clip_verts, unsigned* __restrict__ tile_bits, int nl)
+                                                       unsigned n_clip_verts, unsigned* __restrict__ tile_bits, int nl,
+                                                       int small_area)
 {
     __shared__ unsigned bm[SLHIP_NUM_LIGHTS][kShadowMaxWords];   // the chunk's touched tiles, ORed into the scene's bits at the end
     const slhip_chunk ch = chunks[blockIdx.x];
@@ -1018,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
         ShadowTarget tgt;
         tgt.sm = shadow + ((size_t)ch.scene * nl + light) * S * S;
         tgt.W = S;
-        raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene | ((unsigned)light << 24));
+        raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene | ((unsigned)light << 24), small_area);
     }
     __syncthreads();
     for (int k = (int)threadIdx.x; k < SLHIP_NUM_LIGHTS * words; k += 256) {
@@ -1515,7 +1521,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                 const float dudy = interp(by, vo[0].uv[0], vo[1].uv[0], vo[2].uv[0]) - u, dvdy = interp(by, vo[0].uv[1], vo[1].uv[1], vo[2].uv[1]) - v;
                 if (dr->flags & SLHIP_DRAW_HAS_BASE_TEX) {
                     float tc[4];
-                    tex_sample(pool.d_tex + dr->tex_offset, (int)dr->tex_w, (int)dr->tex_h, dr->tex_sampler[0], u, v, dudx, dvdx, dudy, dvdy, tc);
+                    tex_sample(pool.d_tex, dr->tex_offset, (int)dr->tex_w, (int)dr->tex_h, dr->tex_sampler[0], u, v, dudx, dvdx, dudy, dvdy, tc);
                     base[0] *= pow22(tc[0]);
                     base[1] *= pow22(tc[1]);
                     base[2] *= pow22(tc[2]);
@@ -1572,7 +1578,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                         for (int c = 0; c < 3; ++c) bw[k][c] *= t4.w;
                     }
                     float tc[4];
-                    tex_sample(pool.d_tex + dr->normal_tex_offset, (int)dr->normal_tex_w, (int)dr->normal_tex_h, dr->tex_sampler[1], u, v, dudx, dvdx, dudy, dvdy, tc);
+                    tex_sample(pool.d_tex, dr->normal_tex_offset, (int)dr->normal_tex_w, (int)dr->normal_tex_h, dr->tex_sampler[1], u, v, dudx, dvdx, dudy, dvdy, tc);
                     const float nx = tc[0] * 2.0f - 1.0f, ny = tc[1] * 2.0f - 1.0f, nz = tc[2] * 2.0f - 1.0f;
                     float nn[3];
 #pragma unroll
@@ -1585,18 +1591,18 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
                 float emissive[3] = {dr->emissive[0], dr->emissive[1], dr->emissive[2]};
                 if (dr->flags & SLHIP_DRAW_HAS_MR_TEX) {
                     float tc[4];
-                    tex_sample(pool.d_tex + dr->mr_tex_offset, (int)dr->mr_tex_w, (int)dr->mr_tex_h, dr->tex_sampler[2], u, v, dudx, dvdx, dudy, dvdy, tc);
+                    tex_sample(pool.d_tex, dr->mr_tex_offset, (int)dr->mr_tex_w, (int)dr->mr_tex_h, dr->tex_sampler[2], u, v, dudx, dvdx, dudy, dvdy, tc);
                     roughness *= tc[1];
                     metallic *= tc[2];
                 }
                 if (dr->flags & SLHIP_DRAW_HAS_OCCLUSION_TEX) {
                     float tc[4];
-                    tex_sample(pool.d_tex + dr->occlusion_tex_offset, (int)dr->occlusion_tex_w, (int)dr->occlusion_tex_h, dr->tex_sampler[3], u, v, dudx, dvdx, dudy, dvdy, tc);
+                    tex_sample(pool.d_tex, dr->occlusion_tex_offset, (int)dr->occlusion_tex_w, (int)dr->occlusion_tex_h, dr->tex_sampler[3], u, v, dudx, dvdx, dudy, dvdy, tc);
                     occlusion = tc[0];
                 }
                 if (dr->flags & SLHIP_DRAW_HAS_EMISSIVE_TEX) {
                     float tc[4];
-                    tex_sample(pool.d_tex + dr->emissive_tex_offset, (int)dr->emissive_tex_w, (int)dr->emissive_tex_h, dr->tex_sampler[4], u, v, dudx, dvdx, dudy, dvdy, tc);
+                    tex_sample(pool.d_tex, dr->emissive_tex_offset, (int)dr->emissive_tex_w, (int)dr->emissive_tex_h, dr->tex_sampler[4], u, v, dudx, dvdx, dudy, dvdy, tc);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) emissive[c] *= pow22(tc[c]);
                 }
@@ -2054,6 +2060,10 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     const int S = (int)scratch->shadow_res;
     // light maps per scene in d_shadow: 0 = all SLHIP_NUM_LIGHTS; a caller whose scenes only use the first lights saves
     // 4 S^2 bytes per scene and unused light (lights beyond the count cast no shadow)
+    // bounding boxes up to this many pixels are walked by the triangle's own thread, larger ones go to the tile queue
+    // (developer knobs; on the C2 scenes 48 / 16 instead of 128 cost the shadow pass +16 % / +100 %)
+    static const int raster_small = getenv("SLHIP_RASTER_SMALL") ? atoi(getenv("SLHIP_RASTER_SMALL")) : kSmallArea;
+    static const int shadow_small = getenv("SLHIP_SHADOW_SMALL") ? atoi(getenv("SLHIP_SHADOW_SMALL")) : kSmallArea;
     const int NL = scratch->shadow_lights == 0u ? SLHIP_NUM_LIGHTS : (int)min(scratch->shadow_lights, (uint32_t)SLHIP_NUM_LIGHTS);
     if (n_chunks > 0 && (!scratch->d_clip || scratch->n_clip_verts == 0)) {
         slhip::set_error("slhip_render: d_clip scratch (n_clip_verts x 16 B x planes) is required");
@@ -2116,7 +2126,7 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
         SLHIP_CHECK(hipMemsetAsync(scratch->d_queue, 0, 16, stream));
         k_shadow_raster<<<n_chunks, 256, 0, stream>>>(
             *pool, d_scenes, d_draws, d_chunks, S, reinterpret_cast<unsigned*>(scratch->d_shadow),
-            scratch->d_queue, scratch->queue_capacity, clipbuf, scratch->n_clip_verts, scratch->d_shadow_tiles, NL);
+            scratch->d_queue, scratch->queue_capacity, clipbuf, scratch->n_clip_verts, scratch->d_shadow_tiles, NL, shadow_small);
         mark(1, stream);
         k_shadow_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, S,
                                                  reinterpret_cast<unsigned*>(scratch->d_shadow), scratch->d_queue,
@@ -2131,10 +2141,10 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     if (n_chunks > 0) {
         k_raster<false><<<n_chunks, 256, 0, stream>>>(*pool, d_scenes, d_draws, d_chunks, W, H, d_depth_peel,
                                                       reinterpret_cast<unsigned long long*>(scratch->d_vis),
-                                                      scratch->d_queue, scratch->queue_capacity, clipbuf, screen);
+                                                      scratch->d_queue, scratch->queue_capacity, clipbuf, screen, raster_small);
         k_raster<true><<<n_chunks, 256, 0, stream>>>(*pool, d_scenes, d_draws, d_chunks, W, H, d_depth_peel,
                                                      reinterpret_cast<unsigned long long*>(scratch->d_vis),
-                                                     scratch->d_queue, scratch->queue_capacity, clipbuf, screen);
+                                                     scratch->d_queue, scratch->queue_capacity, clipbuf, screen, raster_small);
         mark(3, stream);
         k_large<<<2048, 256, 0, stream>>>(*pool, d_scenes, d_draws, W, H,
                                           reinterpret_cast<unsigned long long*>(scratch->d_vis), scratch->d_queue,

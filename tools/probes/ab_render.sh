@@ -1,5 +1,5 @@
-# A/B of a render change inside the full bench: the library of the previous commit (stillleben_amd/lib/libslhip_head.so, built
-# by hand from `git archive HEAD`) against the working tree's
+# A/B of render variants inside the full bench.  AB_LIBS: names of stillleben_amd/lib/libslhip_<name>.so to compare;
+# AB_ENVS: ';'-separated environment settings to compare on the working tree's library
 run() { # name, env...
   name=$1; shift
   env "$@" timeout 300 python bench.py --no-cpu-baseline $BENCH_ARGS > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
@@ -12,5 +12,7 @@ except Exception as e:
     print("$name failed", e); print(open("gpurun_out/ab_$name.err").read()[-600:])
 P
 }
-[ -n "$AB_HEAD" ] && [ -f stillleben_amd/lib/libslhip_head.so ] && run head SLHIP_LIB=$PWD/stillleben_amd/lib/libslhip_head.so
-run new
+for n in $AB_LIBS; do run $n SLHIP_LIB=$PWD/stillleben_amd/lib/libslhip_$n.so; done
+i=0
+IFS=';' read -ra ENVS <<< "$AB_ENVS"
+for e in "${ENVS[@]}"; do i=$((i+1)); echo "env$i: $e"; run env$i $e; done
