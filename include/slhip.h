@@ -340,9 +340,11 @@ typedef struct {
 #define SLHIP_MAX_HULL_PAIRS 512  /* candidate hull pairs per scene and step                   */
 #define SLHIP_PAIR_CACHE_MAX_HULLS 256 /* scenes with more convex hulls settle without the pair cache (and without
                                           persistent manifolds: every step builds its manifolds from scratch) */
+#ifndef SLHIP_MAX_ACTIVE_CONTACTS   /* (a build-time experiment may override it; the oracle must be built with the same value) */
 #define SLHIP_MAX_ACTIVE_CONTACTS 160 /* solver contacts per scene and step (PhysX has no such cap, scene.cpp:738-739): the table
                                          contacts first; when the body pairs offer more than what is left, every pair keeps its
                                          first B contacts with the largest B that fits -- slhip_settle_caps says how often */
+#endif
 
 /* Steps every scene of the batch `frames * substeps` times without a host round trip -- a short sequence of kernel launches per
  * step over the whole batch (broadphase; GJK / portal refinement per hull pair; tilted runs for NEW contact pairs; persistent

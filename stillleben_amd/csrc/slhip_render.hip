@@ -1408,6 +1408,7 @@ struct ShadeParams {
     int shadow_lights;   // light maps per scene in `shadow`
     int inline_tonemap;  // 1: no SSAO and manual exposure -> write rgb directly
     int want_lum;        // 1: write per-block HDR sums for auto exposure
+    int tiled;           // 1: a block shades a 32 x 8 pixel region, a wave an 8 x 8 tile (needs W % 32 == 0 and H % 8 == 0)
 };
 
 // The corners' vertex-stage outputs and window coordinates come from the records k_vertex_attr wrote (`vattr`).
@@ -1424,8 +1425,22 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
     unsigned scene, blk;
     if (!scene_block(blocks_per_scene, prm.n_scenes, scene, blk)) return;
-    const unsigned pix = blk * 256 + threadIdx.x;
-    const bool active = pix < P;
+    // Pixel of the thread.  Tiled (whenever the viewport divides into 32 x 8 regions): a wave shades an 8 x 8 tile, so the
+    // silhouette of an object cuts through fewer waves than with 64 x 1 strips -- a wave that holds one object pixel pays the
+    // whole fragment path (textures, 25 shadow texels) for all its lanes -- and the gathers of a wave land in a compact
+    // window of the texture and of the shadow map.  Every lane still stores 16 contiguous bytes per target, a tile row is
+    // one 128-byte line.  Otherwise: 256 consecutive pixels per block.  Placement only: the values do not depend on it.
+    unsigned pix;
+    bool active;
+    if (prm.tiled) {
+        const unsigned per_row = (unsigned)W >> 5, l = threadIdx.x & 63u;
+        const unsigned tx = (blk % per_row) * 32u + (threadIdx.x >> 6) * 8u + (l & 7u), ty = (blk / per_row) * 8u + (l >> 3);
+        pix = ty * (unsigned)W + tx;
+        active = true;
+    } else {
+        pix = blk * 256 + threadIdx.x;
+        active = pix < P;
+    }
     const slhip_scene* sc = scenes + scene;
     const size_t gp = (size_t)scene * P + pix;
     // the block's pixels belong to one scene: its draws' first primitive ids go to LDS once
@@ -2159,6 +2174,8 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     prm.W = W; prm.H = H; prm.n_scenes = n_scenes; prm.flags = flags; prm.S = S; prm.shadow_lights = NL;
     prm.inline_tonemap = 0;
     prm.want_lum = want_rgb ? 1 : 0;
+    static const int shade_tiled = getenv("SLHIP_SHADE_TILED") ? atoi(getenv("SLHIP_SHADE_TILED")) : 1;   // developer knob
+    prm.tiled = (shade_tiled && W % 32 == 0 && H % 8 == 0) ? 1 : 0;
     float* hdr0 = want_rgb ? scratch->d_hdr : nullptr;
     float* hdr1 = want_rgb ? scratch->d_hdr + 4 * (size_t)n_scenes * P : nullptr;
     mark(4, stream);
