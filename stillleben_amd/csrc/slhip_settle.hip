@@ -1441,7 +1441,7 @@ __device__ __forceinline__ int hp_ha(unsigned e) { return (int)((e >> 12) & 1023
 __device__ __forceinline__ int hp_hb(unsigned e) { return (int)(e >> 22); }
 
 // solver group = all contacts between one body pair (b = 0xff: body a against the plane);
-// [begin, end) is its range in the contact list (<= 160, fits a byte)
+// [begin, end) is its range in the contact list (<= SLHIP_MAX_ACTIVE_CONTACTS, fits a byte)
 struct Group { unsigned char a, b, begin, end, color; };
 constexpr int kNoBody = 0xff;
 static_assert(sizeof(Group) == 5, "Group layout");
