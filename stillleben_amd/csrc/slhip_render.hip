@@ -167,7 +167,7 @@ __device__ __forceinline__ bool setup_tri(const float* c0, const float* c1, cons
     return setup_finish(W, H, t);
 }
 
-// The vertex pass (k_vertex_attr) stores screen_vertex() of every vertex in front of the near plane as one float4 (X and Y
+// The vertex pass (k_vertex_xform) stores screen_vertex() of every vertex in front of the near plane as one float4 (X and Y
 // as integer bit patterns); a vertex behind the plane gets kScreenClipped in X -- snap() never returns it -- and its triangles
 // take the clip-space path.  A triangle whose three corners are stored is set up without a single division.
 constexpr int kScreenClipped = (int)0x80000000;
@@ -330,7 +330,7 @@ __device__ __forceinline__ void vertex_full(const slhip_mesh_pool& pool, const s
 //   One instruction transforms 16 vertices into camera clip space AND the three shadow clip
 //   spaces.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; it receives D[(l>>4)*4+r][l&15],
 //   i.e. lanes 0-15 hold the camera clip position of their vertex, lanes 16-31 light 0, ...
-//   and every lane stores one float4 (fully coalesced 256 B per plane).
+//   and every lane parks its float4 in LDS for the per-vertex half of the kernel (below).
 // ---------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -343,14 +343,30 @@ __device__ __forceinline__ bool light_active(const slhip_scene* sc, int l)
              (ld[0] == 0.0f && ld[1] == 0.0f && ld[2] == 0.0f));
 }
 
+// ... and the REST of the vertex stage in the same kernel, once per vertex (thread = vertex) -- a post-transform vertex cache.
+// The wave's four MFMA results go through LDS (lane l of batch b holds plane l >> 4 of vertex 16 b + (l & 15); thread j wants
+// all planes of vertex j), so the clip positions never make the round trip through HBM that a separate attribute kernel paid
+// (64 B per vertex and pass saved of ~160: the pass is bound by its bytes).  Per vertex:
+//   * clip plane 0: the camera clip position (the near-plane clipper of the raster / shading passes reads it for the rare
+//     triangles that cross the plane);
+//   * clip planes 1..3: the WINDOW coordinates screen_vertex() of the light clip positions in the S x S map (the shadow pass
+//     clips nothing, so its set-up never needs the clip position itself);
+//   * one 64-byte record for the shading pass: (object xyz, camera z), (world xyz, camera x), (world normal, camera y) =
+//     vertex_full(), and the window coordinates of the camera clip position (kScreenClipped behind the near plane);
+//   * the camera window coordinates once more as a dense plane behind the records, for the raster pass.
+// The shading pass then fetches one cache line per corner instead of re-running three matrix products, nine divisions and a
+// normalisation per corner of every PIXEL and twelve more divisions per triangle set-up (160 k vertices per C2 scene against
+// 3 x 307 k pixel corners).  Same functions, same inputs, same bits as the per-pixel evaluation they replace.
 __global__ __launch_bounds__(256) void k_vertex_xform(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                       const slhip_draw* __restrict__ draws, float4* __restrict__ clip,
-                                                      unsigned n_clip_verts, int with_lights)
+                                                      unsigned n_clip_verts, float4* __restrict__ vattr, int W, int H,
+                                                      int with_lights, int S)
 {
+    __shared__ float4 s_clip[4][4][64];   // [wave][MFMA batch][lane]
     const slhip_draw* dr = draws + blockIdx.x;
     const unsigned nv = dr->n_verts;
+    if (blockIdx.y * 256 >= nv) return;
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if ((blockIdx.y * 4 + wave) * 64 >= nv) return;
     const slhip_scene* sc = scenes + dr->scene;
     // composite matrices (wave-uniform inputs; every lane evaluates the same chains)
     float T1[16], T2[16], M[16];
@@ -367,71 +383,55 @@ __global__ __launch_bounds__(256) void k_vertex_xform(slhip_mesh_pool pool, cons
         a = M[4 * (row & 3) + k];
     }
     const float* pos = pool.d_pos + 4 * (size_t)dr->vtx_base;
-    // 64 vertices per wave and pass = 4 MFMA batches; grid-stride over the draw's vertices
-    for (unsigned first = (blockIdx.y * 4 + wave) * 64; first < nv; first += gridDim.y * 256)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const unsigned v0 = first + 16 * b;
-        if (v0 >= nv) break;
-        const unsigned vj = min(v0 + (lane & 15), nv - 1);
-        // B[k][j]: component k of vertex j (w = 1): the wave reads 16 x 16 contiguous bytes
-        const float bval = k < 3 ? pos[4 * (size_t)vj + k] : 1.0f;
-        floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc, 0, 0, 0);
-        // lane holds rows (lane>>4)*4 + 0..3 of column lane&15 = the float4 of plane (lane>>4)
-        const unsigned plane = lane >> 4;
-        if (v0 + (lane & 15) < nv && (plane == 0 || (with_lights && light_active(sc, (int)plane - 1))))
-            clip[(size_t)plane * n_clip_verts + dr->clip_base + v0 + (lane & 15)] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-}
-
-// k_vertex_attr: the REST of the vertex stage once per vertex (thread = vertex) -- a post-transform vertex cache.  Per vertex
-// one 64-byte record: (object xyz, camera z), (world xyz, camera x), (world normal, camera y) = vertex_full(), and the window
-// coordinates screen_vertex() of the clip position k_vertex_xform wrote (kScreenClipped behind the near plane); the window
-// coordinates also as a dense plane behind the records.  The shading pass then fetches one cache line per corner instead of
-// re-running three matrix products, nine divisions and a normalisation per corner of every PIXEL and twelve more divisions
-// per triangle set-up (160 k vertices per C2 scene against 3 x 307 k pixel corners); the raster pass sets its triangles up
-// from the dense plane.  Same functions, same inputs, same bits as the per-pixel evaluation they replace.
-__global__ __launch_bounds__(256) void k_vertex_attr(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
-                                                     const slhip_draw* __restrict__ draws, float4* __restrict__ clip,
-                                                     unsigned n_clip_verts, float4* __restrict__ vattr, int W, int H,
-                                                     int with_lights, int S)
-{
-    const slhip_draw* dr = draws + blockIdx.x;
-    const unsigned nv = dr->n_verts;
-    if (blockIdx.y * 256 >= nv) return;
-    const slhip_scene* sc = scenes + dr->scene;
     const float hw = 0.5f * (float)W, hh = 0.5f * (float)H, hs = 0.5f * (float)S;
-    for (unsigned v = blockIdx.y * 256 + threadIdx.x; v < nv; v += gridDim.y * 256) {
-        // the light clip positions (planes 1..3) become window coordinates of the S x S map IN PLACE: the shadow pass clips
-        // nothing, so its set-up never needs the clip position itself
-        if (with_lights)
-            for (int l = 0; l < SLHIP_NUM_LIGHTS; ++l) {
-                if (!light_active(sc, l)) continue;
-                float4* slot = clip + (size_t)(1 + l) * n_clip_verts + dr->clip_base + v;
-                const float4 l4 = *slot;
-                const float lc[4] = {l4.x, l4.y, l4.z, l4.w};
-                int X, Y;
-                float z, invw;
-                screen_vertex(lc, hs, hs, X, Y, z, invw);
-                *reinterpret_cast<uint4*>(slot) = make_uint4((unsigned)X, (unsigned)Y, __float_as_uint(z), __float_as_uint(invw));
-            }
-        VsOut o;
-        vertex_full(pool, sc, dr, dr->vtx_base + v, o);
-        const float4 c4 = clip[dr->clip_base + v];
-        const float c[4] = {c4.x, c4.y, c4.z, c4.w};
-        int X = kScreenClipped, Y = 0;
-        float z = 0.0f, invw = 0.0f;
-        if (c[2] >= -c[3]) screen_vertex(c, hw, hh, X, Y, z, invw);   // the inside test of clip_near()
-        // one 64-byte record per vertex for the shading pass (one cache line per pixel corner) ...
-        float4* dst = vattr + 4 * (size_t)(dr->clip_base + v);
-        const uint4 scr = make_uint4((unsigned)X, (unsigned)Y, __float_as_uint(z), __float_as_uint(invw));
-        dst[0] = make_float4(o.objc[0], o.objc[1], o.objc[2], o.cam[2]);
-        dst[1] = make_float4(o.world[0], o.world[1], o.world[2], o.cam[0]);
-        dst[2] = make_float4(o.nrm[0], o.nrm[1], o.nrm[2], o.cam[1]);
-        reinterpret_cast<uint4*>(dst)[3] = scr;
-        // ... and the window coordinates once more as a dense plane for the raster pass (16 B per vertex, like the clip plane)
-        reinterpret_cast<uint4*>(vattr)[4 * (size_t)n_clip_verts + dr->clip_base + v] = scr;
+    // 256 vertices per block and pass (64 per wave = 4 MFMA batches); grid-stride over the draw's vertices, block-uniform trip count
+    for (unsigned base = blockIdx.y * 256; base < nv; base += gridDim.y * 256) {
+        const unsigned first = base + wave * 64;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned v0 = first + 16 * b;
+            const unsigned vj = min(v0 + (lane & 15), nv - 1);
+            // B[k][j]: component k of vertex j (w = 1): the wave reads 16 x 16 contiguous bytes
+            const float bval = k < 3 ? pos[4 * (size_t)vj + k] : 1.0f;
+            floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc, 0, 0, 0);
+            // lane holds rows (lane>>4)*4 + 0..3 of column lane&15 = the float4 of plane (lane>>4)
+            s_clip[wave][b][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        __syncthreads();
+        const unsigned v = first + lane;
+        if (v < nv) {
+            const float4* mine = &s_clip[wave][lane >> 4][lane & 15];   // + 16 * plane
+            if (with_lights)
+                for (int l = 0; l < SLHIP_NUM_LIGHTS; ++l) {
+                    if (!light_active(sc, l)) continue;
+                    const float4 l4 = mine[16 * (1 + l)];
+                    const float lc[4] = {l4.x, l4.y, l4.z, l4.w};
+                    int X, Y;
+                    float z, invw;
+                    screen_vertex(lc, hs, hs, X, Y, z, invw);
+                    reinterpret_cast<uint4*>(clip)[(size_t)(1 + l) * n_clip_verts + dr->clip_base + v] =
+                        make_uint4((unsigned)X, (unsigned)Y, __float_as_uint(z), __float_as_uint(invw));
+                }
+            VsOut o;
+            vertex_full(pool, sc, dr, dr->vtx_base + v, o);
+            const float4 c4 = mine[0];
+            clip[dr->clip_base + v] = c4;
+            const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+            int X = kScreenClipped, Y = 0;
+            float z = 0.0f, invw = 0.0f;
+            if (c[2] >= -c[3]) screen_vertex(c, hw, hh, X, Y, z, invw);   // the inside test of clip_near()
+            // one 64-byte record per vertex for the shading pass (one cache line per pixel corner) ...
+            float4* dst = vattr + 4 * (size_t)(dr->clip_base + v);
+            const uint4 scr = make_uint4((unsigned)X, (unsigned)Y, __float_as_uint(z), __float_as_uint(invw));
+            dst[0] = make_float4(o.objc[0], o.objc[1], o.objc[2], o.cam[2]);
+            dst[1] = make_float4(o.world[0], o.world[1], o.world[2], o.cam[0]);
+            dst[2] = make_float4(o.nrm[0], o.nrm[1], o.nrm[2], o.cam[1]);
+            reinterpret_cast<uint4*>(dst)[3] = scr;
+            // ... and the window coordinates once more as a dense plane for the raster pass (16 B per vertex, like the clip plane)
+            reinterpret_cast<uint4*>(vattr)[4 * (size_t)n_clip_verts + dr->clip_base + v] = scr;
+        }
+        __syncthreads();   // the LDS batch is free for the next pass
     }
 }
 
@@ -775,7 +775,7 @@ __device__ __forceinline__ void raster_or_enqueue(const Setup& t, const Target& 
 // Two instantiations over the same chunk list; a chunk (block) belongs to exactly one of them, the other returns at once:
 //   kAttr = false: plain triangles -- depth and primitive id only.  No texture sampling, no per-vertex attributes: a fraction
 //                  of the registers of the general form (the kernel's time follows its waves per SIMD), and triangles
-//                  entirely in front of the near plane are set up from the window coordinates k_vertex_attr stored per
+//                  entirely in front of the near plane are set up from the window coordinates k_vertex_xform stored per
 //                  vertex (`screen`), without a division;
 //   kAttr = true:  chunks whose fragments may be discarded before the depth write (alpha test against the base texture,
 //                  depth peeling): barycentrics, texture coordinates and camera z per fragment.
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, con
         if (!have_tri) continue;
         const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
         Setup t;
-        const uint4* sp = reinterpret_cast<const uint4*>(plane);   // k_vertex_attr turned the light's clip positions into window coordinates
+        const uint4* sp = reinterpret_cast<const uint4*>(plane);   // k_vertex_xform stores the light's clip positions as window coordinates
         if (!setup_from_screen(sp[i0], sp[i1], sp[i2], S, S, t)) continue;
         if (t.flipped) continue;  // front face culled
         // tiles of the triangle's pixel box (a 16k-triangle object: almost always one tile, at most a handful)
@@ -1411,7 +1411,7 @@ struct ShadeParams {
     int tiled;           // 1: a block shades a 32 x 8 pixel region, a wave an 8 x 8 tile (needs W % 32 == 0 and H % 8 == 0)
 };
 
-// The corners' vertex-stage outputs and window coordinates come from the records k_vertex_attr wrote (`vattr`).
+// The corners' vertex-stage outputs and window coordinates come from the records k_vertex_xform wrote (`vattr`).
 __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                const slhip_draw* __restrict__ draws, ShadeParams prm,
                                                const unsigned long long* __restrict__ vis,
@@ -2122,11 +2122,8 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     }
     // vertex transform on the matrix cores: camera clip + (if shadows) the three light clips
     if (n_chunks > 0) {
-        k_vertex_xform<<<dim3(n_draws, 32), 256, 0, stream>>>(*pool, d_scenes, d_draws,
-                                                                      reinterpret_cast<float4*>(scratch->d_clip),
-                                                                      scratch->n_clip_verts, shadows ? 1 : 0);
-        k_vertex_attr<<<dim3(n_draws, 32), 256, 0, stream>>>(*pool, d_scenes, d_draws, reinterpret_cast<float4*>(scratch->d_clip),
-                                                                 scratch->n_clip_verts, vattr, W, H, shadows ? 1 : 0, S);
+        k_vertex_xform<<<dim3(n_draws, 32), 256, 0, stream>>>(*pool, d_scenes, d_draws, reinterpret_cast<float4*>(scratch->d_clip),
+                                                                      scratch->n_clip_verts, vattr, W, H, shadows ? 1 : 0, S);
         SLHIP_LAUNCH_CHECK();
     }
     // shadow pass (maps clean on entry, see k_shadow_raster)
