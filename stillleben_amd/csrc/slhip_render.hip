@@ -1203,11 +1203,26 @@ __device__ __forceinline__ float shadow_pcf16(const float* __restrict__ sm, int 
             cx[k] = min(max(ix[0] + k, 0), S - 1);
             off_y[k] = (unsigned)min(max(iy[0] + k, 0), S - 1) * (unsigned)S;
         }
+        bool lit[5][5];
+        unsigned long long all_lit = ~0ull, any_lit = 0ull;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                lit[j][i] = r <= sm[off_y[j] + (unsigned)cx[i]];
+                const unsigned long long m = __ballot(lit[j][i]);
+                all_lit &= m; any_lit |= m;
+            }
+        // Away from shadow edges all 25 compares of a pixel agree, and then the sixteen bilinear taps are exactly 1 (or 0) each
+        // and their sum exactly 16 (or 0): when that holds for every lane of the wave that is here, the lerps are skipped.
+        const unsigned long long here = __ballot(true);
+        if (all_lit == here) return 1.0f;
+        if (any_lit == 0ull) return 0.0f;
         float c[5][5];
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
-            for (int i = 0; i < 5; ++i) c[j][i] = r <= sm[off_y[j] + (unsigned)cx[i]] ? 1.0f : 0.0f;
+            for (int i = 0; i < 5; ++i) c[j][i] = lit[j][i] ? 1.0f : 0.0f;
 #pragma unroll
         for (int yy = 0; yy < 4; ++yy)
 #pragma unroll
@@ -1462,7 +1477,7 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
     // the block's pixels belong to one scene: its draws' first primitive ids go to LDS once
     __shared__ unsigned s_prim_base[64];
     const unsigned n_scene_draws = sc->draw_end - sc->draw_begin;
-    if (threadIdx.x < 64 && threadIdx.x < n_scene_draws) s_prim_base[threadIdx.x] = draws[sc->draw_begin + threadIdx.x].prim_base;
+    if (threadIdx.x < 64) s_prim_base[threadIdx.x] = threadIdx.x < n_scene_draws ? draws[sc->draw_begin + threadIdx.x].prim_base : 0xFFFFFFFFu;
     __syncthreads();
 
     const slhip_light_map* lm = (sc->light_map != 0u && pool.d_light_maps) ? pool.d_light_maps + (sc->light_map - 1u) : nullptr;
@@ -1480,8 +1495,12 @@ __global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip
             const unsigned prim = (unsigned)(key & 0xFFFFFFFFull);
             unsigned d = sc->draw_begin;
             if (n_scene_draws <= 64) {
-                for (unsigned i = 1; i < n_scene_draws; ++i)
-                    if (prim >= s_prim_base[i]) d = sc->draw_begin + i;
+                // the last draw whose first primitive id is <= prim: six halving steps over the table (padded with ~0)
+                unsigned lo = 0u;
+#pragma unroll
+                for (unsigned step = 32u; step > 0u; step >>= 1)
+                    if (prim >= s_prim_base[lo + step]) lo += step;
+                d = sc->draw_begin + lo;
             } else {
                 for (unsigned i = sc->draw_begin + 1; i < sc->draw_end; ++i)
                     if (prim >= draws[i].prim_base) d = i;
