@@ -1761,11 +1761,15 @@ __device__ __forceinline__ float rect_bilinear_z(const float* __restrict__ img, 
     const float yc = __builtin_amdgcn_fmed3f(fy, -1.0f, (float)(H - 1));
     const int pitch = W + 2;
     const int idx = (int)fmaf(yc, (float)pitch, xc);                  // (row - 1) * pitch + (column - 1), may be negative
-    // byte offsets in 32 bits from the wave-uniform plane base: scalar base + one VGPR offset per load
-    const unsigned off = (unsigned)(idx * 4 + (pitch + 1) * 4);
+    // byte offsets in 32 bits from wave-uniform bases: ONE VGPR offset (a shift-and-add of the index) serves both rows, the
+    // lower row's base is the upper one's plus a pitch, in scalar registers
+    unsigned c0 = (unsigned)(pitch + 1) * 4u;
+    asm("" : "+s"(c0));   // opaque scalar: (idx << 2) + c0 is ONE v_lshl_add_u32 (the compiler otherwise splits the constant: add, shift-add)
+    const unsigned off = ((unsigned)idx << 2) + c0;
     const char* base = reinterpret_cast<const char*>(img);
+    const char* base_bot = base + (size_t)pitch * 4u;
     const ZPair top2 = *reinterpret_cast<const ZPair*>(base + off);
-    const ZPair bot2 = *reinterpret_cast<const ZPair*>(base + (off + (unsigned)pitch * 4u));
+    const ZPair bot2 = *reinterpret_cast<const ZPair*>(base_bot + off);
     const float top = fmaf(ax, top2.b - top2.a, top2.a), bot = fmaf(ax, bot2.b - bot2.a, bot2.a);
     return fmaf(ay, bot - top, top);
 }
@@ -1847,12 +1851,12 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
         // (on open surfaces whole waves skip it)
         const bool occludes = sd <= spz - bias;
         const float adz = fabsf(frag[2] - sd);
-        float rc = 1.0f;
+        float add = occludes ? 1.0f : 0.0f;
         if (occludes && adz > radius) {
             const float tt = clampf(radius / adz, 0.0f, 1.0f);
-            rc = tt * tt * (3.0f - 2.0f * tt);
+            add = tt * tt * (3.0f - 2.0f * tt);
         }
-        occlusion += occludes ? rc : 0.0f;
+        occlusion += add;
     }
     };
     if (w_is_z) taps(std::true_type{});   // scene-uniform: the whole wave takes one side
