@@ -24,6 +24,36 @@
 #include "slhip_common.h"
 #include "slhip_cubemap.h"
 
+// Occupancy ceilings of the render kernels (waves per SIMD; 0 = whatever the registers allow).  In the pipeline the settle stream
+// is the critical path -- 2400 dependent launches whose single-wave blocks have to find a free wave slot and 100-170 free VGPRs on
+// a SIMD -- and k_ssao, alone, would hold all eight wave slots of every SIMD for a quarter of the render's time.  With five
+// waves per SIMD it runs 7 % longer alone (21.5 -> 23.1 ms per 1024 scenes) and the pipeline 2 % faster (settle of a step next to
+// the render 1610 -> 1573 ms; 9 507 -> 9 703 scenes/s on the same box).  Six is worse than either (9 212), four too few (9 440);
+// ceilings on the other light kernels (-DSLHIP_RENDER_WAVES=n) or on k_shade (-DSLHIP_SHADE_WAVES=2) lose: DESIGN.md section 4.
+#ifndef SLHIP_RENDER_WAVES
+#define SLHIP_RENDER_WAVES 0
+#endif
+#ifndef SLHIP_SHADE_WAVES
+#define SLHIP_SHADE_WAVES 0
+#endif
+#ifndef SLHIP_SSAO_WAVES
+#define SLHIP_SSAO_WAVES 5
+#endif
+#if SLHIP_RENDER_WAVES > 0
+#define SLHIP_LIGHT_KERNEL __attribute__((amdgpu_waves_per_eu(1, SLHIP_RENDER_WAVES)))
+#else
+#define SLHIP_LIGHT_KERNEL
+#endif
+#if SLHIP_SSAO_WAVES > 0
+#define SLHIP_SSAO_KERNEL __attribute__((amdgpu_waves_per_eu(1, SLHIP_SSAO_WAVES)))
+#else
+#define SLHIP_SSAO_KERNEL
+#endif
+#if SLHIP_SHADE_WAVES > 0
+#define SLHIP_SHADE_KERNEL __attribute__((amdgpu_waves_per_eu(1, SLHIP_SHADE_WAVES)))
+#else
+#define SLHIP_SHADE_KERNEL
+#endif
 namespace {
 
 static_assert(sizeof(slhip_draw) == 432, "slhip_draw layout");
@@ -186,14 +216,16 @@ __device__ __forceinline__ bool screen_all_inside(const uint4& s0, const uint4& 
 // coverage + screen-space barycentrics at pixel (px,py) (R4, R5)
 __device__ __forceinline__ bool coverage(const Setup& t, int px, int py, float* lambda)
 {
-    const long long cx = 256ll * px + 128, cy = 256ll * py + 128;
+    // every factor fits 32 bits (snap() keeps |X|, |Y| <= 2^26, a pixel centre is below 2^23): each product is ONE
+    // 32 x 32 -> 64-bit multiply-add instead of a 64 x 64 product
+    const int cx = 256 * px + 128, cy = 256 * py + 128;
     long long E[3];
     bool inside = true;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int a = (i + 1) % 3, b = (i + 2) % 3;
-        long long e = (long long)(t.X[b] - t.X[a]) * (cy - t.Y[a]) -
-                      (long long)(t.Y[b] - t.Y[a]) * (cx - t.X[a]);
+        long long e = (long long)(t.X[b] - t.X[a]) * (long long)(cy - t.Y[a]) -
+                      (long long)(t.Y[b] - t.Y[a]) * (long long)(cx - t.X[a]);
         if (t.flipped) e = -e;
         inside = inside && (e + t.bias[i] >= 0);
         E[i] = e;
@@ -302,16 +334,29 @@ __device__ __forceinline__ void vertex_full(const slhip_mesh_pool& pool, const s
     const float4 p = reinterpret_cast<const float4*>(pool.d_pos)[v];
     const float pos[4] = {p.x, p.y, p.z, 1.0f};
     float obj4[4], world4[4], cam4[4];
+    // x / 1.0f is x, bit for bit: with affine matrices (the rule) the homogeneous coordinate is exactly 1 and the nine IEEE
+    // divisions (eleven instructions each) are jumped over by the whole wave
     mv4(dr->mesh_to_object, pos, obj4);
-    o.objc[0] = obj4[0] / obj4[3];
-    o.objc[1] = obj4[1] / obj4[3];
-    o.objc[2] = obj4[2] / obj4[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.objc[i] = obj4[i];
+    if (obj4[3] != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o.objc[i] = obj4[i] / obj4[3];
+    }
     mv4(dr->object_to_world, obj4, world4);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) o.world[i] = world4[i] / world4[3];
+    for (int i = 0; i < 3; ++i) o.world[i] = world4[i];
+    if (world4[3] != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o.world[i] = world4[i] / world4[3];
+    }
     mv4(sc->world_to_cam, world4, cam4);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) o.cam[i] = cam4[i] / cam4[3];
+    for (int i = 0; i < 3; ++i) o.cam[i] = cam4[i];
+    if (cam4[3] != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o.cam[i] = cam4[i] / cam4[3];
+    }
     o.objc[3] = o.cam[2];
     const float4 n4 = reinterpret_cast<const float4*>(pool.d_nrm)[v];
     const float n[3] = {n4.x, n4.y, n4.z};
@@ -357,7 +402,7 @@ __device__ __forceinline__ bool light_active(const slhip_scene* sc, int l)
 // The shading pass then fetches one cache line per corner instead of re-running three matrix products, nine divisions and a
 // normalisation per corner of every PIXEL and twelve more divisions per triangle set-up (160 k vertices per C2 scene against
 // 3 x 307 k pixel corners).  Same functions, same inputs, same bits as the per-pixel evaluation they replace.
-__global__ __launch_bounds__(256) void k_vertex_xform(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+__global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_vertex_xform(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                       const slhip_draw* __restrict__ draws, float4* __restrict__ clip,
                                                       unsigned n_clip_verts, float4* __restrict__ vattr, int W, int H,
                                                       int with_lights, int S)
@@ -564,13 +609,13 @@ __device__ __forceinline__ void tex_sample(const uint8_t* __restrict__ pool_tex,
 // set-up sub-triangle -- also outside its edges (used for the texture footprint)
 __device__ __forceinline__ void bary_at(const Setup& t, const float* b0, const float* b1, const float* b2, int px, int py, float* b)
 {
-    const long long cx = 256ll * px + 128, cy = 256ll * py + 128;
+    const int cx = 256 * px + 128, cy = 256 * py + 128;   // 32-bit factors, see coverage()
     float l[3];
     const float fa = (float)t.area2;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int a = (i + 1) % 3, c = (i + 2) % 3;
-        long long e = (long long)(t.X[c] - t.X[a]) * (cy - t.Y[a]) - (long long)(t.Y[c] - t.Y[a]) * (cx - t.X[a]);
+        long long e = (long long)(t.X[c] - t.X[a]) * (long long)(cy - t.Y[a]) - (long long)(t.Y[c] - t.Y[a]) * (long long)(cx - t.X[a]);
         if (t.flipped) e = -e;
         l[i] = (float)e / fa;
     }
@@ -695,14 +740,14 @@ struct QItem {
 template <class Target>
 __device__ __forceinline__ void raster_bbox(const Setup& t, const Target& tgt)
 {
-    const long long cx = 256ll * t.xmin + 128, cy = 256ll * t.ymin + 128;
+    const int cx = 256 * t.xmin + 128, cy = 256 * t.ymin + 128;   // 32-bit factors, see coverage()
     long long row[3], sx[3], sy[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int a = (i + 1) % 3, b = (i + 2) % 3;
-        const long long A = t.X[b] - t.X[a], B = t.Y[b] - t.Y[a];
-        long long e = A * (cy - t.Y[a]) - B * (cx - t.X[a]);
-        long long dx = -256ll * B, dy = 256ll * A;
+        const int Ai = t.X[b] - t.X[a], Bi = t.Y[b] - t.Y[a];
+        long long e = (long long)Ai * (long long)(cy - t.Y[a]) - (long long)Bi * (long long)(cx - t.X[a]);
+        long long dx = -256ll * (long long)Bi, dy = 256ll * (long long)Ai;
         if (t.flipped) { e = -e; dx = -dx; dy = -dy; }
         row[i] = e + t.bias[i]; sx[i] = dx; sy[i] = dy;
     }
@@ -891,7 +936,7 @@ __device__ __forceinline__ void raster_chunk(unsigned chunk, const slhip_mesh_po
 // with a few thousand blocks that skim the list for the (usually few or no) chunks that are theirs -- 340 k blocks that look at
 // one chunk header each and leave cost 1.1 ms per 1024 C2 scenes.
 template <bool kAttr>
-__global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+__global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_raster(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                 const slhip_draw* __restrict__ draws,
                                                 const slhip_chunk* __restrict__ chunks, unsigned n_chunks, int W, int H,
                                                 const float* __restrict__ depth_peel,
@@ -906,7 +951,7 @@ __global__ __launch_bounds__(256) void k_raster(slhip_mesh_pool pool, const slhi
 // k_large: one wave per (triangle, 8x8 tile); lane == pixel.  Every wave takes a CONTIGUOUS run of
 // queue items: the tiles of one triangle sit next to each other in the queue, so the fetch, the
 // near-plane clip and the setup are done once per run of equal triangles, not once per tile.
-__global__ __launch_bounds__(256) void k_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+__global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                const slhip_draw* __restrict__ draws, int W, int H,
                                                unsigned long long* __restrict__ vis,
                                                const unsigned* __restrict__ queue, unsigned capacity,
@@ -997,7 +1042,7 @@ constexpr int kShadowMaxWords = 32;   // LDS bitmap of k_shadow_raster: 1024 til
 __host__ __device__ inline int shadow_tiles_x(int S) { return (S + kShadowTile - 1) / kShadowTile; }
 __host__ __device__ inline int shadow_tile_words(int S) { return (shadow_tiles_x(S) * shadow_tiles_x(S) + 31) / 32; }
 
-__global__ __launch_bounds__(256) void k_shadow_raster(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+__global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_shadow_raster(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                        const slhip_draw* __restrict__ draws,
                                                        const slhip_chunk* __restrict__ chunks, int S,
                                                        unsigned* __restrict__ shadow, unsigned* queue,
@@ -1081,7 +1126,7 @@ __global__ __launch_bounds__(256) void k_shadow_restore(unsigned* __restrict__ s
     if (threadIdx.x == 0) tile_bits[wi] = 0u;
 }
 
-__global__ __launch_bounds__(256) void k_shadow_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+__global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_shadow_large(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                       const slhip_draw* __restrict__ draws, int S,
                                                       unsigned* __restrict__ shadow,
                                                       const unsigned* __restrict__ queue, unsigned capacity,
@@ -1358,19 +1403,21 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
 }
 
 // tone map of one HDR texel (tone_map_shader.frag:102-131); exposure_div < 0 => multiply by
-// manual exposure
+// manual exposure.  Colour only (8-bit tolerance): the six divisions go through the hardware reciprocal (1 ulp) -- an IEEE
+// division is eleven instructions in a pipeline bound by instruction issue.
 __device__ __forceinline__ uchar4 tone_map_px(const float* c, float manual_exposure, float lum)
 {
     const float X = 0.4124564f * c[0] + 0.3575761f * c[1] + 0.1804375f * c[2];
     float Y = 0.2126729f * c[0] + 0.7151522f * c[1] + 0.0721750f * c[2];
     const float Z = 0.0193339f * c[0] + 0.1191920f * c[1] + 0.9503041f * c[2];
-    const float inv = 1.0f / (X + Y + Z);
+    const float inv = frcp(X + Y + Z);
     const float xx = X * inv, yy = Y * inv;
     if (manual_exposure >= 0.0f) Y *= manual_exposure;
-    else Y /= (9.6f * lum + 0.0001f);
-    const float x2 = Y * xx / yy;
+    else Y *= frcp(9.6f * lum + 0.0001f);
+    const float ryy = frcp(yy);
+    const float x2 = Y * xx * ryy;
     const float y2 = Y;
-    const float z2 = Y * (1.0f - xx - yy) / yy;
+    const float z2 = Y * (1.0f - xx - yy) * ryy;
     float o[3];
     o[0] = 3.2404542f * x2 + -1.5371385f * y2 + -0.4985314f * z2;
     o[1] = -0.9692660f * x2 + 1.8760108f * y2 + 0.0415560f * z2;
@@ -1379,7 +1426,7 @@ __device__ __forceinline__ uchar4 tone_map_px(const float* c, float manual_expos
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float x = o[k];
-        float v = (x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f);
+        float v = (x * (2.51f * x + 0.03f)) * frcp(x * (2.43f * x + 0.59f) + 0.14f);
         v = fminf(fmaxf(v, 0.0f), 1.0f);
         if (!(v == v)) v = 0.0f;
         r[k] = (unsigned char)floorf(v * 255.0f + 0.5f);
@@ -1443,7 +1490,7 @@ struct ShadeParams {
 };
 
 // The corners' vertex-stage outputs and window coordinates come from the records k_vertex_xform wrote (`vattr`).
-__global__ __launch_bounds__(256) void k_shade(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
+__global__ __launch_bounds__(256) SLHIP_SHADE_KERNEL void k_shade(slhip_mesh_pool pool, const slhip_scene* __restrict__ scenes,
                                                const slhip_draw* __restrict__ draws, ShadeParams prm,
                                                const unsigned long long* __restrict__ vis,
                                                slhip_render_out out, float* __restrict__ hdr,
@@ -1787,7 +1834,7 @@ __device__ __forceinline__ float ssao_rcp(float x)
     return __uint_as_float((__float_as_uint(r) & 0x7fffffffu) | (__float_as_uint(x) & 0x80000000u));
 }
 
-__global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
+__global__ __launch_bounds__(256) SLHIP_SSAO_KERNEL void k_ssao(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
                                               const float* __restrict__ cam, const float* __restrict__ nrm,
                                               const float* __restrict__ zplane, float* __restrict__ ao,
                                               const float* __restrict__ kern)
@@ -1867,7 +1914,7 @@ __global__ __launch_bounds__(256) void k_ssao(const slhip_scene* __restrict__ sc
 // ... and the tone map of the result in the same pass (tone_map_shader.frag after ssao_apply_shader.frag): the blurred-AO colour
 // goes straight into tone_map_px, the float image is stored only on request (SLHIP_RENDER_KEEP_HDR).  `lum_scene`: the scene's
 // exposure luminance from k_lum_reduce (auto exposure), one float per scene at a stride of 4 * blocks_per_scene.
-__global__ __launch_bounds__(256) void k_ssao_apply(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
+__global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_ssao_apply(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
                                                     const float* __restrict__ hdr_in, const float* __restrict__ ao,
                                                     const float* __restrict__ zplane, float* __restrict__ hdr_out,
                                                     const float* __restrict__ lum_scene, uint8_t* __restrict__ rgb)
@@ -1917,11 +1964,11 @@ __global__ __launch_bounds__(256) void k_ssao_apply(const slhip_scene* __restric
             const float dz = corner(x, y);
             const float r = sqrtf((float)(x * x + y * y));
             const float dd = (dz - cd) * 300.0f;
-            const float w = exp2f(-r * r * falloff - dd * dd);
+            const float w = __builtin_amdgcn_exp2f(-r * r * falloff - dd * dd);   // (a weight that underflows adds nothing to sums that hold the centre's 1)
             wt += w;
             result += c * w;
         }
-    const float a = result / wt;
+    const float a = result * frcp(wt);
     const float4 h = reinterpret_cast<const float4*>(hdr_in)[gp];
     const float c4[4] = {h.x * a, h.y * a, h.z * a, h.w};
     if (hdr_out) reinterpret_cast<float4*>(hdr_out)[gp] = make_float4(c4[0], c4[1], c4[2], c4[3]);
