@@ -90,7 +90,8 @@ class Pipeline:
         self.batch, self.render_chunk, self.ssao = batch, render_chunk, ssao
         self.mask = _abi.OUT_GT6
         dev = self.eng.device
-        self.ring = settle_streams + 1
+        # record sets: one more than settle streams, so that a settle never waits for the render before last (SLHIP_BENCH_RING: developer knob)
+        self.ring = int(os.environ.get("SLHIP_BENCH_RING", settle_streams + 1))
         self.sets = []
         for _ in range(self.ring):
             b = sl.SceneBatch(table, batch, N_OBJECTS, resolution=RESOLUTION, seed=seed, render_chunk=render_chunk,
