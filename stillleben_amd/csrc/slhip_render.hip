@@ -1403,7 +1403,7 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
 }
 
 // tone map of one HDR texel (tone_map_shader.frag:102-131); exposure_div < 0 => multiply by
-// manual exposure.  Colour only (8-bit tolerance): the six divisions go through the hardware reciprocal (1 ulp) -- an IEEE
+// manual exposure.  Colour only (8-bit tolerance): five of the six divisions go through the hardware reciprocal (1 ulp) -- an IEEE
 // division is eleven instructions in a pipeline bound by instruction issue.
 __device__ __forceinline__ uchar4 tone_map_px(const float* c, float manual_exposure, float lum)
 {
@@ -1413,7 +1413,7 @@ __device__ __forceinline__ uchar4 tone_map_px(const float* c, float manual_expos
     const float inv = frcp(X + Y + Z);
     const float xx = X * inv, yy = Y * inv;
     if (manual_exposure >= 0.0f) Y *= manual_exposure;
-    else Y *= frcp(9.6f * lum + 0.0001f);
+    else Y /= (9.6f * lum + 0.0001f);
     const float ryy = frcp(yy);
     const float x2 = Y * xx * ryy;
     const float y2 = Y;
