@@ -24,12 +24,12 @@
 #include "slhip_common.h"
 #include "slhip_cubemap.h"
 
-// Occupancy ceilings of the render kernels (waves per SIMD; 0 = whatever the registers allow).  In the pipeline the settle stream
-// is the critical path -- 2400 dependent launches whose single-wave blocks have to find a free wave slot and 100-170 free VGPRs on
-// a SIMD -- and k_ssao, alone, would hold all eight wave slots of every SIMD for a quarter of the render's time.  With five
-// waves per SIMD it runs 7 % longer alone (21.5 -> 23.1 ms per 1024 scenes) and the pipeline 2 % faster (settle of a step next to
-// the render 1610 -> 1573 ms; 9 507 -> 9 703 scenes/s on the same box).  Six is worse than either (9 212), four too few (9 440);
-// ceilings on the other light kernels (-DSLHIP_RENDER_WAVES=n) or on k_shade (-DSLHIP_SHADE_WAVES=2) lose: DESIGN.md section 4.
+// Occupancy ceilings of the render kernels (waves per SIMD; 0 = whatever the registers allow; build-time experiment knobs).  In
+// the pipeline the settle stream is the critical path -- 2400 dependent launches whose single-wave blocks have to find a free
+// wave slot and 100-170 free VGPRs on a SIMD -- and how fast it runs beside the render depends on what the render kernels leave
+// free.  With two scenes per solver wave, k_ssao held to five waves per SIMD bought 2 % (9 507 -> 9 703 scenes/s; six: 9 212, four:
+// 9 440); with ONE scene per solver wave (the default since) no ceiling wins: k_ssao at 8 / 7 / 6 / 5 waves 9 789 / 9 433 / 9 555 /
+// 9 434, the other light kernels at 7 / 6: 9 795 / 9 631, k_shade at two waves: a loss.  All off: DESIGN.md section 4.
 #ifndef SLHIP_RENDER_WAVES
 #define SLHIP_RENDER_WAVES 0
 #endif
@@ -37,7 +37,7 @@
 #define SLHIP_SHADE_WAVES 0
 #endif
 #ifndef SLHIP_SSAO_WAVES
-#define SLHIP_SSAO_WAVES 5
+#define SLHIP_SSAO_WAVES 0
 #endif
 #if SLHIP_RENDER_WAVES > 0
 #define SLHIP_LIGHT_KERNEL __attribute__((amdgpu_waves_per_eu(1, SLHIP_RENDER_WAVES)))

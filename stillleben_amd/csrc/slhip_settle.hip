@@ -1624,12 +1624,14 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         const BeginLds BL = begin_layout(nb_cap, lhc);
         const FinishLds FL = finish_layout(nb_cap);
         const SolveLds SL = solve_layout(nb_cap);
-        // Scenes per solver wave: 2 -- cost-sorted neighbours side by side, 32 lanes each, same bits: 28 % fewer VALU instructions
-        // (28.4 k per scene and launch against 39.6 k).  Two scenes' LDS per wave leave five waves per CU, so the kernel ALONE is
-        // slower (2.05 against 1.33 ms per launch), but the pipeline as a whole is bound by VALU issue and the render stream takes
-        // the slots the solver leaves: 7 730 against 7 370 scenes/s over 20 steps.  SLHIP_SOLVE_SPW=1: one scene per wave.
-        int spw = 2;
-        if (const char* e = getenv("SLHIP_SOLVE_SPW")) spw = atoi(e) == 1 ? 1 : 2;
+        // Scenes per solver wave.  Two (cost-sorted neighbours side by side, 32 lanes each, same bits) cost a quarter fewer VALU
+        // instructions per scene and won in round 2, when the render stream was the pipeline's critical path and took the issue
+        // slots the solver left (7 730 against 7 370 scenes/s).  Since the end of round 3 the critical path is the settle stream
+        // itself, and what counts is how long its chain of launches takes next to the render: ONE scene per wave (20 KB of LDS, up
+        // to eight solver waves per CU, half the dependent rows per wave) settles a batch in 0.93 instead of 1.07 s alone and in
+        // 1.47 instead of 1.61 s beside the render: 9 511 -> 9 789 scenes/s on one box.  SLHIP_SOLVE_SPW=2: two scenes per wave.
+        int spw = 1;
+        if (const char* e = getenv("SLHIP_SOLVE_SPW")) spw = atoi(e) == 2 ? 2 : 1;
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SL.total));
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL.total));
         const unsigned cstride = pair_cache_stride(params);

@@ -283,18 +283,18 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
 
 
 def test_solver_wave_packing_and_odd_batches(sl, oracle, monkeypatch):
-    """The lockstep pipeline on a batch of mixed scenes (tabletop settle): two scenes per solver wave (default) and one give the
-    oracle's bits, also when the last solver wave holds a single scene."""
+    """The lockstep pipeline on a batch of mixed scenes (tabletop settle): one scene per solver wave (default) and two give the
+    oracle's bits, also when the last two-scene solver wave holds a single scene."""
     cube = scaled(sl, S.CUBE, 0.15)
     bunny = scaled(sl, S.BUNNY, 0.2)
     scs = [heap(sl, 300 + i, 4 + 3 * i, cube, bunny) for i in range(6)]
     gpu, ref = run_both(oracle, scs, frames=60)
     assert_bodies_equal(gpu, ref)
+    monkeypatch.setenv("SLHIP_SOLVE_SPW", "2")        # two cost-sorted scenes per wave instead of one
+    gpu2s, _ = run_both(oracle, scs, frames=60)
+    assert_bodies_equal(gpu2s, ref)
     gpu2, ref2 = run_both(oracle, scs + [heap(sl, 310, 9, cube, bunny)], frames=60)   # odd number: the last solver wave holds one scene
     assert_bodies_equal(gpu2, ref2)
-    monkeypatch.setenv("SLHIP_SOLVE_SPW", "1")        # one scene per wave instead of two
-    gpu1s, _ = run_both(oracle, scs, frames=60)
-    assert_bodies_equal(gpu1s, ref)
 
 
 def test_refused_first_scene_leaves_the_others_exact(sl, oracle):
