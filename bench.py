@@ -421,7 +421,7 @@ def main():
     cap_contacts, cap_pairs = b_last.settle_caps()
     scene_steps = args.batch * int(b_last.settle_params["frames"]) * int(b_last.settle_params["substeps"])
     caps = {"contact_cap_hit_rate": cap_contacts / scene_steps, "pair_cap_hit_rate": cap_pairs / scene_steps,
-            "max_active_contacts": 216, "max_hull_pairs": 512, "scene_steps": scene_steps,
+            "max_active_contacts": 255, "max_hull_pairs": 512, "scene_steps": scene_steps,
             "note": "share of (scene, step) pairs in which the body pairs offered more contacts than the cap left room for (every "
                     "pair then keeps its first B contacts, B the largest that fits) / the broadphase found more hull pairs than "
                     "the list holds; measured on one settle of the step's scenes after the timed region"}

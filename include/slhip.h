@@ -341,7 +341,7 @@ typedef struct {
 #define SLHIP_PAIR_CACHE_MAX_HULLS 256 /* scenes with more convex hulls settle without the pair cache (and without
                                           persistent manifolds: every step builds its manifolds from scratch) */
 #ifndef SLHIP_MAX_ACTIVE_CONTACTS   /* (a build-time experiment may override it; the oracle must be built with the same value) */
-#define SLHIP_MAX_ACTIVE_CONTACTS 216 /* solver contacts per scene and step (PhysX has no such cap, scene.cpp:738-739): the table
+#define SLHIP_MAX_ACTIVE_CONTACTS 255 /* solver contacts per scene and step (PhysX has no such cap, scene.cpp:738-739): the table
                                          contacts first; when the body pairs offer more than what is left, every pair keeps its
                                          first B contacts with the largest B that fits -- slhip_settle_caps says how often */
 #endif

@@ -1,5 +1,5 @@
 """Edge cases of the hot path on the GPU, each compared with the oracle: empty and ragged inputs,
-odd viewports, the documented caps (64 bodies, 512 candidate hull pairs, 216 solver contacts), scenes
+odd viewports, the documented caps (64 bodies, 512 candidate hull pairs, 255 solver contacts), scenes
 too large for the 8-per-CU LDS share, and the loud error paths of the C-ABI."""
 import ctypes as C
 
@@ -68,7 +68,7 @@ def test_empty_and_single_body_scenes(sl, oracle):
 
 def test_maximum_body_count_and_contact_caps(sl, oracle):
     """64 bodies (SLHIP_MAX_BODIES) dropped as one heap: the candidate hull-pair list and the solver
-    contact list run into their caps (512 / 216); the drop rules are part of the contract and the
+    contact list run into their caps (512 / 255); the drop rules are part of the contract and the
     GPU must apply them exactly like the oracle.  The LDS share of such a scene exceeds 20 KB, so
     fewer than 8 scenes are resident per CU."""
     cube = scaled(sl, S.CUBE, 0.12)

@@ -332,8 +332,8 @@ def test_cap_saturation_is_counted(sl, oracle):
     scs = []
     for i in range(4):                                    # bunnies (121 hulls each) dropped on each other: many hull pairs
         scene = sl.Scene((320, 240), seed=500 + i)
-        for k in range(6):
-            scene.add_object(sl.Object(bunny if k < 4 else cube))
+        for k in range(12):                               # (six bunnies + six cubes: up to 283 contacts offered against the cap of 255)
+            scene.add_object(sl.Object(bunny if k < 6 else cube))
         physics.prepare_tabletop(scene)
         scs.append(scene)
     se = physics.settle_engine()
