@@ -557,7 +557,7 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
         "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms_launch, "launches_per_settle": launches_per_settle,
         "measured": measured,
         "note": "the time-dominant kernel is NOT HBM-bound but bound by VALU issue (a wave64 instruction holds its SIMD for four "
-                "cycles with ~7 of 64 lanes active: Gauss-Seidel sweeps over chains of dependent contact rows); the HBM fraction "
+                "cycles with ~5 of 64 lanes active: Gauss-Seidel sweeps over chains of dependent contact rows); the HBM fraction "
                 "is reported because the schema asks for one -- see valu_frac / active_lanes.  ms_per_launch is taken in the "
                 "timed region, where the kernel shares the GPU with the render stream (the event pairs also bracket its wait for "
                 "free CU slots); ms_per_launch_alone / valu_frac_alone: one settle with the GPU to itself after the timed region",
