@@ -175,6 +175,14 @@ class Pipeline:
         torch.cuda.synchronize()
 
 
+def _header_define(name):
+    """Value of an integer #define of include/slhip.h (the caps the bench line quotes are the library's, not a copy)."""
+    import re
+
+    m = re.search(r"^#define %s (\d+)" % name, open(os.path.join(ROOT, "include", "slhip.h")).read(), re.M)
+    return int(m.group(1)) if m else None
+
+
 def cpu_baseline(table_meshes, scenes_per_thread, ssao, max_threads=32):
     """The oracle (scalar C restatement) timed on the host cores on a bounded sample of the same workload: every
     thread takes `scenes_per_thread` scenes through {tabletop set-up + 400-step settle + camera / light placement +
@@ -421,7 +429,8 @@ def main():
     cap_contacts, cap_pairs = b_last.settle_caps()
     scene_steps = args.batch * int(b_last.settle_params["frames"]) * int(b_last.settle_params["substeps"])
     caps = {"contact_cap_hit_rate": cap_contacts / scene_steps, "pair_cap_hit_rate": cap_pairs / scene_steps,
-            "max_active_contacts": 255, "max_hull_pairs": 512, "scene_steps": scene_steps,
+            "max_active_contacts": _header_define("SLHIP_MAX_ACTIVE_CONTACTS"), "max_hull_pairs": _header_define("SLHIP_MAX_HULL_PAIRS"),
+            "scene_steps": scene_steps,
             "note": "share of (scene, step) pairs in which the body pairs offered more contacts than the cap left room for (every "
                     "pair then keeps its first B contacts, B the largest that fits) / the broadphase found more hull pairs than "
                     "the list holds; measured on one settle of the step's scenes after the timed region"}
