@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define SLHIP_ABI_VERSION 2   /* 2: slhip_render_scratch.d_shadow_tiles, slhip_render_scratch_bytes fills 7 sizes */
+#define SLHIP_ABI_VERSION 3   /* 2: slhip_render_scratch.d_shadow_tiles, slhip_render_scratch_bytes fills 7 sizes
+                                 3: slhip_render_scratch.d_vattr is REQUIRED (the post-transform vertex cache) and `_pad` became
+                                    shadow_lights; d_clip holds 9 float4 planes per vertex; slhip_settle_params.resume (the contact
+                                    state of a settle outlives the call: 104 bytes)                                              */
 #define SLHIP_NUM_LIGHTS 3 /* reference include/stillleben/common.h:17 */
 
 /* ---------------------------------------------------------------------------------------------
@@ -333,6 +336,12 @@ typedef struct {
     uint32_t max_bodies_per_scene;
     uint32_t max_hull_verts_per_scene;   /* sum over a scene's bodies of their hull vertices  */
     uint32_t max_hulls_per_scene;
+    /* 0: the call starts from a cold contact state (it initialises the scratch).  N > 0: the call CONTINUES the N steps that earlier
+       calls ran on the same d_scratch with the same scenes, bodies (same order, same hulls) and sizing hints -- the state PhysX
+       keeps for the life of a PxScene (pair cache, persistent manifolds and their impulses, table contacts; scene.cpp:720-739,
+       903-912, manipulation_sim.cpp:83-93) is taken from the scratch as the last call left it, d_bodies carries poses, velocities,
+       wake counters and sleep flags.  k calls of one step give bit for bit what one call of k steps gives.                      */
+    uint32_t resume;
 } slhip_settle_params;
 
 /* per-scene scratch (device), sized by slhip_settle_scratch_bytes */
@@ -349,8 +358,10 @@ typedef struct {
 /* Steps every scene of the batch `frames * substeps` times without a host round trip -- a short sequence of kernel launches per
  * step over the whole batch (broadphase; GJK / portal refinement per hull pair; tilted runs for NEW contact pairs; persistent
  * manifolds, contact list and colouring; the warm-started 4 + 4 Gauss-Seidel sweeps, integration, sleeping), including the redrop
- * heuristic when params->tabletop.  State that PhysX keeps from step to step lives in the scratch for the duration of the call:
- * the cached simplex, the persistent contact manifold and its impulses per hull pair, the table contacts per body.
+ * heuristic when params->tabletop.  State that PhysX keeps from step to step lives in the scratch: the cached simplex, the
+ * persistent contact manifold and its impulses per hull pair, the table contacts per body -- and stays valid after the call:
+ * a later call with params->resume = (steps run so far) continues from it (Scene::simulate, ManipulationSim::step and the
+ * frames of simulateTableTopScene with a visualisation callback step ONE long-lived PxScene in the reference).
  * d_bodies is updated in place (pose, velocities, separation).  Replaces the hot loop of
  * Scene::simulateTableTopScene (scene.cpp:720-756) and, with frames=substeps=1 and
  * tabletop=0, Scene::simulate(dt) (scene.cpp:903-912).                                       */

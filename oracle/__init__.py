@@ -98,7 +98,24 @@ def ssao_tables():
     return noise, kern
 
 
-def settle(srec, bodies, hulls, hull_verts, params):
+class SettleState:
+    """Contact state of a settle that outlives a call (slref_settle_ex): created by a call with params['resume'] == 0,
+    continued by calls with params['resume'] == the steps run so far."""
+
+    def __init__(self):
+        self.handle = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                L = lib()
+                L.slref_settle_state_free.argtypes = [C.c_void_p]
+                L.slref_settle_state_free(self.handle)
+        except Exception:
+            pass
+
+
+def settle(srec, bodies, hulls, hull_verts, params, state=None):
     """Runs the CPU reference stepper in place on `bodies` (numpy structured array)."""
     L = lib()
     srec = np.ascontiguousarray(srec)
@@ -106,8 +123,9 @@ def settle(srec, bodies, hulls, hull_verts, params):
     hull_verts = np.ascontiguousarray(hull_verts, dtype=np.float32)
     params = np.ascontiguousarray(params)
     assert bodies.flags["C_CONTIGUOUS"]
-    L.slref_settle.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    st = L.slref_settle(_p(srec), len(srec), _p(bodies), _p(hulls), _p(hull_verts), _p(params))
+    L.slref_settle_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    st = L.slref_settle_ex(_p(srec), len(srec), _p(bodies), _p(hulls), _p(hull_verts), _p(params),
+                           C.byref(state.handle) if state is not None else None)
     if st != 0:
         raise RuntimeError("slref_settle failed: %d" % st)
     return bodies

@@ -1489,29 +1489,69 @@ void slref_settle_set_caps(unsigned* c) { g_caps = c; }
 static float* g_trace = NULL;
 void slref_settle_set_trace(float* t) { g_trace = t; }
 
-int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body* bodies,
-                 const slhip_hull* hulls, const float* hull_verts, const slhip_settle_params* prm)
+/* What a scene keeps between steps -- and, for a caller that steps one long-lived scene through many calls (Scene::simulate,
+   ManipulationSim::step, simulateTableTopScene with a visualisation callback: one PxScene in the reference, scene.cpp:720-739,
+   903-912, manipulation_sim.cpp:83-93), between calls: slhip_settle_params.resume.  */
+typedef struct {
+    gjk_seed* cache;
+    pmanifold* pm;
+    pplane pp[SLHIP_MAX_BODIES];
+    int step, n_hulls;
+    unsigned cap_hits[4];
+} scene_keep;
+typedef struct { uint32_t n_scenes; scene_keep* k; } settle_state;
+
+void slref_settle_state_free(void* state_)
 {
+    settle_state* st = (settle_state*)state_;
+    if (!st) return;
+    for (uint32_t s = 0; s < st->n_scenes; ++s) { free(st->k[s].cache); free(st->k[s].pm); }
+    free(st->k);
+    free(st);
+}
+
+/* `state` NULL: the contact state lives for this call only.  Otherwise *state is created by a call with prm->resume == 0 (an old
+   one is released) and continued by calls with prm->resume == the steps run so far (checked).  */
+int slref_settle_ex(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body* bodies,
+                    const slhip_hull* hulls, const float* hull_verts, const slhip_settle_params* prm, void** state)
+{
+    settle_state* st = state ? (settle_state*)*state : NULL;
+    if (prm->resume != 0u && (!st || st->n_scenes != n_scenes)) return -3;
+    if (prm->resume == 0u) {
+        if (st) slref_settle_state_free(st);
+        st = (settle_state*)calloc(1, sizeof(settle_state));
+        if (!st) return -1;
+        st->n_scenes = n_scenes;
+        st->k = (scene_keep*)calloc(n_scenes ? n_scenes : 1u, sizeof(scene_keep));
+        if (!st->k) { free(st); if (state) *state = NULL; return -1; }
+        if (state) *state = st;
+    }
     scene_ws* ws = (scene_ws*)malloc(sizeof(scene_ws));
-    if (!ws) return -1;
-    for (uint32_t s = 0; s < n_scenes; ++s) {
+    int rc = ws ? 0 : -1;
+    for (uint32_t s = 0; s < n_scenes && rc == 0; ++s) {
         const slhip_settle_scene* sc = &scenes[s];
         const int nb = (int)(sc->body_end - sc->body_begin);
-        if (nb > SLHIP_MAX_BODIES) { free(ws); return -2; }
+        if (nb > SLHIP_MAX_BODIES) { rc = -2; break; }
         slhip_body* b = bodies + sc->body_begin;
+        scene_keep* K = &st->k[s];
         ws->n_hulls = 0;
         for (int i = 0; i < nb; ++i) { ws->body_lh[i] = ws->n_hulls; ws->n_hulls += (int)(b[i].hull_end - b[i].hull_begin); }
         ws->body_lh[nb] = ws->n_hulls;
-        ws->cache = NULL;
-        ws->pm = NULL;
-        ws->step = 1;
-        memset(ws->pp, 0, sizeof(ws->pp));
-        memset(ws->cap_hits, 0, sizeof(ws->cap_hits));
-        if (ws->n_hulls > 0 && ws->n_hulls <= SLHIP_PAIR_CACHE_MAX_HULLS) {
-            ws->cache = (gjk_seed*)calloc((size_t)ws->n_hulls * ws->n_hulls, sizeof(gjk_seed));
-            ws->pm = (pmanifold*)calloc((size_t)ws->n_hulls * ws->n_hulls, sizeof(pmanifold));
-            if (!ws->cache || !ws->pm) { free(ws); return -1; }
-        }
+        if (prm->resume == 0u) {
+            K->step = 1;
+            K->n_hulls = ws->n_hulls;
+            if (ws->n_hulls > 0 && ws->n_hulls <= SLHIP_PAIR_CACHE_MAX_HULLS) {
+                K->cache = (gjk_seed*)calloc((size_t)ws->n_hulls * ws->n_hulls, sizeof(gjk_seed));
+                K->pm = (pmanifold*)calloc((size_t)ws->n_hulls * ws->n_hulls, sizeof(pmanifold));
+                if (!K->cache || !K->pm) { rc = -1; break; }
+            }
+        } else if (K->step != (int)prm->resume + 1 || K->n_hulls != ws->n_hulls) { rc = -3; break; }
+        ws->cache = K->cache;
+        ws->pm = K->pm;
+        ws->step = K->step;
+        memcpy(ws->pp, K->pp, sizeof(ws->pp));
+        memcpy(ws->cap_hits, K->cap_hits, sizeof(ws->cap_hits));
+        ws->n_groups = 0;
         for (uint32_t f = 0; f < prm->frames; ++f) {
             for (uint32_t ss = 0; ss < prm->substeps; ++ss) step_scene(sc, bodies, hulls, hull_verts, prm, ws);
             if (!prm->tabletop) continue;
@@ -1539,13 +1579,20 @@ int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body
             }
         }
         if (g_caps) { g_caps[4 * s] = ws->cap_hits[0]; g_caps[4 * s + 1] = ws->cap_hits[1]; g_caps[4 * s + 2] = ws->cap_hits[2]; g_caps[4 * s + 3] = (unsigned)(ws->step - 1); }
-        free(ws->cache);
-        free(ws->pm);
-        ws->cache = NULL;
-        ws->pm = NULL;
+        K->step = ws->step;
+        memcpy(K->pp, ws->pp, sizeof(ws->pp));
+        memcpy(K->cap_hits, ws->cap_hits, sizeof(ws->cap_hits));
     }
     free(ws);
-    return 0;
+    if (!state) slref_settle_state_free(st);
+    else if (rc != 0 && prm->resume == 0u) { slref_settle_state_free(st); *state = NULL; }
+    return rc;
+}
+
+int slref_settle(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_body* bodies,
+                 const slhip_hull* hulls, const float* hull_verts, const slhip_settle_params* prm)
+{
+    return slref_settle_ex(scenes, n_scenes, bodies, hulls, hull_verts, prm, NULL);
 }
 
 /* boolean overlap of each body against all others (+ the plane); scene.cpp:355-385 */

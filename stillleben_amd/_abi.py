@@ -39,7 +39,7 @@ RENDER_SSAO = 0x100
 RENDER_SHADOWS = 0x200
 RENDER_SHADOW_RESET = 0x400
 RENDER_KEEP_HDR = 0x800
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 
 

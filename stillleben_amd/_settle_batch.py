@@ -35,8 +35,9 @@ PARAMS_DTYPE = np.dtype([
     ("plane_mu_s", np.float32), ("plane_mu_d", np.float32), ("plane_restitution", np.float32),
     ("redrop_z", np.float32), ("stuck_separation", np.float32), ("stuck_frames", np.int32), ("tabletop", np.uint32),
     ("max_bodies_per_scene", np.uint32), ("max_hull_verts_per_scene", np.uint32), ("max_hulls_per_scene", np.uint32),
+    ("resume", np.uint32),
 ])
-assert PARAMS_DTYPE.itemsize == 100
+assert PARAMS_DTYPE.itemsize == 104
 
 BODY_STATIC = 1
 BODY_ASLEEP = 2
@@ -153,6 +154,12 @@ def _body_template(obj, pool):
     mesh with default settings; pose, velocities and per-step state are patched in per use."""
     rec = np.zeros((), dtype=BODY_DTYPE)
     body_record(obj, pool, rec)
+    # a template is shared by every object with the same mesh and settings: the spring drive of a ManipulationSim manipulator
+    # that happens to be the first object seen for its key must not travel with it
+    rec["drive_flags"] = 0
+    rec["drive_target"] = 0.0
+    rec["drive_frame"] = 0.0
+    rec["drive_params"] = 0.0
     return rec
 
 

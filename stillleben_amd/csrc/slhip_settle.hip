@@ -21,7 +21,7 @@ namespace {
 
 static_assert(sizeof(slhip_body) == 288, "slhip_body layout");
 static_assert(sizeof(slhip_hull) == 64, "slhip_hull layout");
-static_assert(sizeof(slhip_settle_params) == 100, "slhip_settle_params layout");
+static_assert(sizeof(slhip_settle_params) == 104, "slhip_settle_params layout");
 
 constexpr int kMaxContactsPerHP = 4;
 constexpr int kMaxGroups = SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES;
@@ -1635,12 +1635,13 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SL.total));
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL.total));
         const unsigned cstride = pair_cache_stride(params);
-        k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, cache_w, cstride);
+        // a resumed call finds everything the prologue would set up -- and the contact state it would clear -- in the scratch
+        if (params->resume == 0u) k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, cache_w, cstride);
         // the compacted narrowphase passes walk their work lists with a grid stride: enough waves for a step's typical list
         // (a scene has ~40 candidate pairs), never more than the worst case needs
         const unsigned list_stride = n_scenes * (unsigned)SLHIP_MAX_HULL_PAIRS;
         const unsigned work_grid = n_scenes < 16u ? n_scenes * (SLHIP_MAX_HULL_PAIRS / 64) : n_scenes;
-        uint32_t step = 0;
+        uint32_t step = params->resume;
         for (uint32_t f = 0; f < params->frames; ++f)
             for (uint32_t sub = 0; sub < params->substeps; ++sub, ++step) {
                 // (a caller that never reads the timings must not grow the lists for ever: sampling stops at kMaxTimedEvents)

@@ -2,10 +2,7 @@
 a world-anchored D6 joint drags the manipulator object towards a goal pose with a linear spring
 drive (stiffness 600, damping 0.1, force limit 60) while its rotation is locked; `step` sets the
 drive target and advances the whole scene by one `dt`."""
-import numpy as np
-
 from . import _math as M
-from . import _settle_batch as SB
 from ._context import require_context
 from ._math import as_mat4, f32
 
@@ -42,8 +39,4 @@ class ManipulationSim:
 
         goal = as_mat4(goal_pose)
         self._manipulator._drive["target"] = goal[:3, 3].copy()
-        se = physics.settle_engine()
-        srec, bodies = SB.build_settle_batch([self._scene], se.pool, [(False, 0.0)])
-        bodies["flags"] &= ~np.uint32(SB.BODY_ASLEEP)
-        bodies = se.run(srec, bodies, SB.default_params(tabletop=False, dt=float(dt), frames=1, substeps=1))
-        SB.write_back([self._scene], bodies)
+        physics.step_scene(self._scene, (False, 0.0), tabletop=False, dt=float(dt), frames=1, substeps=1)

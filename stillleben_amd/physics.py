@@ -54,13 +54,14 @@ class SettleEngine:
         out = np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy()
         return out
 
-    def check_status(self, n_scenes, stream=None):
+    def check_status(self, n_scenes, stream=None, scratch=None):
         """Raises if the last launch on `stream` left scenes untouched (sizing hints too small): the
         kernel refuses such scenes instead of corrupting LDS, and that must not pass silently."""
         eng = self.eng
         if stream is None:
             stream = torch.cuda.current_stream(eng.device).cuda_stream
-        scratch = self._scratch[stream]
+        if scratch is None:
+            scratch = self._scratch[stream]
         bad = C.c_uint32()
         with torch.cuda.device(eng.device):
             st = eng.L.slhip_settle_status(_abi_ptr(scratch), n_scenes, None, C.byref(bad), C.c_void_p(stream))
@@ -96,7 +97,14 @@ class SettleEngine:
         out = self.run(srec, bodies, params)
         return out, self.caps(len(srec))
 
-    def run_device(self, srec, bodies, params, d_bodies=None, hints=None):
+    def scratch_bytes(self, n_scenes, prm):
+        need = C.c_uint64()
+        self.eng.L.slhip_settle_scratch_bytes(n_scenes, C.c_void_p(prm.ctypes.data), C.byref(need))
+        return int(need.value)
+
+    def run_device(self, srec, bodies, params, d_bodies=None, hints=None, scratch=None):
+        """`scratch`: a caller-owned scratch tensor (a scene that keeps its contact state between calls, SceneState) instead
+        of the stream's."""
         eng = self.eng
         d_hulls, d_verts = self.hulls_dev()
         d_s = eng.upload_records(srec)
@@ -108,7 +116,8 @@ class SettleEngine:
         prm = np.ascontiguousarray(params).copy()
         for k, v in (hints or {}).items():
             prm[k] = v
-        scratch = self.scratch(len(srec), stream, prm)
+        if scratch is None:
+            scratch = self.scratch(len(srec), stream, prm)
         with torch.cuda.device(eng.device):
             st = eng.L.slhip_settle(_abi_ptr(d_s), len(srec), _abi_ptr(d_bodies), _abi_ptr(d_hulls), _abi_ptr(d_verts),
                                     C.c_void_p(prm.ctypes.data), _abi_ptr(scratch), scratch.numel(), C.c_void_p(stream))
@@ -274,26 +283,102 @@ def choose_camera_poses_batch(scenes):
         s._camera_pose = c.copy()
 
 
+class SceneState:
+    """What the reference's PxScene keeps while the sl.Scene lives (scene.cpp:134-173: one PxScene per Scene, stepped by every
+    simulate / ManipulationSim::step / frame of simulateTableTopScene): the contact state of the stepper -- pair cache, persistent
+    manifolds and their impulses, table contacts, in the scene's own device scratch --, wake counters and sleep flags of the
+    bodies, the number of steps run.  A call continues it (slhip_settle_params.resume) as long as the scene is what the last call
+    left: same objects in the same order, same table, poses untouched from outside."""
+
+    def __init__(self):
+        self.scratch = None
+        self.steps = 0
+        self.sig = None
+        self.bodies = None      # the records the last call returned
+        self.refs = None        # the pose / velocity arrays that call wrote into the objects
+
+
+def _signature(scene, srec, bodies, prm):
+    return (tuple(id(o) for o in scene._objects), bodies["hull_begin"].tobytes(), bodies["hull_end"].tobytes(),
+            bodies["inv_mass"].tobytes(), srec.tobytes(), int(prm["max_bodies_per_scene"]), int(prm["max_hull_verts_per_scene"]),
+            int(prm["max_hulls_per_scene"]), int(prm["tabletop"]))
+
+
+def step_scene(scene, plane, **prm_kw):
+    """One slhip_settle call on the scene's long-lived state (created cold when the scene has none, or is not what the last
+    call left).  Returns the body records."""
+    se = settle_engine()
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [plane])
+    hulls = se.pool.arrays()[0]
+    prm = SB.sizing_hints(SB.default_params(**prm_kw), srec, bodies, hulls)
+    sig = _signature(scene, srec, bodies, prm)
+    st = scene._phys_state
+    resume = st is not None and st.sig == sig and len(st.bodies) == len(bodies)
+    if resume:
+        for i, o in enumerate(scene._objects):
+            r = st.refs[i]
+            if o._static:
+                continue
+            if o._pose is not r[0]:
+                resume = False      # set_pose from outside: a teleport -- the contact state is not this arrangement's
+                break
+    if st is None:
+        st = scene._phys_state = SceneState()
+    if resume:
+        # what only the stepper knows about a body travels in the records: wake counter, sleep flag
+        keep = st.bodies
+        for i, o in enumerate(scene._objects):
+            r = st.refs[i]
+            if o._static:
+                continue
+            if o._linear_velocity is r[1] and o._angular_velocity is r[2]:
+                bodies["wake_counter"][i] = keep["wake_counter"][i]
+                bodies["flags"][i] = keep["flags"][i]
+            # (a velocity set from outside wakes the body, like PxRigidBody::setLinearVelocity's autowake)
+        prm["resume"] = st.steps
+    else:
+        st.steps = 0
+        prm["resume"] = 0
+    need = se.scratch_bytes(1, np.ascontiguousarray(prm))
+    if st.scratch is None or st.scratch.numel() < need or st.scratch.device != se.eng.device:
+        if resume:
+            raise RuntimeError("settle scratch of a live scene changed size")
+        st.scratch = torch.empty(need, dtype=torch.uint8, device=se.eng.device)
+    d_bodies = se.run_device(srec, None, prm, d_bodies=se.eng.upload_records(bodies), scratch=st.scratch)
+    if not resume:
+        se.check_status(1, scratch=st.scratch)
+    out = np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy()
+    SB.write_back([scene], out)
+    st.steps += int(prm["frames"]) * int(prm["substeps"])
+    st.sig = sig
+    st.bodies = out
+    st.refs = [(o._pose, o._linear_velocity, o._angular_velocity) for o in scene._objects]
+    return out
+
+
 def simulate_tabletop_scene(scene, vis_cb=None):
     has_plane = prepare_tabletop(scene)
-    se = settle_engine()
-    srec, bodies = SB.build_settle_batch([scene], se.pool, [(has_plane, PLANE_HALF_Z)])
+    scene._phys_state = None
     if vis_cb is None:
+        se = settle_engine()
+        srec, bodies = SB.build_settle_batch([scene], se.pool, [(has_plane, PLANE_HALF_Z)])
         bodies = se.run(srec, bodies, SB.default_params(tabletop=True))
         SB.write_back([scene], bodies)
     else:
-        # quirk q7: the callback runs BEFORE each frame's sub-steps (scene.cpp:723-724)
-        prm = SB.default_params(tabletop=True, frames=1)
+        # quirk q7: the callback runs BEFORE each frame's sub-steps (scene.cpp:723-724); the frames step ONE scene whose
+        # contact state carries over (scene.cpp:720-739) -- the poses are those of the call without a callback, bit for bit
         for i in range(100):
             vis_cb(i)
-            bodies = se.run(srec, bodies, prm)
-            SB.write_back([scene], bodies)
+            step_scene(scene, (has_plane, PLANE_HALF_Z), tabletop=True, frames=1)
+        scene._phys_state = None
     scene.choose_random_camera_pose()
 
 
 def settle_batch(scenes, frames=None):
     """Additive batch API (the GPU counterpart of JobQueue): settles many scenes in one launch."""
     planes = [(hp, PLANE_HALF_Z) for hp in prepare_tabletop_batch(scenes)]
+    for sc in scenes:
+        sc._phys_state = None
     se = settle_engine()
     srec, bodies = SB.build_settle_batch(scenes, se.pool, planes)
     bodies = se.run(srec, bodies, SB.default_params(tabletop=True, frames=frames))
@@ -304,11 +389,7 @@ def settle_batch(scenes, frames=None):
 def simulate(scene, dt):
     """One step of dt without a table (scene.cpp:903-912)."""
     scene.load_physics()
-    se = settle_engine()
-    srec, bodies = SB.build_settle_batch([scene], se.pool, [(False, 0.0)])
-    bodies["flags"] &= ~np.uint32(SB.BODY_ASLEEP)
-    bodies = se.run(srec, bodies, SB.default_params(tabletop=False, dt=dt, frames=1, substeps=1))
-    SB.write_back([scene], bodies)
+    step_scene(scene, (False, 0.0), tabletop=False, dt=dt, frames=1, substeps=1)
 
 
 def check_collisions(scene):

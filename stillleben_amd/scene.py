@@ -13,6 +13,8 @@ NUM_LIGHTS = 3
 
 
 class Scene:
+    _phys_state = None   # physics.SceneState: what the reference's PxScene keeps between simulate calls
+
     def __init__(self, viewport_size, seed=None):
         from ._context import require_context
 

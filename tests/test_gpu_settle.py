@@ -353,3 +353,158 @@ def test_cap_saturation_is_counted(sl, oracle):
     assert_bodies_equal(gpu, ref)
     assert caps == (int(oc[:, 0].sum()), int(oc[:, 1].sum()))
     assert caps[0] > 0                                     # the case is exercised
+
+
+# ---- the contact state outlives the call (slhip_settle_params.resume; PhysX: one PxScene per sl.Scene) ----------------------
+def _object_state(scene):
+    return np.stack([np.concatenate([o._pose.reshape(-1), o._linear_velocity, o._angular_velocity, [o._separation]]) for o in scene._objects]).astype(np.float32)
+
+
+def test_resume_equals_one_call(sl, oracle):
+    """k calls of one frame on the same scratch == one call of k frames, bit for bit, on a batch (C-ABI level), and equal to the
+    oracle's; cold starts per call give something else."""
+    from stillleben_amd import physics
+
+    cube = scaled(sl, S.CUBE, 0.15)
+    scs = [heap(sl, 900 + i, 7, cube) for i in range(8)]
+    se = physics.settle_engine()
+    srec, bodies = SB.build_settle_batch(scs, se.pool, [(True, TABLE)] * len(scs))
+    frames = 25
+    one = se.run(srec, bodies.copy(), SB.default_params(frames=frames))
+    d_b = se.eng.upload_records(bodies.copy())
+    cold = bodies.copy()
+    for f in range(frames):
+        prm = SB.default_params(frames=1)
+        prm["resume"] = 4 * f
+        prm = SB.sizing_hints(prm, srec, bodies, se.pool.arrays()[0])
+        d_b = se.run_device(srec, None, prm, d_bodies=d_b)
+    many = np.frombuffer(d_b.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy()
+    assert_bodies_equal(many, one)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    oracle.settle(srec, ref, hulls, verts, SB.default_params(frames=frames))
+    assert_bodies_equal(many, ref)
+    for f in range(frames):
+        cold = se.run(srec, cold, SB.default_params(frames=1))
+    assert cold["pose"].tobytes() != one["pose"].tobytes()
+
+
+def test_vis_cb_settle_equals_plain_settle(sl, oracle):
+    """simulate_tabletop_scene(vis_cb=f) steps the same long-lived scene as simulate_tabletop_scene() (scene.cpp:720-739):
+    same bodies, bit for bit."""
+    cube = scaled(sl, S.CUBE, 0.2)
+    bunny = scaled(sl, S.BUNNY, 0.25)
+    out = []
+    for cb in (None, lambda i: None):
+        scene = sl.Scene((320, 240), seed=21)
+        for i in range(6):
+            scene.add_object(sl.Object(bunny if i == 2 else cube))
+        scene.simulate_tabletop_scene(vis_cb=cb)
+        out.append(_object_state(scene))
+        assert scene._phys_state is None
+    assert out[0].tobytes() == out[1].tobytes()
+    # ... and what the oracle's single call gives
+    from stillleben_amd import physics
+
+    scene = sl.Scene((320, 240), seed=21)
+    for i in range(6):
+        scene.add_object(sl.Object(bunny if i == 2 else cube))
+    hp = physics.prepare_tabletop(scene)
+    se = physics.settle_engine()
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(hp, physics.PLANE_HALF_Z)])
+    hulls, verts = se.pool.arrays()
+    oracle.settle(srec, bodies, hulls, verts, SB.default_params(tabletop=True))
+    assert np.array_equal(bodies["pose"].reshape(-1, 16), out[0][:, :16])
+
+
+def _column(sl, n):
+    """n cubes in a column on a static slab (Scene::simulate has no table, scene.cpp:903-912)."""
+    cube = scaled(sl, S.CUBE, 0.2)
+    slab = scaled(sl, S.CUBE, 1.5)
+    h = 0.2 / np.sqrt(3.0) / 2.0
+    H = 1.5 / np.sqrt(3.0) / 2.0
+    scene = sl.Scene((320, 240))
+    base = sl.Object(slab)
+    base.static = True
+    p = torch.eye(4)
+    p[2, 3] = -H
+    base.set_pose(p)
+    scene.add_object(base)
+    zs = [h + 0.003 + k * (2 * h + 0.003) for k in range(n)]
+    for z in zs:
+        o = sl.Object(cube)
+        p = torch.eye(4)
+        p[2, 3] = float(z)
+        o.set_pose(p)
+        scene.add_object(o)
+    return scene, zs
+
+
+def test_column_stands_through_scene_simulate(sl, oracle):
+    """A column of 6 cubes stepped by 400 Scene.simulate(0.01) calls stands (a cold start per call topples it: round 3), and is
+    bit for bit what ONE 400-step call gives."""
+    from stillleben_amd import physics
+
+    scene, zs = _column(sl, 6)
+    se = physics.settle_engine()
+    scene.load_physics()
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(False, 0.0)])
+    for _ in range(400):
+        scene.simulate(0.01)
+    assert scene._phys_state.steps == 400
+    z = np.array([float(o.pose()[2, 3]) for o in scene.objects[1:]])
+    assert np.allclose(z, zs, atol=4e-3), z
+    for o in scene.objects[1:]:
+        R = o.pose().numpy()[:3, :3]
+        assert np.degrees(np.arccos(min(1.0, float(R[2, 2])))) < 0.5
+    prm = SB.default_params(tabletop=False, dt=0.01, frames=400, substeps=1)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    oracle.settle(srec, ref, hulls, verts, prm)
+    assert np.array_equal(ref["pose"].reshape(-1, 4, 4), np.stack([o._pose for o in scene._objects]))
+    assert np.array_equal(ref["flags"], scene._phys_state.bodies["flags"])
+    # a pose set from outside is a teleport: the next call starts cold
+    scene.objects[3].set_pose(scene.objects[3].pose())
+    scene.simulate(0.01)
+    assert scene._phys_state.steps == 1
+
+
+def test_manipulation_steps_equal_one_call(sl, oracle):
+    """50 ManipulationSim.step calls == one 50-frame slhip_settle (manipulation_sim.cpp:83-93 steps one PxScene), bit for bit --
+    and a plain object sharing the manipulator's mesh does not inherit its spring drive (round-3 advisor)."""
+    from stillleben_amd import physics
+
+    cube = scaled(sl, S.CUBE, 0.1)
+
+    def make():
+        scene = sl.Scene((320, 240))
+        tool = sl.Object(cube)
+        sim = sl.ManipulationSim(scene, tool, torch.eye(4))     # the manipulator is the FIRST object seen for its template key
+        for k in range(3):
+            o = sl.Object(cube)
+            p = torch.eye(4)
+            p[0, 3] = 0.105 * (k + 1)
+            o.set_pose(p)
+            scene.add_object(o)
+        return scene, tool, sim
+
+    se = physics.settle_engine()
+    se.pool.__dict__.pop("_body_templates", None)
+    scene, tool, sim = make()
+    goal = torch.eye(4)
+    goal[0, 3] = 0.2
+    tool._drive["target"] = goal[:3, 3].numpy().copy()
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(False, 0.0)])
+    assert (bodies["drive_flags"] != 0).sum() == 1 and bodies["drive_flags"][0] == 15
+    prm = SB.default_params(tabletop=False, dt=0.005, frames=50, substeps=1)
+    one = se.run(srec, bodies.copy(), prm)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    oracle.settle(srec, ref, hulls, verts, prm)
+    assert_bodies_equal(one, ref)
+    for _ in range(50):
+        sim.step(goal, 0.005)
+    assert scene._phys_state.steps == 50
+    assert np.array_equal(one["pose"].reshape(-1, 4, 4), np.stack([o._pose for o in scene._objects]))
+    assert np.array_equal(one["lin_vel"][:, :3], np.stack([o._linear_velocity for o in scene._objects]))
+    assert float(scene.objects[1].pose()[0, 3]) > 0.105      # the tool pushed its neighbour

@@ -241,3 +241,42 @@ def test_manipulation_drive_spring(sl, oracle):
     R = bodies[1]["pose"].reshape(4, 4)[:3, :3]
     assert np.allclose(R, np.eye(3), atol=2e-2)          # rotation stayed locked
     assert np.all(np.isfinite(bodies["pose"]))
+
+
+def _heap(sl, seed, n=6):
+    rng = np.random.default_rng(seed)
+    cube = scaled_cube(sl)
+    scene = sl.Scene((320, 240), seed=seed)
+    for i in range(n):
+        o = sl.Object(cube)
+        p = np.eye(4, dtype=np.float32)
+        p[:3, :3] = S.random_rotation(rng)
+        p[:3, 3] = [rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), TABLE + 0.1 + 0.13 * i]
+        o.set_pose(torch.from_numpy(p))
+        scene.add_object(o)
+    return scene
+
+
+def test_contact_state_outlives_the_call(sl, oracle):
+    """slhip_settle_params.resume: k calls of one frame == one call of k frames, bit for bit (PhysX keeps its contact cache for
+    the life of the PxScene, scene.cpp:720-739) -- and a cold start per call is NOT the same thing (what rounds 1-3 did)."""
+    frames = 30
+    pool = SB.HullPool()
+    srec, b0 = SB.build_settle_batch([_heap(sl, 3), _heap(sl, 4)], pool, [(True, TABLE)] * 2)
+    hulls, verts = pool.arrays()
+    one = b0.copy()
+    oracle.settle(srec, one, hulls, verts, SB.default_params(frames=frames))
+    many, cold = b0.copy(), b0.copy()
+    st = oracle.SettleState()
+    for f in range(frames):
+        prm = SB.default_params(frames=1)
+        prm["resume"] = 4 * f
+        oracle.settle(srec, many, hulls, verts, prm, state=st)
+        oracle.settle(srec, cold, hulls, verts, SB.default_params(frames=1))
+    assert one.tobytes() == many.tobytes()
+    assert one.tobytes() != cold.tobytes()
+    # a resume that does not match the steps run so far is refused
+    prm = SB.default_params(frames=1)
+    prm["resume"] = 7
+    with pytest.raises(RuntimeError):
+        oracle.settle(srec, many, hulls, verts, prm, state=st)
