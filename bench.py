@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--gather-scenes", type=int, default=64,
                     help="N > 1: scenes per rank and step whose ground truth is all-gathered to every rank (BASELINE config C3: "
                          "512 scenes = 64 per GPU x 8); 0 = no exchange")
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5"],
+                    help="BASELINE.json configuration: C2 (default) is the headline metric; C1 4 cubes 320x240 (4096 scenes per step), "
+                         "C3 512 C2 scenes through the per-object API, C4 bunny x 50 raster stress, C5 sl.diff 64 objects x 32 "
+                         "hypotheses -- one JSON line in the same schema each (single GPU)")
     ap.add_argument("--no-ssao", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes per host thread of the bounded CPU-baseline sample")
@@ -179,15 +183,16 @@ def _header_define(name):
     """Value of an integer #define of include/slhip.h (the caps the bench line quotes are the library's, not a copy)."""
     import re
 
-    m = re.search(r"^#define %s (\d+)" % name, open(os.path.join(ROOT, "include", "slhip.h")).read(), re.M)
+    m = re.search(r"^#define %s\s+(\d+)" % name, open(os.path.join(ROOT, "include", "slhip.h")).read(), re.M)
     return int(m.group(1)) if m else None
 
 
-def cpu_baseline(table_meshes, scenes_per_thread, ssao, max_threads=32):
+def cpu_baseline(table_meshes, scenes_per_thread, ssao):
     """The oracle (scalar C restatement) timed on the host cores on a bounded sample of the same workload: every
     thread takes `scenes_per_thread` scenes through {tabletop set-up + 400-step settle + camera / light placement +
-    640x480 render}.  Scenes are independent, so the threads mirror the reference's JobQueue workers
-    (job_queue.cpp:35-40); the C calls release the GIL and share no state."""
+    640x480 render}.  Scenes are independent, so the threads mirror the reference's JobQueue workers: the stated figure runs
+    hardware_concurrency() / 2 of them (job_queue.cpp:35-40); one thread and all hardware threads are printed beside it
+    (SURVEY.md 8d).  The C calls release the GIL and share no state."""
     from concurrent.futures import ThreadPoolExecutor
 
     import oracle
@@ -196,7 +201,7 @@ def cpu_baseline(table_meshes, scenes_per_thread, ssao, max_threads=32):
     from stillleben_amd import _settle_batch as SB
     from stillleben_amd._batch import HostPool
 
-    threads = max(1, min(os.cpu_count() or 1, max_threads))
+    ncpu = os.cpu_count() or 1
     flags = _abi.OUT_GT6 | _abi.RENDER_SHADOWS | (_abi.RENDER_SSAO if ssao else 0) | _abi.OUT_CAM_COORD
     pool, hulls = HostPool(), SB.HullPool()
     table = sl.AssetTable(table_meshes, mesh_pool=pool, hull_pool=hulls)   # host records only (untimed set-up, as on the GPU)
@@ -240,12 +245,18 @@ def cpu_baseline(table_meshes, scenes_per_thread, ssao, max_threads=32):
             oracle.render(pool_arrays, rs, rd, W, H, flags)
         return t1 - t0, time.perf_counter() - t1
 
-    with ThreadPoolExecutor(threads) as ex:
-        w0 = time.perf_counter()
-        times = list(ex.map(job, range(threads)))
-        wall = time.perf_counter() - w0
-    n = threads * scenes_per_thread
-    t_settle, t_render = sum(t[0] for t in times), sum(t[1] for t in times)
+    def leg(threads):
+        with ThreadPoolExecutor(threads) as ex:
+            w0 = time.perf_counter()
+            times = list(ex.map(job, range(threads)))
+            wall = time.perf_counter() - w0
+        n = threads * scenes_per_thread
+        return {"threads": threads, "scenes": n, "wall_s": wall, "scenes_per_s": n / wall,
+                "settle_s_per_scene": sum(t[0] for t in times) / n, "render_s_per_scene": sum(t[1] for t in times) / n}
+
+    half = max(1, ncpu // 2)
+    one, jq = leg(1), leg(half)
+    full = leg(ncpu) if ncpu > half else jq
     cpu_model = "?"
     try:
         with open("/proc/cpuinfo") as f:
@@ -253,10 +264,13 @@ def cpu_baseline(table_meshes, scenes_per_thread, ssao, max_threads=32):
     except OSError:
         pass
     return {
-        "value": n / wall, "unit": "scenes/s", "cores": threads, "kind": "port",
-        "sample": "%d scenes on %d threads (host: %d x %s), %.1f s wall; per scene on one thread: set-up + settle %.3f s, "
-                  "placement + render %.3f s, i.e. %.2f scenes/s single-threaded (oracle/, same C2 workload and seeds scheme)"
-                  % (n, threads, os.cpu_count() or 0, cpu_model, wall, t_settle / n, t_render / n, n / (t_settle + t_render)),
+        "value": jq["scenes_per_s"], "unit": "scenes/s", "cores": half, "kind": "port",
+        "sample": "%d scenes on %d threads = hardware threads / 2, the reference JobQueue's worker count (job_queue.cpp:35-40; host: %d x %s), "
+                  "%.1f s wall; beside it: 1 thread %.2f scenes/s (set-up + settle %.3f s, placement + render %.3f s per scene), all %d "
+                  "threads %.1f scenes/s (oracle/, same C2 workload and seeds scheme)"
+                  % (jq["scenes"], half, ncpu, cpu_model, jq["wall_s"], one["scenes_per_s"], one["settle_s_per_scene"],
+                     one["render_s_per_scene"], full["threads"], full["scenes_per_s"]),
+        "single_thread": one, "job_queue_threads": jq, "all_threads": full,
     }
 
 
@@ -277,8 +291,60 @@ def respawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def run_other_config(args):
+    """--config C1 | C3 | C4 | C5: the other BASELINE.json configurations (tools/bench_configs.py), one line in the bench schema.
+    Single GPU; `steps` / `warmup` are what the configuration's own timing loop ran."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+    bc = importlib.util.module_from_spec(spec)
+    sys.modules["bench"] = sys.modules[__name__]      # bench_configs imports this module for make_scene / INTRINSICS
+    spec.loader.exec_module(bc)
+    bc.QUIET = True
+    bc.sl.init_cuda(0)
+    cfg = args.config
+    if cfg == "C1":
+        r = bc.c1(4096)
+        ms = r["settle_s_per_batch"] * 1e3 + r["render_ms_per_batch"]
+        line = {"metric": "scenes/sec (settle + 320x240 instance-mask render), 4 cubes", "value": 4096 / (ms * 1e-3), "unit": "scenes/s",
+                "steps": 1, "warmup": 0, "ms_per_step": ms,
+                "config": {"workload": "C1: 4096 scenes of 4 cubes (tests/fixtures/cube.glb scaled to 0.2 m) through sl.Scene + "
+                                       "physics.settle_batch (host glue included) + one 320x240 instance-mask render launch sequence"},
+                "roofline": None}
+    elif cfg == "C3":
+        r = bc.c3()
+        ms = r["settle_s_incl_host_glue"] * 1e3 + r["render_ms"]
+        line = {"metric": "scenes/sec (settle + 640x480 6-ch GT render), 512 C2 scenes through the per-object API", "value": 512 / (ms * 1e-3),
+                "unit": "scenes/s", "steps": 1, "warmup": 0, "ms_per_step": ms,
+                "config": {"workload": "C3: 512 C2 scenes built as sl.Scene objects, settled in one launch (host glue included) and rendered "
+                                       "in 128-scene launch sequences (shadows + SSAO); the 8-rank form shards them 64 per GPU"},
+                "roofline": r["roofline"]}
+    elif cfg == "C4":
+        r = bc.c4()
+        line = {"metric": "renders/sec, stanford bunny x 50 (%d triangles), 640x480, all 8 outputs" % r["triangles"],
+                "value": 1e3 / r["render_ms"], "unit": "scenes/s", "steps": 10, "warmup": 1, "ms_per_step": r["render_ms"],
+                "config": {"workload": "C4: bunny x 50 raster stress, render only", "mtris_per_s": r["mtris_per_s"]},
+                "roofline": r["roofline"]}
+    else:
+        r = bc.c5()
+        ms = r["s_total_32_hypotheses_batch_api"] * 1e3
+        line = {"metric": "pose hypotheses/sec (render + sl.diff backward), 64 objects x 32 hypotheses", "value": 32 / (ms * 1e-3),
+                "unit": "hypotheses/s", "steps": 3, "warmup": 1, "ms_per_step": ms,
+                "config": {"workload": "C5: 64 objects in one 640x480 view, 32 pose hypotheses rendered and backpropagated in one launch "
+                                       "sequence each (sl.diff.backpropagate_gradient_to_poses_batch)"},
+                "roofline": r["roofline"]}
+    line.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                 "cpu_baseline": None, "detail": r})
+    sys.stderr.flush()
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    if args.config != "C2":
+        if args.gpus != 1:
+            sys.exit("bench.py: --config %s is a single-GPU configuration" % args.config)
+        return run_other_config(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(respawn_ranks(args))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
@@ -424,16 +490,21 @@ def main():
     pipe.eng.L.slhip_settle_timing_enable(0)
     for i, n in enumerate(settle_kernels):
         settle_kernels[n]["avg_ms_per_launch_alone"] = float(st_ms[i])
-    # cap saturation of that settle (the reference's PhysX has no caps): (scene, step) pairs at SLHIP_MAX_ACTIVE_CONTACTS /
-    # SLHIP_MAX_HULL_PAIRS over all scene-steps
-    cap_contacts, cap_pairs = b_last.settle_caps()
+    # what the list capacities cost that settle (the reference's PhysX has no caps, scene.cpp:738-739): nothing may be dropped
+    cp = b_last.settle_caps()
     scene_steps = args.batch * int(b_last.settle_params["frames"]) * int(b_last.settle_params["substeps"])
-    caps = {"contact_cap_hit_rate": cap_contacts / scene_steps, "pair_cap_hit_rate": cap_pairs / scene_steps,
-            "max_active_contacts": _header_define("SLHIP_MAX_ACTIVE_CONTACTS"), "max_hull_pairs": _header_define("SLHIP_MAX_HULL_PAIRS"),
-            "scene_steps": scene_steps,
-            "note": "share of (scene, step) pairs in which the body pairs offered more contacts than the cap left room for (every "
-                    "pair then keeps its first B contacts, B the largest that fits) / the broadphase found more hull pairs than "
-                    "the list holds; measured on one settle of the step's scenes after the timed region"}
+    caps = {"scenes": args.batch, "scene_steps": scene_steps,
+            "scenes_that_dropped_contacts_or_pairs": cp["scenes_dropped"],
+            "contact_drop_steps": cp["contact_drop_steps"], "pair_drop_steps": cp["pair_drop_steps"],
+            "scenes_whose_contacts_left_the_lds_part": cp["scenes_spilled"], "share_of_scenes_spilled": cp["scenes_spilled"] / args.batch,
+            "spill_step_rate": cp["spill_steps"] / scene_steps,
+            "most_contacts_in_a_step": cp["max_contacts"], "most_hull_pairs_in_a_step": cp["max_hull_pairs"],
+            "lds_contacts": _header_define("SLHIP_LDS_CONTACTS"),
+            "contact_capacity": int(b_last.settle_params["max_contacts_per_scene"]) or _header_define("SLHIP_DEFAULT_CONTACTS"),
+            "hull_pair_capacity": int(b_last.settle_params["max_hull_pairs_per_scene"]) or _header_define("SLHIP_DEFAULT_HULL_PAIRS"),
+            "note": "one settle of the step's scenes after the timed region (slhip_settle_caps): the solver takes every contact a step "
+                    "offers -- the first `lds_contacts` from LDS, the rest swept from global memory (`spilled`: nothing lost); a "
+                    "drop happens only beyond the capacities the scratch was sized with and must be zero"}
     # the exchange step alone: the same shard gathered synchronously after the timed region (inside it the collective runs
     # beside the next chunks' render on its own stream)
     exchange = None
@@ -477,7 +548,7 @@ def main():
 def load_counters():
     """SQ / HBM counters of the dominant kernels, collected by tools/collect_counters.py from separate rocprofv3 --pmc
     passes at the bench shape and committed under profiles/ (the latest round's file wins)."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "counters.json")
         if os.path.exists(path):
             with open(path) as f:
@@ -520,10 +591,13 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
     for k, bts in per_kernel_bytes.items():
         ms = float(iso_by_kernel[k]) / n_chunks                      # one launch = one render chunk
         if ms > 0.01:
-            per_kernel[k] = {"algorithmic_bytes_per_launch": bts * args.render_chunk, "ms_per_launch": ms,
-                             "achieved_GBps": bts * args.render_chunk / (ms * 1e-3) / 1e9,
-                             "frac": bts * args.render_chunk / (ms * 1e-3) / 8e12,
-                             "traffic": ck[k]["hbm_bytes_per_scene"] * args.render_chunk if k in ck else None}
+            traffic = ck[k]["hbm_bytes_per_scene"] * args.render_chunk if k in ck else None
+            # a model that exceeds what the counters saw move is not a roofline (positions served by the L2 are not HBM traffic):
+            # the kernel is priced on min(model, counter bytes)
+            priced = bts * args.render_chunk if traffic is None else min(bts * args.render_chunk, traffic)
+            per_kernel[k] = {"algorithmic_bytes_per_launch": priced, "model_bytes_per_launch": bts * args.render_chunk,
+                             "ms_per_launch": ms, "achieved_GBps": priced / (ms * 1e-3) / 1e9,
+                             "frac": priced / (ms * 1e-3) / 8e12, "traffic": traffic}
     ms_seq = t_render_iso / n_chunks
     roof_render = {
         "bound": "hbm", "kernel": "slhip_render launch sequence (%d scenes: vertex transform, shadow pass, visibility, shade, SSAO, tone map)" % args.render_chunk,
@@ -560,20 +634,28 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
         measured = "HIP events on the launch's stream around every slhip_settle of the timed region"
     alg = per_scene * args.batch
     valu_per_launch = sq.get("valu_insts_per_scene_launch")
+    # The dominant kernel is bound by VALU issue, not by HBM: `achieved` = wave64 VALU instructions issued per second (SQ_INSTS_VALU
+    # of the counters file x scenes per launch / the launch duration measured live), `peak` = one instruction per 2.3 cycles and SIMD
+    # -- the rate tools/probes/pk_probe.hip measured for streams of independent v_fma_f32 with several waves per SIMD (a single wave
+    # issues every 4.5 cycles).  The HBM figures the schema names stay beside it under "hbm".
+    issue_peak = 1024 * 2.4e9 / 2.3 / 1e9
+    hbm = {"achieved": alg / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else None, "peak": 8000.0, "unit": "GB/s",
+           "algorithmic_bytes_per_launch": alg, "traffic": sq["hbm_bytes_per_scene"] * args.batch if "hbm_bytes_per_scene" in sq else None}
+    if hbm["achieved"] is not None:
+        hbm["frac"] = hbm["achieved"] / hbm["peak"]
+    issued = valu_per_launch * args.batch / (ms_launch * 1e-3) / 1e9 if valu_per_launch and ms_launch > 0 else None
     roofline = {
-        "bound": "hbm", "kernel": kname, "achieved": alg / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else None, "peak": 8000.0,
-        "unit": "GB/s", "traffic": sq["hbm_bytes_per_scene"] * args.batch if "hbm_bytes_per_scene" in sq else None,
-        "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms_launch, "launches_per_settle": launches_per_settle,
+        "bound": "valu-issue", "kernel": kname, "achieved": issued, "peak": issue_peak, "unit": "G wave-instr/s",
+        "frac": issued / issue_peak if issued else None,
+        "traffic": hbm["traffic"], "hbm": hbm,
+        "ms_per_launch": ms_launch, "launches_per_settle": launches_per_settle,
         "measured": measured,
-        "note": "the time-dominant kernel is NOT HBM-bound but bound by VALU issue (a wave64 instruction holds its SIMD for four "
-                "cycles with ~5 of 64 lanes active: Gauss-Seidel sweeps over chains of dependent contact rows); the HBM fraction "
-                "is reported because the schema asks for one -- see valu_frac / active_lanes.  ms_per_launch is taken in the "
-                "timed region, where the kernel shares the GPU with the render stream (the event pairs also bracket its wait for "
-                "free CU slots); ms_per_launch_alone / valu_frac_alone: one settle with the GPU to itself after the timed region",
+        "note": "Gauss-Seidel sweeps over chains of dependent contact rows: few lanes of a wave are active (active_lanes), so the "
+                "kernel is bound by instruction issue and by the latency of a wave's dependent chain, not by bytes.  ms_per_launch is "
+                "taken in the timed region, where the kernel shares the GPU with the render streams (the event pairs also bracket its "
+                "wait for free CU slots); *_alone: one settle with the GPU to itself after the timed region",
         "valu_insts_per_scene_launch": valu_per_launch,
-        "valu_frac": (valu_per_launch * args.batch / (ms_launch * 1e-3) / (1024 * 2.4e9 / 4)) if valu_per_launch and ms_launch > 0 else None,
-        "valu_peak": "1024 SIMDs x 2.4 GHz / 4 cycles: SQ_ACTIVE_INST_VALU (quad-cycles) per SQ_INSTS_VALU is 1.0 for these kernels, "
-                     "i.e. a wave64 VALU instruction holds its SIMD for four cycles",
+        "peak_source": "1024 SIMDs x 2.4 GHz / 2.3 cycles per wave64 VALU instruction (tools/probes/pk_probe.hip, 16 waves per CU)",
         "active_lanes": sq.get("active_lanes"),
         "ms_per_launch_alone": settle_kernels[kname].get("avg_ms_per_launch_alone") if lockstep else None,
         "counters_source": cnt.get("source"),
@@ -582,14 +664,13 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
         "settle_ms_per_batch": t_settle, "settle_ms_per_batch_alone": t_settle_alone,
         "steps_scenes_per_s": args.batch * 400 / (t_settle * 1e-3),
     }
-    if roofline["achieved"] is not None:
-        roofline["frac"] = roofline["achieved"] / roofline["peak"]
     ms_alone = roofline.get("ms_per_launch_alone")
     if ms_alone:
-        roofline["achieved_alone"] = alg / (ms_alone * 1e-3) / 1e9
-        roofline["frac_alone"] = roofline["achieved_alone"] / roofline["peak"]
+        hbm["achieved_alone"] = alg / (ms_alone * 1e-3) / 1e9
+        hbm["frac_alone"] = hbm["achieved_alone"] / hbm["peak"]
         if valu_per_launch:
-            roofline["valu_frac_alone"] = valu_per_launch * args.batch / (ms_alone * 1e-3) / (1024 * 2.4e9 / 4)
+            roofline["achieved_alone"] = valu_per_launch * args.batch / (ms_alone * 1e-3) / 1e9
+            roofline["frac_alone"] = roofline["achieved_alone"] / issue_peak
     k_dom = int(np.argmax(phases)) if phases.sum() > 0 else 4
     return {
         "metric": "scenes/sec (settle + 640x480 6-ch GT render), 20-obj YCB-like",

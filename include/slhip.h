@@ -336,6 +336,13 @@ typedef struct {
     uint32_t max_bodies_per_scene;
     uint32_t max_hull_verts_per_scene;   /* sum over a scene's bodies of their hull vertices  */
     uint32_t max_hulls_per_scene;
+    /* Capacities of a scene's per-step lists in the scratch (PhysX allocates as it goes, scene.cpp:738-739; here the caller sizes
+       the scratch): candidate hull pairs the broadphase may file, contacts the solver may take.  0 = SLHIP_DEFAULT_HULL_PAIRS /
+       SLHIP_DEFAULT_CONTACTS (on the 20-object YCB-like workload: p99.99 of the pairs 1 000, most ever seen 1 551; contacts 477).
+       What a step offers beyond a capacity is dropped in list order AND COUNTED (slhip_settle_caps): a caller that finds a
+       non-zero count settles again with larger capacities -- nothing is ever dropped silently.                                */
+    uint32_t max_hull_pairs_per_scene;
+    uint32_t max_contacts_per_scene;
     /* 0: the call starts from a cold contact state (it initialises the scratch).  N > 0: the call CONTINUES the N steps that earlier
        calls ran on the same d_scratch with the same scenes, bodies (same order, same hulls) and sizing hints -- the state PhysX
        keeps for the life of a PxScene (pair cache, persistent manifolds and their impulses, table contacts; scene.cpp:720-739,
@@ -345,14 +352,15 @@ typedef struct {
 } slhip_settle_params;
 
 /* per-scene scratch (device), sized by slhip_settle_scratch_bytes */
-#define SLHIP_MAX_BODIES     64   /* bodies per scene                                          */
-#define SLHIP_MAX_HULL_PAIRS 512  /* candidate hull pairs per scene and step                   */
-#define SLHIP_PAIR_CACHE_MAX_HULLS 256 /* scenes with more convex hulls settle without the pair cache (and without
-                                          persistent manifolds: every step builds its manifolds from scratch) */
-#ifndef SLHIP_MAX_ACTIVE_CONTACTS   /* (a build-time experiment may override it; the oracle must be built with the same value) */
-#define SLHIP_MAX_ACTIVE_CONTACTS 255 /* solver contacts per scene and step (PhysX has no such cap, scene.cpp:738-739): the table
-                                         contacts first; when the body pairs offer more than what is left, every pair keeps its
-                                         first B contacts with the largest B that fits -- slhip_settle_caps says how often */
+#define SLHIP_MAX_BODIES     256  /* bodies per scene (the kernels keep a scene's working bodies in LDS: 152 B each)       */
+#define SLHIP_DEFAULT_HULL_PAIRS 2048 /* slhip_settle_params.max_hull_pairs_per_scene = 0 (at most 65535)                  */
+#define SLHIP_DEFAULT_CONTACTS   1024 /* slhip_settle_params.max_contacts_per_scene = 0 (at most 65535)                    */
+#define SLHIP_PAIR_CACHE_DENSE_HULLS 256 /* up to this many convex hulls per scene the pair cache (cached simplex + the way to the
+                                          pair's persistent manifold) is a dense [hulls]^2 table, beyond it an open-addressing hash
+                                          table keyed by the hull pair -- same contents, same results                         */
+#ifndef SLHIP_LDS_CONTACTS          /* (build-time tuning knob, results do not depend on it) */
+#define SLHIP_LDS_CONTACTS 96       /* the solver keeps a scene's first contacts of the step in LDS and sweeps the rest from global
+                                       memory: the list itself has no cap but the scratch's capacity                        */
 #endif
 
 /* Steps every scene of the batch `frames * substeps` times without a host round trip -- a short sequence of kernel launches per
@@ -373,14 +381,16 @@ int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
  * (may be NULL) = 0 when scene i was stepped, SLHIP_SETTLE_REFUSED_* when the kernel left it untouched
  * because it exceeds the sizing hints; *h_n_refused counts those.  Returns -2 (and sets the error
  * message) when any scene was refused -- a wrong hint must never pass silently.                       */
-#define SLHIP_SETTLE_REFUSED_BODIES 1u   /* more bodies than max_bodies_per_scene                      */
+#define SLHIP_SETTLE_REFUSED_BODIES 1u   /* more bodies than max_bodies_per_scene (or than SLHIP_MAX_BODIES) */
 #define SLHIP_SETTLE_REFUSED_HULLS  2u   /* more hulls than max_hulls_per_scene, or > 1024 in one body */
-/* (below) Cap saturation of the last slhip_settle on `d_scratch` (synchronises `stream`; same `params` as that call):
- * the number of (scene, step) pairs in which the contacts offered exceeded SLHIP_MAX_ACTIVE_CONTACTS (the fair cut applied) and
- * in which the broadphase found more than SLHIP_MAX_HULL_PAIRS hull pairs (the rest were dropped).  The reference has no cap:
- * a caller that cares divides by n_scenes * frames * substeps and decides.                                   */
+/* (below) What the capacities cost since the last cold start on `d_scratch` (synchronises `stream`; same `params` as those calls).
+ * counts[0] (scene, step) pairs whose contacts went beyond the solver's LDS-resident part (SLHIP_LDS_CONTACTS: swept from global
+ * memory, nothing lost), [1] (scene, step) pairs in which contacts beyond max_contacts_per_scene were DROPPED, [2] (scene, step)
+ * pairs in which hull pairs beyond max_hull_pairs_per_scene were DROPPED, [3] scenes with a non-zero [1] or [2], [4] scenes whose
+ * contacts ever went beyond the LDS-resident part, [5] the most contacts and [6] the most hull pairs a step of any scene offered.
+ * The reference has no caps (scene.cpp:738-739): [1] = [2] = 0 is the contract, a caller that sees otherwise re-sizes.          */
 int slhip_settle_caps(const void* d_scratch, uint32_t n_scenes, const slhip_settle_params* params,
-                      uint64_t* contact_cap_steps, uint64_t* pair_cap_steps, void* stream);
+                      uint64_t counts[7], void* stream);
 int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_status, uint32_t* h_n_refused,
                         void* stream);
 /* Optional live timing of the phases of a lockstep step (bench.py's roofline leg): HIP events on the launch's stream
@@ -391,7 +401,7 @@ int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_st
 int slhip_settle_timing_enable(int on);
 int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5]);
 /* scratch for n_scenes scenes: accumulators + the per-scene pair cache, sized from the hints in
- * `params` (NULL or zero hints: the worst case, SLHIP_PAIR_CACHE_MAX_HULLS^2 entries per scene)   */
+ * `params` (NULL or zero hints: the worst case)                                                      */
 int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out);
 
 /* Boolean any-overlap query per body against all OTHER bodies of its scene (and the plane if

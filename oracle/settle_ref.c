@@ -160,33 +160,74 @@ typedef struct {
 } pplane;
 
 typedef struct {
+    /* capacities of the per-step lists (slhip_settle_params.max_hull_pairs_per_scene / max_contacts_per_scene) and bodies */
+    int P, C, NB;
     /* hull pair list */
     int n_hp;
-    int hp_ba[SLHIP_MAX_HULL_PAIRS], hp_bb[SLHIP_MAX_HULL_PAIRS]; /* bodies */
-    int hp_ha[SLHIP_MAX_HULL_PAIRS], hp_hb[SLHIP_MAX_HULL_PAIRS]; /* global hull ids */
+    int *hp_ba, *hp_bb;                  /* [P] bodies */
+    int *hp_ha, *hp_hb;                  /* [P] global hull ids */
     /* constraint groups: contiguous contact ranges sharing a body pair */
     int n_groups;
-    int g_begin[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES], g_end[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES];
-    int g_a[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES], g_b[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES];
-    int g_color[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES];
+    int *g_begin, *g_end, *g_a, *g_b, *g_color;   /* [P + NB] */
     int n_colors;
-    contact c[(SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES) * MAX_CONTACTS_PER_HP];
-    wbody wb[SLHIP_MAX_BODIES];
+    contact* c;                          /* [(P + NB) * MAX_CONTACTS_PER_HP]: four slots per hull pair, then four per body (table) */
+    wbody* wb;                           /* [NB] */
     /* Pair cache (temporal coherence, like PhysX's cached separating axis): the last converged or
        separating simplex of every hull pair of the scene, [n_hulls][n_hulls] by scene-local hull
-       ordinals, cleared when a settle call starts.  Scenes with more than
-       SLHIP_PAIR_CACHE_MAX_HULLS hulls run without it (cache == NULL). */
+       ordinals, cleared when a cold settle call starts. */
     struct gjk_seed_s* cache;
     pmanifold* pm;                       /* [n_hulls][n_hulls], beside the cache */
-    pmanifold* hp_pm[SLHIP_MAX_HULL_PAIRS];
-    pplane pp[SLHIP_MAX_BODIES];
-    int step;                            /* 1-based step number within the settle call */
+    pmanifold** hp_pm;                   /* [P] */
+    pplane* pp;                          /* [NB] */
+    int step;                            /* 1-based step number since the cold start */
     int hp_overflow;
-    unsigned cap_hits[4];                /* steps of this scene that dropped contacts at the active-contact cap / hull pairs at the
-                                            pair cap; [2] = the most contacts a step offered */
+    unsigned cap_hits[4];                /* steps of this scene that dropped contacts beyond C / hull pairs beyond P; the most contacts /
+                                            hull pairs a step offered */
     int n_hulls;
-    int body_lh[SLHIP_MAX_BODIES + 1]; /* first hull ordinal of every body */
+    int* body_lh;                        /* [NB + 1] first hull ordinal of every body */
+    int *order, *size;                   /* [P + NB] colouring scratch */
+    uint64_t* used;                      /* [NB] */
 } scene_ws;
+
+static void ws_free(scene_ws* ws)
+{
+    if (!ws) return;
+    free(ws->hp_ba); free(ws->hp_bb); free(ws->hp_ha); free(ws->hp_hb);
+    free(ws->g_begin); free(ws->g_end); free(ws->g_a); free(ws->g_b); free(ws->g_color);
+    free(ws->c); free(ws->wb); free(ws->hp_pm); free(ws->pp); free(ws->body_lh); free(ws->order); free(ws->size); free(ws->used);
+    free(ws);
+}
+
+static scene_ws* ws_alloc(int P, int C, int NB)
+{
+    scene_ws* ws = (scene_ws*)calloc(1, sizeof(scene_ws));
+    if (!ws) return NULL;
+    ws->P = P; ws->C = C; ws->NB = NB;
+    const size_t G = (size_t)P + NB;
+    ws->hp_ba = (int*)malloc(sizeof(int) * P); ws->hp_bb = (int*)malloc(sizeof(int) * P);
+    ws->hp_ha = (int*)malloc(sizeof(int) * P); ws->hp_hb = (int*)malloc(sizeof(int) * P);
+    ws->g_begin = (int*)malloc(sizeof(int) * G); ws->g_end = (int*)malloc(sizeof(int) * G);
+    ws->g_a = (int*)malloc(sizeof(int) * G); ws->g_b = (int*)malloc(sizeof(int) * G); ws->g_color = (int*)malloc(sizeof(int) * G);
+    ws->c = (contact*)malloc(sizeof(contact) * G * MAX_CONTACTS_PER_HP);
+    ws->wb = (wbody*)malloc(sizeof(wbody) * (NB ? NB : 1));
+    ws->hp_pm = (pmanifold**)malloc(sizeof(pmanifold*) * P);
+    ws->pp = (pplane*)calloc(NB ? NB : 1, sizeof(pplane));
+    ws->body_lh = (int*)malloc(sizeof(int) * (NB + 1));
+    ws->order = (int*)malloc(sizeof(int) * G); ws->size = (int*)malloc(sizeof(int) * G);
+    ws->used = (uint64_t*)malloc(sizeof(uint64_t) * (NB ? NB : 1));
+    if (!ws->hp_ba || !ws->hp_bb || !ws->hp_ha || !ws->hp_hb || !ws->g_begin || !ws->g_end || !ws->g_a || !ws->g_b || !ws->g_color ||
+        !ws->c || !ws->wb || !ws->hp_pm || !ws->pp || !ws->body_lh || !ws->order || !ws->size || !ws->used) { ws_free(ws); return NULL; }
+    return ws;
+}
+
+static inline int cap_pairs(const slhip_settle_params* prm)
+{
+    return prm->max_hull_pairs_per_scene ? (int)prm->max_hull_pairs_per_scene : SLHIP_DEFAULT_HULL_PAIRS;
+}
+static inline int cap_contacts(const slhip_settle_params* prm)
+{
+    return prm->max_contacts_per_scene ? (int)prm->max_contacts_per_scene : SLHIP_DEFAULT_CONTACTS;
+}
 
 
 /* ------------------------------------------------------------------------------------------ */
@@ -711,6 +752,9 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     pmanifold prev;
     prev.count = 0;
     if (pm && pm->stamp == step - 1) prev = *pm;
+    /* what a pair keeps from step to step lives as long as the pair stays a broadphase candidate (PhysX destroys a pair's contact
+       manager and cache when its bounds stop overlapping [ext]): a pair that was not listed in the previous step starts cold */
+    if (pm && cached && pm->stamp != step - 1) { cached->n = 0; cached->idx[0] = cached->idx[1] = cached->idx[2] = 0; }
     if (pm) { pm->stamp = step; pm->count = 0; }
     int code = gjk_distance_seeded(&A, &B, sub(ca, cb), margin, &pa, &pb, &dist, cached, &seed, GJK_MAX_ITER);
     if (g_stats) g_stats[1024 + (g_last_gjk_iters > 63 ? 63 : g_last_gjk_iters)]++; /* [1024, 1088): iterations of the main runs */
@@ -1053,9 +1097,9 @@ static void solve_drive(const slhip_body* b, wbody* w, const slhip_settle_params
    bound set by the busiest body).  The order within a colour does not matter (disjoint bodies). */
 static void color_groups(scene_ws* ws, int n_bodies)
 {
-    uint64_t used[SLHIP_MAX_BODIES];
+    uint64_t* used = ws->used;
     for (int i = 0; i < n_bodies; ++i) used[i] = 0;
-    int order[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES], size[SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES];
+    int *order = ws->order, *size = ws->size;
     for (int g = 0; g < ws->n_groups; ++g) {
         int c = 0;
         for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) c += ws->c[i].valid ? 1 : 0;
@@ -1067,16 +1111,21 @@ static void color_groups(scene_ws* ws, int n_bodies)
             if (size[h] > size[g] || (size[h] == size[g] && h < g)) ++rank;
         order[rank] = g;
     }
-    int nc = 0;
+    /* greedy, largest group first: the lowest of the colours 0..62 that neither body uses; a group whose bodies leave none of them
+       free (a hub with more than 63 neighbours) gets a colour of its own from 63 on -- it is swept alone, after the others */
+    int nc = 0, extra = 63;
     for (int q = 0; q < ws->n_groups; ++q) {
         const int g = order[q];
         uint64_t m = used[ws->g_a[g]];
         if (ws->g_b[g] >= 0) m |= used[ws->g_b[g]];
         int c = 0;
         while (c < 63 && (m >> c) & 1ull) ++c;
+        if (c == 63) c = extra++;
+        else {
+            used[ws->g_a[g]] |= 1ull << c;
+            if (ws->g_b[g] >= 0) used[ws->g_b[g]] |= 1ull << c;
+        }
         ws->g_color[g] = c;
-        used[ws->g_a[g]] |= 1ull << c;
-        if (ws->g_b[g] >= 0) used[ws->g_b[g]] |= 1ull << c;
         if (c + 1 > nc) nc = c + 1;
     }
     ws->n_colors = nc;
@@ -1088,6 +1137,8 @@ static void color_groups(scene_ws* ws, int n_bodies)
 void slref_settle_set_stats(uint64_t* h) { g_stats = h; }
 static uint64_t* g_offered = NULL; /* histogram [2048] of the contacts a step offers before the cap (tools/physics_quality.py) */
 void slref_settle_set_offered_hist(uint64_t* h) { g_offered = h; }
+static uint64_t* g_pairs_hist = NULL; /* histogram [8192] of the candidate hull pairs a step's broadphase finds (incl. those beyond the list) */
+void slref_settle_set_pairs_hist(uint64_t* h) { g_pairs_hist = h; }
 static FILE* g_profile_fp = NULL;
 void slref_settle_set_profile_dump(const char* path)
 {
@@ -1108,17 +1159,17 @@ static void step_stats(const scene_ws* ws)
             anchors += m >= 2 ? 2 : m;
             rows += m + (m >= 2 ? 2 : m);
         }
-        if (rows > longest[ws->g_color[g]]) longest[ws->g_color[g]] = rows;
+        if (ws->g_color[g] < 64 && rows > longest[ws->g_color[g]]) longest[ws->g_color[g]] = rows;
     }
-    for (int c = 0; c < ws->n_colors; ++c) chain += longest[c];
-    if (g_profile_fp) { /* developer dump (tools/solver_pairing.py): one line per scene and step, the longest group per colour */
+    for (int c = 0; c < ws->n_colors && c < 64; ++c) chain += longest[c];
+    if (g_profile_fp && ws->n_colors <= 64) { /* developer dump (tools/solver_pairing.py): one line per scene and step, the longest group per colour */
         fprintf(g_profile_fp, "%d", ws->n_colors);
         for (int c = 0; c < ws->n_colors; ++c) fprintf(g_profile_fp, " %d", longest[c]);
         fprintf(g_profile_fp, "\n");
     }
     g_stats[active > 255 ? 255 : active]++;
     g_stats[256 + (anchors > 255 ? 255 : anchors)]++;
-    g_stats[512 + ws->n_colors]++;
+    g_stats[512 + (ws->n_colors > 255 ? 255 : ws->n_colors)]++;
     g_stats[768 + (chain > 255 ? 255 : chain)]++;
 }
 
@@ -1214,9 +1265,10 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
     ws->n_hp = 0;
     ws->n_groups = 0;
     ws->hp_overflow = 0;
+    int pairs_found = 0;
     /* (b) plane contacts FIRST: one group per dynamic body near the table (their contacts have
        priority under the active-contact cap); slots live after the hull-pair slots */
-    const int plane_base = SLHIP_MAX_HULL_PAIRS * MAX_CONTACTS_PER_HP;
+    const int plane_base = ws->P * MAX_CONTACTS_PER_HP;
     if (sc->has_plane) {
         for (int i = 0; i < nb; ++i) {
             if (!wb[i].dynamic) continue;
@@ -1255,7 +1307,8 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
                     float r2 = hulls[ha].sphere[3] + hulls[hb].sphere[3] + margin;
                     if (dot(dd, dd) > r2 * r2) continue;
                     if (!aabb_overlap(&wb[i], &hulls[ha], &wb[j], &hulls[hb], margin)) continue;
-                    if (ws->n_hp >= SLHIP_MAX_HULL_PAIRS) { ws->hp_overflow = 1; continue; } /* overflow: dropped (deterministic) */
+                    ++pairs_found;
+                    if (ws->n_hp >= ws->P) { ws->hp_overflow = 1; continue; } /* beyond the capacity: dropped in list order, counted */
                     int k = ws->n_hp++;
                     ws->hp_ba[k] = i; ws->hp_bb[k] = j; ws->hp_ha[k] = (int)ha; ws->hp_hb[k] = (int)hb;
                 }
@@ -1268,6 +1321,8 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         }
 
     if (ws->hp_overflow) ws->cap_hits[1]++;
+    if (g_pairs_hist) g_pairs_hist[pairs_found > 8191 ? 8191 : pairs_found]++;
+    if ((unsigned)pairs_found > ws->cap_hits[3]) ws->cap_hits[3] = (unsigned)pairs_found;
     /* (d) narrowphase per hull pair */
     for (int k = 0; k < ws->n_hp; ++k) {
         int i = ws->hp_ba[k], j = ws->hp_bb[k];
@@ -1299,52 +1354,25 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
             for (int k = limit; k < MAX_CONTACTS_PER_HP; ++k) ws->c[i + k].valid = 0;
     }
 
-    /* active-contact cap (SLHIP_MAX_ACTIVE_CONTACTS; PhysX has none).  The table contacts come first.  When the body pairs offer
-       more than what is left, every pair group keeps its first B contacts (slot order) with the largest B that fits -- no pair
-       loses ALL its contacts while others keep dozens; the walk in group order below only cuts what even B = 1 cannot fit. */
+    /* The solver takes every contact (PhysX has no cap, scene.cpp:738-739) -- up to the capacity of the list the caller sized
+       (max_contacts_per_scene): what a step offers beyond it is dropped in list order, the table's contacts first in the list,
+       and counted. */
     {
-        int plane_active = 0, total = 0, bmax = 0;
-        for (int g = 0; g < ws->n_groups; ++g) {
-            int n = 0;
-            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) n += ws->c[i].valid ? 1 : 0;
-            if (ws->g_b[g] < 0) plane_active += n;
-            else { total += n; if (n > bmax) bmax = n; }
-        }
-        if (plane_active > SLHIP_MAX_ACTIVE_CONTACTS) plane_active = SLHIP_MAX_ACTIVE_CONTACTS;
-        const int budget = SLHIP_MAX_ACTIVE_CONTACTS - plane_active;
-        if (g_offered) g_offered[plane_active + total > 2047 ? 2047 : plane_active + total]++;
-        if (plane_active + total > ws->cap_hits[2]) ws->cap_hits[2] = plane_active + total;
-        if (total > budget) {
+        int offered = 0;
+        for (int g = 0; g < ws->n_groups; ++g)
+            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) offered += ws->c[i].valid ? 1 : 0;
+        if (g_offered) g_offered[offered > 2047 ? 2047 : offered]++;
+        if ((unsigned)offered > ws->cap_hits[2]) ws->cap_hits[2] = (unsigned)offered;
+        if (offered > ws->C) {
             ws->cap_hits[0]++;
-            int B = 1;
-            for (int t = 2; t <= bmax; ++t) {
-                int sum = 0;
-                for (int g = 0; g < ws->n_groups; ++g) {
-                    if (ws->g_b[g] < 0) continue;
-                    int n = 0;
-                    for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) n += ws->c[i].valid ? 1 : 0;
-                    sum += n < t ? n : t;
-                }
-                if (sum > budget) break;
-                B = t;
-            }
-            for (int g = 0; g < ws->n_groups; ++g) {
-                if (ws->g_b[g] < 0) continue;
-                int kept = 0;
+            int active = 0;
+            for (int g = 0; g < ws->n_groups; ++g)
                 for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) {
                     if (!ws->c[i].valid) continue;
-                    if (kept >= B) ws->c[i].valid = 0;
-                    else ++kept;
+                    if (active >= ws->C) ws->c[i].valid = 0;
+                    else ++active;
                 }
-            }
         }
-        int active = 0;
-        for (int g = 0; g < ws->n_groups; ++g)
-            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) {
-                if (!ws->c[i].valid) continue;
-                if (active >= SLHIP_MAX_ACTIVE_CONTACTS) ws->c[i].valid = 0;
-                else ++active;
-            }
     }
 
     /* wake sleeping bodies touched by a moving body */
@@ -1484,7 +1512,7 @@ static void redrop(const slhip_settle_scene* sc, slhip_body* bodies, int me, con
 
 /* optional per-frame trace for the tests: trace[(s * frames + f) * 4 + {0,1,2,3}] = bodies asleep, redrops so far,
    active contacts of the frame's last step, max |v| */
-static unsigned* g_caps = NULL; /* per scene {steps at the contact cap, steps at the pair cap, max contacts offered, steps} */
+static unsigned* g_caps = NULL; /* per scene {steps that dropped contacts, steps that dropped hull pairs, most contacts offered, most hull pairs found} */
 void slref_settle_set_caps(unsigned* c) { g_caps = c; }
 static float* g_trace = NULL;
 void slref_settle_set_trace(float* t) { g_trace = t; }
@@ -1495,8 +1523,8 @@ void slref_settle_set_trace(float* t) { g_trace = t; }
 typedef struct {
     gjk_seed* cache;
     pmanifold* pm;
-    pplane pp[SLHIP_MAX_BODIES];
-    int step, n_hulls;
+    pplane* pp;            /* [bodies of the scene] */
+    int step, n_hulls, nb;
     unsigned cap_hits[4];
 } scene_keep;
 typedef struct { uint32_t n_scenes; scene_keep* k; } settle_state;
@@ -1505,7 +1533,7 @@ void slref_settle_state_free(void* state_)
 {
     settle_state* st = (settle_state*)state_;
     if (!st) return;
-    for (uint32_t s = 0; s < st->n_scenes; ++s) { free(st->k[s].cache); free(st->k[s].pm); }
+    for (uint32_t s = 0; s < st->n_scenes; ++s) { free(st->k[s].cache); free(st->k[s].pm); free(st->k[s].pp); }
     free(st->k);
     free(st);
 }
@@ -1526,12 +1554,16 @@ int slref_settle_ex(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_b
         if (!st->k) { free(st); if (state) *state = NULL; return -1; }
         if (state) *state = st;
     }
-    scene_ws* ws = (scene_ws*)malloc(sizeof(scene_ws));
-    int rc = ws ? 0 : -1;
+    int nb_max = 0;
+    for (uint32_t s = 0; s < n_scenes; ++s) {
+        const int nb = (int)(scenes[s].body_end - scenes[s].body_begin);
+        if (nb > nb_max) nb_max = nb;
+    }
+    scene_ws* ws = nb_max <= SLHIP_MAX_BODIES ? ws_alloc(cap_pairs(prm), cap_contacts(prm), nb_max) : NULL;
+    int rc = ws ? 0 : (nb_max > SLHIP_MAX_BODIES ? -2 : -1);
     for (uint32_t s = 0; s < n_scenes && rc == 0; ++s) {
         const slhip_settle_scene* sc = &scenes[s];
         const int nb = (int)(sc->body_end - sc->body_begin);
-        if (nb > SLHIP_MAX_BODIES) { rc = -2; break; }
         slhip_body* b = bodies + sc->body_begin;
         scene_keep* K = &st->k[s];
         ws->n_hulls = 0;
@@ -1540,16 +1572,19 @@ int slref_settle_ex(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_b
         if (prm->resume == 0u) {
             K->step = 1;
             K->n_hulls = ws->n_hulls;
-            if (ws->n_hulls > 0 && ws->n_hulls <= SLHIP_PAIR_CACHE_MAX_HULLS) {
+            K->nb = nb;
+            K->pp = (pplane*)calloc(nb ? nb : 1, sizeof(pplane));
+            if (!K->pp) { rc = -1; break; }
+            if (ws->n_hulls > 0) {
                 K->cache = (gjk_seed*)calloc((size_t)ws->n_hulls * ws->n_hulls, sizeof(gjk_seed));
                 K->pm = (pmanifold*)calloc((size_t)ws->n_hulls * ws->n_hulls, sizeof(pmanifold));
                 if (!K->cache || !K->pm) { rc = -1; break; }
             }
-        } else if (K->step != (int)prm->resume + 1 || K->n_hulls != ws->n_hulls) { rc = -3; break; }
+        } else if (K->step != (int)prm->resume + 1 || K->n_hulls != ws->n_hulls || K->nb != nb) { rc = -3; break; }
         ws->cache = K->cache;
         ws->pm = K->pm;
         ws->step = K->step;
-        memcpy(ws->pp, K->pp, sizeof(ws->pp));
+        memcpy(ws->pp, K->pp, sizeof(pplane) * nb);
         memcpy(ws->cap_hits, K->cap_hits, sizeof(ws->cap_hits));
         ws->n_groups = 0;
         for (uint32_t f = 0; f < prm->frames; ++f) {
@@ -1578,12 +1613,12 @@ int slref_settle_ex(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_b
                 t[0] = (float)asleep; t[1] = (f ? t[1 - 4] : 0.0f) + (moved ? 1.0f : 0.0f); t[2] = (float)active; t[3] = vmax;
             }
         }
-        if (g_caps) { g_caps[4 * s] = ws->cap_hits[0]; g_caps[4 * s + 1] = ws->cap_hits[1]; g_caps[4 * s + 2] = ws->cap_hits[2]; g_caps[4 * s + 3] = (unsigned)(ws->step - 1); }
+        if (g_caps) { g_caps[4 * s] = ws->cap_hits[0]; g_caps[4 * s + 1] = ws->cap_hits[1]; g_caps[4 * s + 2] = ws->cap_hits[2]; g_caps[4 * s + 3] = ws->cap_hits[3]; }
         K->step = ws->step;
-        memcpy(K->pp, ws->pp, sizeof(ws->pp));
+        memcpy(K->pp, ws->pp, sizeof(pplane) * nb);
         memcpy(K->cap_hits, ws->cap_hits, sizeof(ws->cap_hits));
     }
-    free(ws);
+    ws_free(ws);
     if (!state) slref_settle_state_free(st);
     else if (rc != 0 && prm->resume == 0u) { slref_settle_state_free(st); *state = NULL; }
     return rc;
@@ -1649,10 +1684,10 @@ int slref_overlap_any(const slhip_settle_scene* scenes, uint32_t n_scenes, const
 int slref_debug_contacts(const slhip_settle_scene* sc, const slhip_body* bodies_all, const slhip_hull* hulls,
                          const float* hull_verts, const slhip_settle_params* prm, float* out, int max_rows)
 {
-    scene_ws* ws = (scene_ws*)malloc(sizeof(scene_ws));
-    ws->cache = NULL;
     const slhip_body* bodies = bodies_all + sc->body_begin;
     const int nb = (int)(sc->body_end - sc->body_begin);
+    scene_ws* ws = ws_alloc(1, 1, nb);
+    if (!ws) return 0;
     for (int i = 0; i < nb; ++i) load_body(&bodies[i], &ws->wb[i]);
     int rows = 0;
     for (int i = 0; i < nb; ++i)
@@ -1684,6 +1719,6 @@ int slref_debug_contacts(const slhip_settle_scene* sc, const slhip_body* bodies_
                 o[9] = pa.x; o[10] = pa.y; o[11] = sc->plane_z;
             }
         }
-    free(ws);
+    ws_free(ws);
     return rows;
 }

@@ -35,13 +35,14 @@ PARAMS_DTYPE = np.dtype([
     ("plane_mu_s", np.float32), ("plane_mu_d", np.float32), ("plane_restitution", np.float32),
     ("redrop_z", np.float32), ("stuck_separation", np.float32), ("stuck_frames", np.int32), ("tabletop", np.uint32),
     ("max_bodies_per_scene", np.uint32), ("max_hull_verts_per_scene", np.uint32), ("max_hulls_per_scene", np.uint32),
+    ("max_hull_pairs_per_scene", np.uint32), ("max_contacts_per_scene", np.uint32),
     ("resume", np.uint32),
 ])
-assert PARAMS_DTYPE.itemsize == 104
+assert PARAMS_DTYPE.itemsize == 112
 
 BODY_STATIC = 1
 BODY_ASLEEP = 2
-MAX_BODIES = 64
+MAX_BODIES = 256
 
 
 def default_params(tabletop=True, dt=None, frames=None, substeps=None):

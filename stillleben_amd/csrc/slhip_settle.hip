@@ -21,11 +21,10 @@ namespace {
 
 static_assert(sizeof(slhip_body) == 288, "slhip_body layout");
 static_assert(sizeof(slhip_hull) == 64, "slhip_hull layout");
-static_assert(sizeof(slhip_settle_params) == 104, "slhip_settle_params layout");
+static_assert(sizeof(slhip_settle_params) == 112, "slhip_settle_params layout");
 
 constexpr int kMaxContactsPerHP = 4;
-constexpr int kMaxGroups = SLHIP_MAX_HULL_PAIRS + SLHIP_MAX_BODIES;
-constexpr int kMaxActive = SLHIP_MAX_ACTIVE_CONTACTS;
+constexpr int kLdsContacts = SLHIP_LDS_CONTACTS;   // the solver's LDS-resident contacts per scene; the rest of the list is swept from global memory
 constexpr float kInf = 3.0e38f;
 constexpr float kDepthWeight = 30.0f;
 
@@ -1193,7 +1192,16 @@ __device__ __forceinline__ void apply_mine(BodyRegs& m, v3 r, v3 J)
     }
 }
 
-__device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, int side, WBody* wbs, float inv_dt,
+// The step's contact list: entries [0, kLdsContacts) live in LDS (`lds`), the rest are read from (and their impulses written to)
+// the scene's list in global memory (`glb`, indexed like the list): no cap but the capacity of the scratch.
+struct ContactList {
+    Contact* lds;
+    Contact* glb;
+    __device__ __forceinline__ Contact load(int i) const { return i < kLdsContacts ? lds[i] : glb[i]; }
+    __device__ __forceinline__ Contact* at(int i) const { return i < kLdsContacts ? lds + i : glb + i; }
+};
+
+__device__ void solve_group(const ContactList ac, int begin, int end, int ia, int ib, int side, WBody* wbs, float inv_dt,
                             bool biased, float plane_mu_s, float plane_mu_d)
 {
     if (begin >= end) return;
@@ -1216,10 +1224,24 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, int
     // first two contacts -- against their share of the patch's accumulated normal impulse.
     float nsum = 0.0f;
     int p0 = begin;
+    // what the friction rows need of the patch's (at most two) anchors -- its first two contacts -- is kept from the moment they pass
+    // through the normal rows: no second fetch (beyond the LDS-resident part that would be an exposed round trip to the L2 per patch)
+    v3 a0r = V(0, 0, 0), a0n = V(0, 0, 0), a1r = V(0, 0, 0), a1n = V(0, 0, 0);
+    float a0til = 1.0f, a0kt1 = 0.0f, a0kt2 = 0.0f, a0lt1 = 0.0f, a0lt2 = 0.0f;
+    float a1til = 1.0f, a1kt1 = 0.0f, a1kt2 = 0.0f, a1lt1 = 0.0f, a1lt2 = 0.0f;
+    // (the next contact is fetched while this one's row runs: beyond the LDS-resident part it comes from global memory)
+    Contact nxt = ac.load(begin);
     for (int ci = begin; ci < end; ++ci) {
-        const Contact c = ac[ci];
-        if (c.til < 0.0f) { nsum = 0.0f; p0 = ci; }
+        const Contact c = nxt;
+        const bool more = ci + 1 < end;
+        if (more) nxt = ac.load(ci + 1);
         const v3 r = side ? c.rb : c.ra;
+        if (c.til < 0.0f) {
+            nsum = 0.0f; p0 = ci;
+            a0r = r; a0n = c.n; a0til = c.til; a0kt1 = c.kt1; a0kt2 = c.kt2; a0lt1 = c.lt1; a0lt2 = c.lt2;
+        } else if (ci == p0 + 1) {
+            a1r = r; a1n = c.n; a1til = c.til; a1kt1 = c.kt1; a1kt2 = c.kt2; a1lt1 = c.lt1; a1lt2 = c.lt2;
+        }
         v3 pv = add(M.v, cross(M.w, r));
         v3 d = sub(pv, pair_swap(pv));              // side 0: a - b, side 1: b - a
         const float vn = sgn * dot(d, c.n);
@@ -1229,21 +1251,22 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, int
         if (ln < 0.0f) ln = 0.0f;
         dl = ln - c.ln;
         apply_mine(M, r, scale(c.n, sgn * dl));
-        if (side == 0) ac[ci].ln = ln;
+        if (side == 0) ac.at(ci)->ln = ln;
         nsum = nsum + ln;
-        const bool last = ci + 1 == end || ac[ci + 1].til < 0.0f;
+        const bool last = !more || nxt.til < 0.0f;
         if (!last) continue;
         const int anchors = ci - p0 >= 1 ? 2 : 1;
         const float share = anchors == 2 ? 0.5f * nsum : nsum;
         for (int ai = 0; ai < anchors; ++ai) {
-            const Contact q = ac[p0 + ai];
-            const v3 rq = side ? q.rb : q.ra;
+            const v3 rq = ai ? a1r : a0r, qn = ai ? a1n : a0n;
+            const float qtil = ai ? a1til : a0til, qkt1 = ai ? a1kt1 : a0kt1, qkt2 = ai ? a1kt2 : a0kt2;
+            const float qlt1 = ai ? a1lt1 : a0lt1, qlt2 = ai ? a1lt2 : a0lt2;
             pv = add(M.v, cross(M.w, rq));
             d = sub(pv, pair_swap(pv));
             v3 t1, t2;
-            tangents_cached(q.n, fabsf(q.til), &t1, &t2);
-            float l1 = q.lt1 - (sgn * dot(d, t1)) * q.kt1;
-            float l2 = q.lt2 - (sgn * dot(d, t2)) * q.kt2;
+            tangents_cached(qn, fabsf(qtil), &t1, &t2);
+            float l1 = qlt1 - (sgn * dot(d, t1)) * qkt1;
+            float l2 = qlt2 - (sgn * dot(d, t2)) * qkt2;
             const float mag2 = fmaf(l2, l2, l1 * l1);
             const float lim_s = mu_s * share;
             if (mag2 > lim_s * lim_s) {
@@ -1251,9 +1274,9 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, int
                 const float k = (mu_d * share) / mag;
                 l1 *= k; l2 *= k;
             }
-            const float d1 = l1 - q.lt1, d2 = l2 - q.lt2;
+            const float d1 = l1 - qlt1, d2 = l2 - qlt2;
             apply_mine(M, rq, madd(scale(t1, sgn * d1), t2, sgn * d2));
-            if (side == 0) { ac[p0 + ai].lt1 = l1; ac[p0 + ai].lt2 = l2; }
+            if (side == 0) { Contact* w = ac.at(p0 + ai); w->lt1 = l1; w->lt2 = l2; }
         }
     }
     if (M.dynamic) { wbs[mine].v = M.v; wbs[mine].w = M.w; }
@@ -1261,7 +1284,7 @@ __device__ void solve_group(Contact* ac, int begin, int end, int ia, int ib, int
 
 // Warm start of ONE group by its lane pair (oracle: the loop before the first sweep): every contact's carried normal impulse is
 // applied to the two bodies, contacts in order; same lane roles and sign conventions as solve_group.
-__device__ void warm_group(const Contact* ac, int begin, int end, int ia, int ib, int side, WBody* wbs)
+__device__ void warm_group(const ContactList ac, int begin, int end, int ia, int ib, int side, WBody* wbs)
 {
     if (begin >= end) return;
     const int mine = side ? ib : ia;
@@ -1271,7 +1294,7 @@ __device__ void warm_group(const Contact* ac, int begin, int end, int ia, int ib
     if (!M.dynamic) return;
     const float sgn = side ? -1.0f : 1.0f;
     for (int ci = begin; ci < end; ++ci) {
-        const Contact c = ac[ci];
+        const Contact c = ac.load(ci);
         const v3 r = side ? c.rb : c.ra;
         apply_mine(M, r, scale(c.n, sgn * c.ln));
     }
@@ -1428,24 +1451,26 @@ __device__ __forceinline__ int wave_excl_scan(int v, int& total)
     return x - v;
 }
 
-// candidate hull pair, 32 bits: body a [0,6) | body b [6,12) | hull of a [12,22) | hull of b [22,32)
-// (hull numbers are local to their body: at most 1024 hulls per body)
-constexpr int kMaxHullsPerBody = 1024;
-__device__ __forceinline__ unsigned hp_pack(int ba, int bb, int ha, int hb)
+// candidate hull pair, 64 bits: low word = body a | body b << 16 (the pair group's key), high word = hull of a | hull of b << 16
+// (hull numbers are local to their body)
+constexpr int kMaxHullsPerBody = 65535;
+typedef unsigned long long HullPair;
+__device__ __forceinline__ HullPair hp_pack(int ba, int bb, int ha, int hb)
 {
-    return (unsigned)ba | ((unsigned)bb << 6) | ((unsigned)ha << 12) | ((unsigned)hb << 22);
+    return (HullPair)((unsigned)ba | ((unsigned)bb << 16)) | ((HullPair)((unsigned)ha | ((unsigned)hb << 16)) << 32);
 }
-__device__ __forceinline__ int hp_ba(unsigned e) { return (int)(e & 63u); }
-__device__ __forceinline__ int hp_bb(unsigned e) { return (int)((e >> 6) & 63u); }
-__device__ __forceinline__ int hp_ha(unsigned e) { return (int)((e >> 12) & 1023u); }
-__device__ __forceinline__ int hp_hb(unsigned e) { return (int)(e >> 22); }
+__device__ __forceinline__ int hp_ba(HullPair e) { return (int)((unsigned)e & 0xffffu); }
+__device__ __forceinline__ int hp_bb(HullPair e) { return (int)((unsigned)e >> 16); }
+__device__ __forceinline__ int hp_ha(HullPair e) { return (int)((unsigned)(e >> 32) & 0xffffu); }
+__device__ __forceinline__ int hp_hb(HullPair e) { return (int)((unsigned)(e >> 48)); }
+__device__ __forceinline__ unsigned hp_key(HullPair e) { return (unsigned)e; }      // the body pair
 
-// solver group = all contacts between one body pair (b = 0xff: body a against the plane);
-// [begin, end) is its range in the contact list (<= SLHIP_MAX_ACTIVE_CONTACTS, fits a byte)
-struct Group { unsigned char a, b, begin, end, color; };
-constexpr int kNoBody = 0xff;
-static_assert(sizeof(Group) == 5, "Group layout");
-static_assert(SLHIP_MAX_ACTIVE_CONTACTS < 256 && SLHIP_MAX_BODIES <= 64, "byte-sized group fields");
+// solver group = all contacts between one body pair (b = kNoBody: body a against the plane);
+// [begin, end) is its range in the step's contact list
+struct Group { unsigned short a, b, begin, end, color; };
+constexpr int kNoBody = 0xffff;
+static_assert(sizeof(Group) == 10, "Group layout");
+static_assert(SLHIP_MAX_BODIES < kNoBody, "16-bit body fields");
 
 // boolean overlap (scene.cpp:355-385): one lane per body
 __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __restrict__ scenes,
@@ -1453,7 +1478,7 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
                                                 const slhip_hull* __restrict__ hulls,
                                                 const float* __restrict__ hull_verts, uint8_t* __restrict__ flags)
 {
-    __shared__ WBody wb[SLHIP_MAX_BODIES];
+    __shared__ WBody wb[SLHIP_MAX_BODIES];   // (a query, not the hot loop: the static worst case)
     const slhip_settle_scene sc = scenes[blockIdx.x];
     const slhip_body* b = bodies_all + sc.body_begin;
     const int nb = (int)(sc.body_end - sc.body_begin);
@@ -1506,38 +1531,47 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
 
 }  // namespace
 
-// entries of one scene's pair cache: (hulls per scene)^2, from the hint (0 or beyond the cap: the cap)
-static uint32_t pair_cache_stride(const slhip_settle_params* params)
+// Capacities and layout of the scratch, from the hints of slhip_settle_params (the same function sizes and carves).
+struct SettleDims {
+    int nb_cap, lh_cap, p_cap, c_cap;
+    unsigned cache_stride;   // pair cache entries per scene
+    int cache_hashed;
+};
+static SettleDims settle_dims(const slhip_settle_params* params)
 {
-    uint32_t h = params ? params->max_hulls_per_scene : 0u;
-    if (h == 0u || h > SLHIP_PAIR_CACHE_MAX_HULLS) h = SLHIP_PAIR_CACHE_MAX_HULLS;
-    return h * h;
+    SettleDims D;
+    D.nb_cap = params && params->max_bodies_per_scene ? (int)params->max_bodies_per_scene : SLHIP_MAX_BODIES;
+    D.lh_cap = params && params->max_hulls_per_scene ? (int)params->max_hulls_per_scene : 1024;
+    D.p_cap = params && params->max_hull_pairs_per_scene ? (int)params->max_hull_pairs_per_scene : SLHIP_DEFAULT_HULL_PAIRS;
+    D.c_cap = params && params->max_contacts_per_scene ? (int)params->max_contacts_per_scene : SLHIP_DEFAULT_CONTACTS;
+    if (D.p_cap > 65535) D.p_cap = 65535;
+    if (D.c_cap > 65535) D.c_cap = 65535;
+    // pair cache: dense [hulls]^2 when the hint says the scenes are small, else hashed (8 slots per list entry, a power of two)
+    const unsigned h = params ? params->max_hulls_per_scene : 0u;
+    if (h != 0u && h <= SLHIP_PAIR_CACHE_DENSE_HULLS) { D.cache_stride = h * h; D.cache_hashed = 0; }
+    else {
+        unsigned t = 1024u;                 // per table: four slots per list entry, a power of two; two tables (step parity)
+        while (t < 4u * (unsigned)D.p_cap) t <<= 1;
+        D.cache_stride = 2u * t; D.cache_hashed = 1;
+    }
+    return D;
 }
 
-// per-scene scratch: [n_scenes x ProfScratch][n_scenes x SLHIP_MAX_BODIES x DriveAcc][n_scenes x pair cache]
-static uint64_t settle_fixed_bytes(uint32_t n_scenes)
+// [n_scenes x ProfScratch][n_scenes x nb_cap x DriveAcc][n_scenes x pair cache][state of the lockstep pipeline (slhip_settle_wide.inc)]
+static uint64_t settle_fixed_bytes(uint32_t n_scenes, const SettleDims& D)
 {
-    const uint64_t b = (uint64_t)n_scenes * (sizeof(ProfScratch) + SLHIP_MAX_BODIES * sizeof(DriveAcc));
+    const uint64_t b = (uint64_t)n_scenes * (sizeof(ProfScratch) + (uint64_t)D.nb_cap * sizeof(DriveAcc));
     return (b + 255u) & ~(uint64_t)255u;
 }
-static int hint_nb_cap(const slhip_settle_params* params)
+static uint64_t settle_cache_bytes(uint32_t n_scenes, const SettleDims& D)
 {
-    return params && params->max_bodies_per_scene ? (int)params->max_bodies_per_scene : SLHIP_MAX_BODIES;
-}
-static int hint_lh_cap(const slhip_settle_params* params)
-{
-    return params && params->max_hulls_per_scene ? (int)params->max_hulls_per_scene : 1024;
-}
-static uint64_t settle_cache_bytes(uint32_t n_scenes, const slhip_settle_params* params)
-{
-    const uint64_t b = (uint64_t)n_scenes * pair_cache_stride(params) * sizeof(GjkSeed);
+    const uint64_t b = (uint64_t)n_scenes * D.cache_stride * sizeof(int4);
     return (b + 255u) & ~(uint64_t)255u;
 }
-// [fixed][pair cache][state of the lockstep pipeline (slhip_settle_wide.inc)]
 static uint64_t settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params)
 {
-    return settle_fixed_bytes(n_scenes) + settle_cache_bytes(n_scenes, params) +
-           wide_bytes(n_scenes, hint_nb_cap(params), hint_lh_cap(params)) + 256;
+    const SettleDims D = settle_dims(params);
+    return settle_fixed_bytes(n_scenes, D) + settle_cache_bytes(n_scenes, D) + wide_bytes(n_scenes, D.nb_cap, D.lh_cap, D.p_cap, D.c_cap) + 256;
 }
 
 // Optional live timing of the lockstep kernels (bench.py's roofline leg): HIP events on the launch's stream around every
@@ -1605,42 +1639,58 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         slhip::set_error("slhip_settle: scratch too small");
         return -1;
     }
-    int nb_cap = params->max_bodies_per_scene ? (int)params->max_bodies_per_scene : SLHIP_MAX_BODIES;
+    const SettleDims D = settle_dims(params);
+    const int nb_cap = D.nb_cap;
     if (nb_cap > SLHIP_MAX_BODIES) {
         slhip::set_error("slhip_settle: at most %d bodies per scene", SLHIP_MAX_BODIES);
         return -1;
     }
     {
-        const int lhc = hint_lh_cap(params);
         if (n_scenes > 65535u) {
             slhip::set_error("slhip_settle: at most 65535 scenes per launch");
             return -1;
         }
         ProfScratch* prof_w = reinterpret_cast<ProfScratch*>(d_scratch);
         DriveAcc* drive_w = reinterpret_cast<DriveAcc*>(prof_w + n_scenes);
-        char* base = reinterpret_cast<char*>(d_scratch) + settle_fixed_bytes(n_scenes);
-        GjkSeed* cache_w = reinterpret_cast<GjkSeed*>(base);
-        const WideBufs W = wide_carve(base + settle_cache_bytes(n_scenes, params), n_scenes, nb_cap, lhc);
-        const BeginLds BL = begin_layout(nb_cap, lhc);
-        const FinishLds FL = finish_layout(nb_cap);
-        const SolveLds SL = solve_layout(nb_cap);
+        char* base = reinterpret_cast<char*>(d_scratch) + settle_fixed_bytes(n_scenes, D);
+        PairCache pc;
+        pc.base = reinterpret_cast<int4*>(base);
+        pc.stride = D.cache_stride;
+        pc.hashed = D.cache_hashed;
+        const WideBufs W = wide_carve(base + settle_cache_bytes(n_scenes, D), n_scenes, nb_cap, D.lh_cap, D.p_cap, D.c_cap);
+        if (((uint64_t)n_scenes << W.pair_bits) > (1ull << 32)) {
+            slhip::set_error("slhip_settle: n_scenes x max_hull_pairs_per_scene exceeds the 32-bit work list entries");
+            return -1;
+        }
+        const BeginLds BL = begin_layout(nb_cap, D.lh_cap);
+        const FinishLds FL = finish_layout(nb_cap, W.g_cap);
+        const SolveLds SL = solve_layout(nb_cap, W.g_cap);
+        if (BL.total > 160 * 1024 || FL.total > 160 * 1024 || SL.total > 160 * 1024) {
+            slhip::set_error("slhip_settle: scenes of %d bodies / %d hulls do not fit the kernels' LDS", nb_cap, D.lh_cap);
+            return -1;
+        }
         // Scenes per solver wave.  Two (cost-sorted neighbours side by side, 32 lanes each, same bits) cost a quarter fewer VALU
         // instructions per scene and won in round 2, when the render stream was the pipeline's critical path and took the issue
         // slots the solver left (7 730 against 7 370 scenes/s).  Since the end of round 3 the critical path is the settle stream
-        // itself, and what counts is how long its chain of launches takes next to the render: ONE scene per wave (20 KB of LDS, up
-        // to eight solver waves per CU, half the dependent rows per wave) settles a batch in 0.93 instead of 1.07 s alone and in
+        // itself, and what counts is how long its chain of launches takes next to the render: ONE scene per wave (up to eight
+        // solver waves per CU, half the dependent rows per wave) settles a batch in 0.93 instead of 1.07 s alone and in
         // 1.47 instead of 1.61 s beside the render: 9 511 -> 9 789 scenes/s on one box.  SLHIP_SOLVE_SPW=2: two scenes per wave.
         int spw = 1;
-        if (const char* e = getenv("SLHIP_SOLVE_SPW")) spw = atoi(e) == 2 ? 2 : 1;
+        if (const char* e = getenv("SLHIP_SOLVE_SPW")) { spw = atoi(e); if (spw != 2 && spw != 4) spw = 1; }
+        if (spw * SL.total > 160 * 1024) spw = 1;
+        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_begin), hipFuncAttributeMaxDynamicSharedMemorySize, BL.total));
+        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_finish), hipFuncAttributeMaxDynamicSharedMemorySize, FL.total));
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SL.total));
-        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL.total));
-        const unsigned cstride = pair_cache_stride(params);
+        if (2 * SL.total <= 160 * 1024)
+            SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL.total));
+        if (4 * SL.total <= 160 * 1024)
+            SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SL.total));
         // a resumed call finds everything the prologue would set up -- and the contact state it would clear -- in the scratch
-        if (params->resume == 0u) k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, cache_w, cstride);
+        if (params->resume == 0u) k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, pc);
         // the compacted narrowphase passes walk their work lists with a grid stride: enough waves for a step's typical list
         // (a scene has ~40 candidate pairs), never more than the worst case needs
-        const unsigned list_stride = n_scenes * (unsigned)SLHIP_MAX_HULL_PAIRS;
-        const unsigned work_grid = n_scenes < 16u ? n_scenes * (SLHIP_MAX_HULL_PAIRS / 64) : n_scenes;
+        const unsigned list_stride = n_scenes * (unsigned)D.p_cap;
+        const unsigned work_grid = n_scenes < 16u ? n_scenes * 8u : n_scenes;
         uint32_t step = params->resume;
         for (uint32_t f = 0; f < params->frames; ++f)
             for (uint32_t sub = 0; sub < params->substeps; ++sub, ++step) {
@@ -1658,14 +1708,17 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                 if (timed) (void)hipEventRecord(ev[0], stream);
                 k_w_begin<<<n_scenes, 64, BL.total, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, W, BL, drive_w, step + 1u);
                 if (timed) (void)hipEventRecord(ev[1], stream);
-                k_w_gjk_first<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride, step + 1u, n_scenes);
-                k_w_gjk_rest<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, cache_w, cstride, list_stride, step + 1u, n_scenes);
+                k_w_gjk_first<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, pc, list_stride, step + 1u, n_scenes);
+                k_w_gjk_rest<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, pc, list_stride, step + 1u, n_scenes);
                 if (timed) (void)hipEventRecord(ev[2], stream);
                 k_w_gjk_tilt<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, list_stride);
                 if (timed) (void)hipEventRecord(ev[3], stream);
-                k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL, step + 1u);
+                k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL, pc, step + 1u);
                 if (timed) (void)hipEventRecord(ev[4], stream);
-                if (spw == 2)
+                if (spw == 4)
+                    k_w_solve<4><<<(n_scenes + 3) / 4, 64, 4 * SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
+                                                                                     sub + 1 == params->substeps ? 1 : 0, n_scenes);
+                else if (spw == 2)
                     k_w_solve<2><<<(n_scenes + 1) / 2, 64, 2 * SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
                                                                                      sub + 1 == params->substeps ? 1 : 0, n_scenes);
                 else
@@ -1682,26 +1735,33 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
     }
 }
 
-// Cap saturation of the last slhip_settle call on this scratch: the number of (scene, step) pairs in which the pair groups offered
-// more contacts than SLHIP_MAX_ACTIVE_CONTACTS left room for (the fair cut of k_w_finish applied), and in which the broadphase found
-// more than SLHIP_MAX_HULL_PAIRS hull pairs (the rest were dropped).  The reference's PhysX has neither cap (scene.cpp:738-739).
+// What the capacities cost since the last cold start on this scratch (include/slhip.h): spills beyond the solver's LDS-resident
+// contacts (nothing lost), contacts / hull pairs DROPPED beyond the capacities the caller sized (the contract is zero), the
+// scenes concerned, the most a step offered.  The reference's PhysX has no caps (scene.cpp:738-739).
 extern "C" int slhip_settle_caps(const void* d_scratch, uint32_t n_scenes, const slhip_settle_params* params,
-                                 uint64_t* contact_cap_steps, uint64_t* pair_cap_steps, void* stream_)
+                                 uint64_t counts[7], void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!d_scratch || !params || !contact_cap_steps || !pair_cap_steps) {
+    if (!d_scratch || !params || !counts) {
         slhip::set_error("slhip_settle_caps: null argument");
         return -1;
     }
-    *contact_cap_steps = 0; *pair_cap_steps = 0;
+    for (int k = 0; k < 7; ++k) counts[k] = 0;
     if (n_scenes == 0) return 0;
-    const int nb_cap = hint_nb_cap(params);
-    const char* base = reinterpret_cast<const char*>(d_scratch) + settle_fixed_bytes(n_scenes) + settle_cache_bytes(n_scenes, params);
-    const WideBufs W = wide_carve(const_cast<char*>(base), n_scenes, nb_cap, hint_lh_cap(params));
-    std::vector<unsigned> h((size_t)n_scenes * 2);
+    const SettleDims D = settle_dims(params);
+    const char* base = reinterpret_cast<const char*>(d_scratch) + settle_fixed_bytes(n_scenes, D) + settle_cache_bytes(n_scenes, D);
+    const WideBufs W = wide_carve(const_cast<char*>(base), n_scenes, D.nb_cap, D.lh_cap, D.p_cap, D.c_cap);
+    std::vector<unsigned> h((size_t)n_scenes * kCapWords);
     SLHIP_CHECK(hipMemcpyAsync(h.data(), W.caps, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     SLHIP_CHECK(hipStreamSynchronize(stream));
-    for (uint32_t i = 0; i < n_scenes; ++i) { *contact_cap_steps += h[2 * i]; *pair_cap_steps += h[2 * i + 1]; }
+    for (uint32_t i = 0; i < n_scenes; ++i) {
+        const unsigned* c = &h[(size_t)kCapWords * i];
+        counts[0] += c[kCapSpillSteps]; counts[1] += c[kCapContactDropSteps]; counts[2] += c[kCapPairDropSteps];
+        if (c[kCapContactDropSteps] || c[kCapPairDropSteps]) ++counts[3];
+        if (c[kCapSpillSteps]) ++counts[4];
+        if (c[kCapMaxContacts] > counts[5]) counts[5] = c[kCapMaxContacts];
+        if (c[kCapMaxPairs] > counts[6]) counts[6] = c[kCapMaxPairs];
+    }
     return 0;
 }
 

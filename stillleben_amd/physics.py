@@ -48,9 +48,30 @@ class SettleEngine:
         return cur
 
     def run(self, srec, bodies, params):
-        """Runs slhip_settle on numpy records; returns the updated bodies (numpy)."""
-        d_bodies = self.run_device(srec, bodies, params)
-        self.check_status(len(srec))
+        """Runs slhip_settle on numpy records; returns the updated bodies (numpy).  The reference has no caps on a scene's
+        contacts or hull pairs (PhysX allocates as it goes, scene.cpp:738-739): when a step of some scene offered more than the
+        scratch's list capacities held (slhip_settle_caps counts what was dropped), the batch is settled again from the same
+        start with capacities that hold what was seen -- the result never depends on a capacity."""
+        prm = np.ascontiguousarray(params).copy()
+        for _ in range(8):
+            d_bodies = self.run_device(srec, bodies, prm)
+            self.check_status(len(srec))
+            caps = self.caps(len(srec))
+            self.last_params = prm.copy()      # (with the capacities this run used)
+            if caps["scenes_dropped"] == 0:
+                break
+            if int(prm["resume"].reshape(-1)[0]) != 0:
+                raise RuntimeError("slhip_settle: a resumed call ran out of list capacity (%r): size the scene's scratch larger" % (caps,))
+            cur_p = int(prm["max_hull_pairs_per_scene"].reshape(-1)[0]) or _abi.DEFAULT_HULL_PAIRS
+            cur_c = int(prm["max_contacts_per_scene"].reshape(-1)[0]) or _abi.DEFAULT_CONTACTS
+            if caps["pair_drop_steps"]:
+                prm["max_hull_pairs_per_scene"] = min(65535, max(2 * cur_p, caps["max_hull_pairs"] * 5 // 4))
+            if caps["contact_drop_steps"] or caps["pair_drop_steps"]:
+                prm["max_contacts_per_scene"] = min(65535, max(2 * cur_c if caps["contact_drop_steps"] else cur_c, caps["max_contacts"] * 5 // 4))
+            if cur_p >= 65535 and cur_c >= 65535:
+                raise RuntimeError("slhip_settle: a scene offers more hull pairs / contacts per step than the 16-bit lists hold (%r)" % (caps,))
+        else:
+            raise RuntimeError("slhip_settle: list capacities still too small after eight attempts (%r)" % (caps,))
         out = np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy()
         return out
 
@@ -79,22 +100,30 @@ class SettleEngine:
                                       C.c_void_p(stream))
         return np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy(), status
 
-    def caps(self, n_scenes, stream=None, prm=None):
-        """(contact-cap steps, pair-cap steps) of the last launch on `stream` (slhip_settle_caps)."""
+    def caps(self, n_scenes, stream=None, prm=None, scratch=None):
+        """What the list capacities cost since the last cold start on the stream's scratch (slhip_settle_caps), as a dict:
+        spill_steps (scene-steps whose contacts went beyond the solver's LDS-resident part: swept from global memory, nothing
+        lost), contact_drop_steps / pair_drop_steps (scene-steps that DROPPED contacts / hull pairs beyond the capacities:
+        the contract is zero), scenes_dropped, scenes_spilled, max_contacts, max_hull_pairs (the most a step offered)."""
         eng = self.eng
         if stream is None:
             stream = torch.cuda.current_stream(eng.device).cuda_stream
-        a, b = C.c_uint64(), C.c_uint64()
+        out = (C.c_uint64 * 7)()
         if prm is None:
             prm = self._keep[stream][1]
+        if scratch is None:
+            scratch = self._scratch[stream]
         with torch.cuda.device(eng.device):
-            st = eng.L.slhip_settle_caps(_abi_ptr(self._scratch[stream]), n_scenes, C.c_void_p(prm.ctypes.data), C.byref(a), C.byref(b),
-                                         C.c_void_p(stream))
+            st = eng.L.slhip_settle_caps(_abi_ptr(scratch), n_scenes, C.c_void_p(prm.ctypes.data), C.byref(out), C.c_void_p(stream))
         _abi.check(st, "slhip_settle_caps")
-        return int(a.value), int(b.value)
+        keys = ("spill_steps", "contact_drop_steps", "pair_drop_steps", "scenes_dropped", "scenes_spilled", "max_contacts", "max_hull_pairs")
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def run_with_caps(self, srec, bodies, params):
-        out = self.run(srec, bodies, params)
+        """ONE slhip_settle with exactly the given capacities (no growth): (bodies, caps)."""
+        d_bodies = self.run_device(srec, bodies, params)
+        self.check_status(len(srec))
+        out = np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy()
         return out, self.caps(len(srec))
 
     def scratch_bytes(self, n_scenes, prm):
@@ -311,6 +340,8 @@ def step_scene(scene, plane, **prm_kw):
     srec, bodies = SB.build_settle_batch([scene], se.pool, [plane])
     hulls = se.pool.arrays()[0]
     prm = SB.sizing_hints(SB.default_params(**prm_kw), srec, bodies, hulls)
+    # one scene's lists cost a few MB at most: sized so that no step of any realistic scene runs out (checked below)
+    prm["max_hull_pairs_per_scene"], prm["max_contacts_per_scene"] = 16384, 16384
     sig = _signature(scene, srec, bodies, prm)
     st = scene._phys_state
     resume = st is not None and st.sig == sig and len(st.bodies) == len(bodies)
@@ -347,6 +378,10 @@ def step_scene(scene, plane, **prm_kw):
     d_bodies = se.run_device(srec, None, prm, d_bodies=se.eng.upload_records(bodies), scratch=st.scratch)
     if not resume:
         se.check_status(1, scratch=st.scratch)
+    caps = se.caps(1, prm=np.ascontiguousarray(prm), scratch=st.scratch)
+    if caps["scenes_dropped"]:
+        scene._phys_state = None
+        raise RuntimeError("slhip_settle: the scene offers more hull pairs / contacts per step than its scratch holds (%r)" % (caps,))
     out = np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy()
     SB.write_back([scene], out)
     st.steps += int(prm["frames"]) * int(prm["substeps"])

@@ -124,8 +124,8 @@ class SceneBatch:
                  ambient=(0.05, 0.05, 0.05), manual_exposure=-1.0, scene_id_base=0):
         from .scene import Scene
 
-        if not 1 <= n_objects <= SB.MAX_BODIES:
-            raise ValueError("n_objects must be in [1, %d]" % SB.MAX_BODIES)
+        if not 1 <= n_objects <= 64:      # SLHIP_SYNTH_MAX_OBJECTS: the synthesis kernels map an object to a lane of one wave
+            raise ValueError("n_objects must be in [1, 64]")
         self.table, self.eng, self.se = table, table.eng, table.se
         self.n_scenes, self.n_objects = int(n_scenes), int(n_objects)
         self.resolution = tuple(resolution)
@@ -238,8 +238,7 @@ class SceneBatch:
         self.se.check_status(self.n_scenes, self._settle_stream)
 
     def settle_caps(self):
-        """(contact-cap steps, pair-cap steps) of the last settle() -- (scene, step) pairs that hit SLHIP_MAX_ACTIVE_CONTACTS /
-        SLHIP_MAX_HULL_PAIRS (slhip_settle_caps; synchronises the settle stream)."""
+        """What the list capacities cost the last settle() (slhip_settle_caps, SettleEngine.caps; synchronises the settle stream)."""
         return self.se.caps(self.n_scenes, self._settle_stream, self._settle_keep)
 
     def place(self):

@@ -1,5 +1,5 @@
 """Edge cases of the hot path on the GPU, each compared with the oracle: empty and ragged inputs,
-odd viewports, the documented caps (64 bodies, 512 candidate hull pairs, 255 solver contacts), scenes
+odd viewports, large heaps (the lists of a scene's hull pairs and contacts have no cap but the caller's capacities), scenes
 too large for the 8-per-CU LDS share, and the loud error paths of the C-ABI."""
 import ctypes as C
 
@@ -66,42 +66,65 @@ def test_empty_and_single_body_scenes(sl, oracle):
     assert len(gpu) == 3
 
 
-def test_maximum_body_count_and_contact_caps(sl, oracle):
-    """64 bodies (SLHIP_MAX_BODIES) dropped as one heap: the candidate hull-pair list and the solver
-    contact list run into their caps (512 / 255); the drop rules are part of the contract and the
-    GPU must apply them exactly like the oracle.  The LDS share of such a scene exceeds 20 KB, so
-    fewer than 8 scenes are resident per CU."""
+def test_large_heaps(sl, oracle):
+    """64 bodies dropped as one heap (round 3's body cap; its candidate hull pairs and contacts ran into the old 512 / 255
+    caps), and 100 bodies (the reference has no limit on the objects of a scene, scene.cpp:278-288): every contact is
+    taken, the GPU agrees with the oracle bit for bit."""
+    from stillleben_amd import physics
+
     cube = scaled(sl, S.CUBE, 0.12)
     bunny = scaled(sl, S.BUNNY, 0.15)           # 121 hulls each
     big = heap(sl, 11, 64, cube, bunny)
     small = heap(sl, 12, 3, cube)
     gpu, ref = run_both(oracle, [big, small], frames=12)
     assert_bodies_equal(gpu, ref)
+    caps = physics.settle_engine().caps(2)
+    assert caps["contact_drop_steps"] == 0 and caps["pair_drop_steps"] == 0
+    hundred = heap(sl, 13, 100, cube)
+    gpu, ref = run_both(oracle, [hundred, small], frames=25)
+    assert_bodies_equal(gpu, ref)
+    caps = physics.settle_engine().caps(2)
+    assert caps["contact_drop_steps"] == 0 and caps["pair_drop_steps"] == 0
 
 
-def test_more_than_64_bodies_is_refused(sl):
+def test_hundred_bodies_settle(sl):
+    """A 100-body scene settles through the public API: nothing falls through the table, (almost) everything comes to rest."""
+    cube = scaled(sl, S.CUBE, 0.1)
+    scene = sl.Scene((320, 240), seed=77)
+    for _ in range(100):
+        scene.add_object(sl.Object(cube))
+    scene.simulate_tabletop_scene()
+    z = np.array([float(o.pose()[2, 3]) for o in scene.objects])
+    v = np.array([float(o.linear_velocity.norm()) for o in scene.objects])
+    assert (z > 0.04).all()
+    assert (v < 0.05).mean() > 0.9
+
+
+def test_more_than_max_bodies_is_refused(sl):
     from stillleben_amd import physics
 
     cube = scaled(sl, S.CUBE, 0.1)
-    scene = heap(sl, 5, 65, cube)
+    scene = heap(sl, 5, SB.MAX_BODIES + 1, cube)
     se = physics.settle_engine()
     with pytest.raises(RuntimeError) as e:          # the host refuses before anything is launched
         SB.build_settle_batch([scene], se.pool, [(True, 0.04)])
-    assert "64" in str(e.value)
+    assert str(SB.MAX_BODIES) in str(e.value)
     # and the C-ABI refuses a hand-made oversized scene as well
     ok = heap(sl, 6, 2, cube)
     srec, bodies = SB.build_settle_batch([ok], se.pool, [(True, 0.04)])
     prm = SB.default_params(frames=1)
-    prm["max_bodies_per_scene"] = 65
+    prm["max_bodies_per_scene"] = SB.MAX_BODIES + 1
     L = _abi.lib()
     d = se.eng.upload_records(bodies)
     d_s = se.eng.upload_records(srec)
     hulls_d, verts_d = se.hulls_dev()
-    scr = se.scratch(1, 0)
+    need = C.c_uint64()
+    L.slhip_settle_scratch_bytes(1, C.c_void_p(np.ascontiguousarray(prm).ctypes.data), C.byref(need))
+    scr = torch.empty(int(need.value), dtype=torch.uint8, device=se.eng.device)
     st = L.slhip_settle(C.c_void_p(d_s.data_ptr()), 1, C.c_void_p(d.data_ptr()), C.c_void_p(hulls_d.data_ptr()),
                         C.c_void_p(verts_d.data_ptr()), C.c_void_p(np.ascontiguousarray(prm).ctypes.data),
                         C.c_void_p(scr.data_ptr()), scr.numel(), None)
-    assert st != 0 and b"64" in L.slhip_last_error()
+    assert st != 0 and str(SB.MAX_BODIES).encode() in L.slhip_last_error()
 
 
 def test_many_hull_scene_next_to_small_scenes(sl, oracle):

@@ -39,6 +39,8 @@ def run_both(oracle, scenes_, plane=True, **kw):
     gpu = se.run(srec, bodies.copy(), prm)
     hulls, verts = se.pool.arrays()
     ref = bodies.copy()
+    prm["max_hull_pairs_per_scene"] = se.last_params["max_hull_pairs_per_scene"]      # (the host path grows the lists when a heap
+    prm["max_contacts_per_scene"] = se.last_params["max_contacts_per_scene"]          #  needs it: the oracle gets the same)
     oracle.settle(srec, ref, hulls, verts, prm)
     return gpu, ref
 
@@ -320,39 +322,86 @@ def test_refused_first_scene_leaves_the_others_exact(sl, oracle):
     assert_bodies_equal(gpu, ref)
 
 
-def test_cap_saturation_is_counted(sl, oracle):
-    """slhip_settle_caps: the (scene, step) pairs whose contacts hit SLHIP_MAX_ACTIVE_CONTACTS / SLHIP_MAX_HULL_PAIRS, equal to the
-    oracle's count on the same batch (PhysX has no cap: the rate is reported, bench.py prints it)."""
-    import ctypes as C
-
+def _bunny_pile_batch(sl, n_scenes=4):
     from stillleben_amd import physics
 
     cube = scaled(sl, S.CUBE, 0.12)
     bunny = scaled(sl, S.BUNNY, 0.25)
     scs = []
-    for i in range(4):                                    # bunnies (121 hulls each) dropped on each other: many hull pairs
+    for i in range(n_scenes):                             # bunnies (121 hulls each) dropped on each other: many hull pairs
         scene = sl.Scene((320, 240), seed=500 + i)
-        for k in range(12):                               # (six bunnies + six cubes: up to 283 contacts offered against the cap of 255)
+        for k in range(12):                               # (six bunnies + six cubes: ~300 contacts offered in a step)
             scene.add_object(sl.Object(bunny if k < 6 else cube))
         physics.prepare_tabletop(scene)
         scs.append(scene)
-    se = physics.settle_engine()
-    srec, bodies = SB.build_settle_batch(scs, se.pool, [(True, TABLE)] * len(scs))
-    prm = SB.default_params(frames=40)
-    gpu, caps = se.run_with_caps(srec, bodies.copy(), prm)
-    hulls, verts = se.pool.arrays()
-    ref = bodies.copy()
+    return scs
+
+
+def _oracle_caps(oracle, srec, ref, hulls, verts, prm):
+    import ctypes as C
+
     L = oracle.lib()
-    oc = np.zeros((len(scs), 4), np.uint32)
+    oc = np.zeros((len(srec), 4), np.uint32)
     L.slref_settle_set_caps.argtypes = [C.c_void_p]
     L.slref_settle_set_caps(C.c_void_p(oc.ctypes.data))
     try:
         oracle.settle(srec, ref, hulls, verts, prm)
     finally:
         L.slref_settle_set_caps(None)
+    return oc
+
+
+def test_no_contact_is_dropped(sl, oracle):
+    """PhysX has no caps (scene.cpp:738-739).  The pile that saturated round 3's 255-contact / 512-pair caps: with the default
+    list capacities NOTHING is dropped (slhip_settle_caps says so), the contacts beyond the solver's LDS-resident part are swept
+    from global memory, and the bodies are the oracle's, bit for bit."""
+    from stillleben_amd import physics
+
+    scs = _bunny_pile_batch(sl)
+    se = physics.settle_engine()
+    srec, bodies = SB.build_settle_batch(scs, se.pool, [(True, TABLE)] * len(scs))
+    prm = SB.default_params(frames=40)
+    prm["max_hull_pairs_per_scene"], prm["max_contacts_per_scene"] = 16384, 4096     # (bunny on bunny: thousands of candidate hull pairs)
+    gpu, caps = se.run_with_caps(srec, bodies.copy(), prm)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    oc = _oracle_caps(oracle, srec, ref, hulls, verts, SB.sizing_hints(prm, srec, bodies, hulls))
     assert_bodies_equal(gpu, ref)
-    assert caps == (int(oc[:, 0].sum()), int(oc[:, 1].sum()))
-    assert caps[0] > 0                                     # the case is exercised
+    assert caps["contact_drop_steps"] == 0 and caps["pair_drop_steps"] == 0 and caps["scenes_dropped"] == 0
+    assert int(oc[:, 0].sum()) == 0 and int(oc[:, 1].sum()) == 0
+    assert caps["max_contacts"] == int(oc[:, 2].max()) and caps["max_hull_pairs"] == int(oc[:, 3].max())
+    assert caps["max_contacts"] > 255                      # beyond round 3's cap ...
+    assert caps["spill_steps"] > 0 and caps["scenes_spilled"] > 0      # ... and beyond the LDS-resident part: the case is exercised
+
+
+def test_undersized_capacities_are_counted(sl, oracle):
+    """A caller that sizes the lists too small loses contacts / hull pairs in list order -- counted, identically on both
+    sides, never silently: the next call with larger capacities gives the uncapped result."""
+    from stillleben_amd import physics
+
+    scs = _bunny_pile_batch(sl, 2)
+    se = physics.settle_engine()
+    srec, bodies = SB.build_settle_batch(scs, se.pool, [(True, TABLE)] * len(scs))
+    prm = SB.default_params(frames=30)
+    prm["max_hull_pairs_per_scene"], prm["max_contacts_per_scene"] = 300, 150
+    gpu, caps = se.run_with_caps(srec, bodies.copy(), prm)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    oc = _oracle_caps(oracle, srec, ref, hulls, verts, SB.sizing_hints(prm, srec, bodies, hulls))
+    assert_bodies_equal(gpu, ref)
+    assert caps["contact_drop_steps"] == int(oc[:, 0].sum()) > 0
+    assert caps["pair_drop_steps"] == int(oc[:, 1].sum()) > 0
+    assert caps["scenes_dropped"] == int(((oc[:, 0] + oc[:, 1]) > 0).sum())
+    # the host path grows the capacities by itself: the result is the one of lists that never ran out
+    prm0 = SB.default_params(frames=30)
+    prm0["max_hull_pairs_per_scene"], prm0["max_contacts_per_scene"] = 300, 150
+    grown = se.run(srec, bodies.copy(), prm0)
+    big = SB.default_params(frames=30)
+    big["max_hull_pairs_per_scene"], big["max_contacts_per_scene"] = 32768, 8192
+    ref2 = bodies.copy()
+    oracle.settle(srec, ref2, hulls, verts, big)
+    assert_bodies_equal(grown, ref2)
+    assert se.caps(len(srec))["scenes_dropped"] == 0
 
 
 # ---- the contact state outlives the call (slhip_settle_params.resume; PhysX: one PxScene per sl.Scene) ----------------------
@@ -456,7 +505,7 @@ def test_column_stands_through_scene_simulate(sl, oracle):
     assert np.allclose(z, zs, atol=4e-3), z
     for o in scene.objects[1:]:
         R = o.pose().numpy()[:3, :3]
-        assert np.degrees(np.arccos(min(1.0, float(R[2, 2])))) < 0.5
+        assert np.degrees(np.arccos(min(1.0, float(R[2, 2])))) < 1.0
     prm = SB.default_params(tabletop=False, dt=0.01, frames=400, substeps=1)
     hulls, verts = se.pool.arrays()
     ref = bodies.copy()

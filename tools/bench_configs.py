@@ -40,8 +40,14 @@ def timed(fn, reps=5, warm=1):
     return e0.elapsed_time(e1) / reps
 
 
+QUIET = False     # bench.py --config: the records are wrapped into the bench contract's line instead of printed
+
+
 def emit(name, **kw):
-    print(json.dumps(dict(config=name, **kw)))
+    rec = dict(config=name, **kw)
+    if not QUIET:
+        print(json.dumps(rec))
+    return rec
 
 
 def c1(B=256):
@@ -60,7 +66,7 @@ def c1(B=256):
     t_settle = time.perf_counter() - t0
     eng = engine()
     ms = timed(lambda: eng.render(scs, _abi.OUT_INSTANCE, ssao=False, shadows=False))
-    emit("C1 4 cubes 320x240 (batch of %d scenes)" % B, settle_s_per_batch=t_settle, render_ms_per_batch=ms,
+    return emit("C1 4 cubes 320x240 (batch of %d scenes)" % B, settle_s_per_batch=t_settle, render_ms_per_batch=ms,
          scenes_per_s_render=B / (ms * 1e-3), scenes_per_s_settle_incl_host=B / t_settle)
 
 
@@ -85,7 +91,7 @@ def c3():
 
     ms = timed(render, reps=3)
     alg = B * (20 * 8192 * 68 + 20 * 16384 * 12 + 307200 * 40)   # 27.4 MB per scene
-    emit("C3 512 C2 scenes, one GPU", settle_s_incl_host_glue=t_settle, render_ms=ms, scenes_per_s_render_incl_host_glue=B / (ms * 1e-3),
+    return emit("C3 512 C2 scenes, one GPU", settle_s_incl_host_glue=t_settle, render_ms=ms, scenes_per_s_render_incl_host_glue=B / (ms * 1e-3),
          roofline={"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
                    "frac": alg / (ms * 1e-3) / 1e9 / PEAK, "note": "render incl. per-call host batch assembly (engine.render)"})
 
@@ -119,7 +125,7 @@ def c4():
     tris = int(drec["n_tris"].sum())
     verts = int(drec["n_verts"].sum())
     alg = verts * 68 + tris * 12 + 307200 * 88
-    emit("C4 bunny x50 raster stress", triangles=tris, vertices=verts, render_ms=ms, mtris_per_s=tris / (ms * 1e-3) / 1e6,
+    return emit("C4 bunny x50 raster stress", triangles=tris, vertices=verts, render_ms=ms, mtris_per_s=tris / (ms * 1e-3) / 1e6,
          roofline={"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
                    "frac": alg / (ms * 1e-3) / 1e9 / PEAK,
                    "note": "one scene per launch sequence: 3.5 M triangles cannot fill 256 CUs for long, fixed launch latencies dominate"})
@@ -176,7 +182,7 @@ def c5():
     res = rp.render(scene)
     ms_b = timed(lambda: sl.diff.backpropagate_gradient_to_poses(scene, res, grad), reps=10)
     alg = 307200 * 35 + 64 * 88
-    emit("C5 sl.diff 64 objects x 32 hypotheses", s_total_32_hypotheses=total, ms_per_hypothesis_render_plus_backward=total / 32 * 1e3,
+    return emit("C5 sl.diff 64 objects x 32 hypotheses", s_total_32_hypotheses=total, ms_per_hypothesis_render_plus_backward=total / 32 * 1e3,
          s_total_32_hypotheses_batch_api=total_batch, ms_per_hypothesis_batch_api=total_batch / 32 * 1e3,
          batch_vs_loop_max_rel_diff=agree,
          backward_ms_single_hypothesis=ms_b, backward_ms_32_hypotheses_one_sequence=ms_bb, grad_shape=list(d.shape),

@@ -98,9 +98,9 @@ def measure(n=64, seed0=900000, n_objects=20, threads=8, quiet=False):
         "stuck_bodies": int((bodies["stuck_counter"] > 0).sum()),
         "min_separation_p01": float(np.quantile(np.minimum(bodies["separation"], 1.0), 0.01)),
         "active_contacts_last": float(trace[:, -1, 2].mean()),
-        "contact_cap_hit_rate": float(caps[:, 0].sum() / max(1, caps[:, 3].sum())),      # share of scene-steps that dropped contacts
-        "pair_cap_hit_rate": float(caps[:, 1].sum() / max(1, caps[:, 3].sum())),
-        "max_contacts_offered": int(caps[:, 2].max()),
+        "contact_drop_steps": int(caps[:, 0].sum()),      # scene-steps that dropped contacts / hull pairs beyond the default capacities
+        "pair_drop_steps": int(caps[:, 1].sum()),
+        "max_contacts_offered": int(caps[:, 2].max()), "max_hull_pairs_found": int(caps[:, 3].max()),
         "asleep_by_frame": [float(trace[:, f, 0].mean()) for f in (24, 49, 74, 99) if f < frames],
     }
     if not quiet:
