@@ -35,8 +35,9 @@ extern "C" {
 
 #define SLHIP_ABI_VERSION 3   /* 2: slhip_render_scratch.d_shadow_tiles, slhip_render_scratch_bytes fills 7 sizes
                                  3: slhip_render_scratch.d_vattr is REQUIRED (the post-transform vertex cache) and `_pad` became
-                                    shadow_lights; d_clip holds 9 float4 planes per vertex; slhip_settle_params.resume (the contact
-                                    state of a settle outlives the call: 104 bytes)                                              */
+                                    shadow_lights; d_clip holds 9 float4 planes per vertex; slhip_settle_params grew to 116 bytes
+                                    (list capacities instead of caps, pair_contact_budget, resume: the contact state of a settle
+                                    outlives the call); slhip_settle_caps fills counts[8]                                        */
 #define SLHIP_NUM_LIGHTS 3 /* reference include/stillleben/common.h:17 */
 
 /* ---------------------------------------------------------------------------------------------
@@ -343,6 +344,13 @@ typedef struct {
        non-zero count settles again with larger capacities -- nothing is ever dropped silently.                                */
     uint32_t max_hull_pairs_per_scene;
     uint32_t max_contacts_per_scene;
+    /* Compound manifold reduction (NOT in the reference: PhysX hands every convex pair's manifold to the solver).  0: the solver takes
+       every point.  B >= 16: a body pair that touches through more than B hull pairs -- nested concave shapes: a mug in a bowl offers
+       several hundred one-point manifolds, one Gauss-Seidel chain of that length -- keeps the B hull pairs with the deepest points
+       (ties: list order); the others stay filed as manifolds (no impulse) and return when they are among the deepest.  Counted per
+       (scene, step) by slhip_settle_caps.  On the 20-object workload a budget of 64 leaves the share of bodies at rest, the redrops
+       and the deepest penetrations where they are without it.                                            */
+    uint32_t pair_contact_budget;
     /* 0: the call starts from a cold contact state (it initialises the scratch).  N > 0: the call CONTINUES the N steps that earlier
        calls ran on the same d_scratch with the same scenes, bodies (same order, same hulls) and sizing hints -- the state PhysX
        keeps for the life of a PxScene (pair cache, persistent manifolds and their impulses, table contacts; scene.cpp:720-739,
@@ -387,10 +395,11 @@ int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
  * counts[0] (scene, step) pairs whose contacts went beyond the solver's LDS-resident part (SLHIP_LDS_CONTACTS: swept from global
  * memory, nothing lost), [1] (scene, step) pairs in which contacts beyond max_contacts_per_scene were DROPPED, [2] (scene, step)
  * pairs in which hull pairs beyond max_hull_pairs_per_scene were DROPPED, [3] scenes with a non-zero [1] or [2], [4] scenes whose
- * contacts ever went beyond the LDS-resident part, [5] the most contacts and [6] the most hull pairs a step of any scene offered.
+ * contacts ever went beyond the LDS-resident part, [5] the most contacts and [6] the most hull pairs a step of any scene offered,
+ * [7] (scene, step) pairs in which pair_contact_budget reduced some body pair's points.
  * The reference has no caps (scene.cpp:738-739): [1] = [2] = 0 is the contract, a caller that sees otherwise re-sizes.          */
 int slhip_settle_caps(const void* d_scratch, uint32_t n_scenes, const slhip_settle_params* params,
-                      uint64_t counts[7], void* stream);
+                      uint64_t counts[8], void* stream);
 int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_status, uint32_t* h_n_refused,
                         void* stream);
 /* Optional live timing of the phases of a lockstep step (bench.py's roofline leg): HIP events on the launch's stream

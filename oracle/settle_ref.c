@@ -136,6 +136,7 @@ typedef struct {
     float vn0;            /* normal velocity before the solve (restitution) */
     float mu_s, mu_d, e;
     int valid;
+    int culled;           /* offered by its manifold but left out of the solver by pair_contact_budget (valid = 0) */
 } contact;
 
 #define MAX_CONTACTS_PER_HP 4
@@ -181,8 +182,8 @@ typedef struct {
     pplane* pp;                          /* [NB] */
     int step;                            /* 1-based step number since the cold start */
     int hp_overflow;
-    unsigned cap_hits[4];                /* steps of this scene that dropped contacts beyond C / hull pairs beyond P; the most contacts /
-                                            hull pairs a step offered */
+    unsigned cap_hits[5];                /* steps of this scene that dropped contacts beyond C / hull pairs beyond P; the most contacts /
+                                            hull pairs a step offered; steps in which pair_contact_budget reduced a body pair */
     int n_hulls;
     int* body_lh;                        /* [NB + 1] first hull ordinal of every body */
     int *order, *size;                   /* [P + NB] colouring scratch */
@@ -734,7 +735,7 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
                                 const slhip_settle_params* prm, float margin, contact* out, gjk_seed* cached,
                                 pmanifold* pm, int step)
 {
-    for (int i = 0; i < MAX_CONTACTS_PER_HP; ++i) out[i].valid = 0;
+    for (int i = 0; i < MAX_CONTACTS_PER_HP; ++i) { out[i].valid = 0; out[i].culled = 0; }
     const wbody* wa = &wbs[ia];
     const wbody* wb = &wbs[ib];
     shape A, B;
@@ -853,7 +854,7 @@ static void plane_contacts(const slhip_body* bodies, const wbody* wbs, int ia, c
                            const float* hull_verts, const slhip_settle_params* prm, float plane_z,
                            float margin, contact* out, pplane* pp, int step)
 {
-    for (int i = 0; i < PLANE_SLOTS; ++i) out[i].valid = 0;
+    for (int i = 0; i < PLANE_SLOTS; ++i) { out[i].valid = 0; out[i].culled = 0; }
     const slhip_body* b = &bodies[ia];
     const wbody* w = &wbs[ia];
     plane_it it = {w, b, hulls, hull_verts, plane_z, margin};
@@ -1354,6 +1355,33 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
             for (int k = limit; k < MAX_CONTACTS_PER_HP; ++k) ws->c[i + k].valid = 0;
     }
 
+    /* compound manifold reduction (slhip_settle_params.pair_contact_budget; not in the reference): a body pair offering more
+       points than the budget keeps the deepest ones -- keys ordered like the floats, ties in list order; the others stay in their
+       manifolds without impulse */
+    {
+        int B = (int)prm->pair_contact_budget;
+        if (B > 0 && B < 16) B = 16;
+        int reduced = 0;
+        if (B > 0) for (int g = 0; g < ws->n_groups; ++g) {
+            if (ws->g_b[g] < 0) continue;
+            int n = 0;
+            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) n += ws->c[i].valid ? 1 : 0;
+            if (n <= B) continue;
+            reduced = 1;
+            while (n > B) {
+                int worst = -1, wkey = 0;
+                for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) {
+                    if (!ws->c[i].valid) continue;
+                    int key; memcpy(&key, &ws->c[i].sep, 4);
+                    key = key >= 0 ? key : key ^ 0x7fffffff;
+                    if (worst < 0 || key >= wkey) { wkey = key; worst = i; }
+                }
+                ws->c[worst].valid = 0; ws->c[worst].culled = 1; --n;
+            }
+        }
+        if (reduced) ws->cap_hits[4]++;
+    }
+
     /* The solver takes every contact (PhysX has no cap, scene.cpp:738-739) -- up to the capacity of the list the caller sized
        (max_contacts_per_scene): what a step offers beyond it is dropped in list order, the table's contacts first in the list,
        and counted. */
@@ -1442,7 +1470,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         if (!pm) continue;
         const contact* c = &ws->c[k * MAX_CONTACTS_PER_HP];
         int kept = 0;   /* points the active-contact cap dropped (a suffix) leave the manifold */
-        while (kept < pm->count && c[kept].valid) { pm->ln[kept] = c[kept].ln; ++kept; }
+        while (kept < pm->count && (c[kept].valid || c[kept].culled)) { pm->ln[kept] = c[kept].valid ? c[kept].ln : 0.0f; ++kept; }
         pm->count = kept;
     }
     if (sc->has_plane)
@@ -1512,7 +1540,8 @@ static void redrop(const slhip_settle_scene* sc, slhip_body* bodies, int me, con
 
 /* optional per-frame trace for the tests: trace[(s * frames + f) * 4 + {0,1,2,3}] = bodies asleep, redrops so far,
    active contacts of the frame's last step, max |v| */
-static unsigned* g_caps = NULL; /* per scene {steps that dropped contacts, steps that dropped hull pairs, most contacts offered, most hull pairs found} */
+static unsigned* g_caps = NULL; /* per scene [5]: {steps that dropped contacts, steps that dropped hull pairs, most contacts offered, most hull pairs found,
+                                   steps reduced by pair_contact_budget} */
 void slref_settle_set_caps(unsigned* c) { g_caps = c; }
 static float* g_trace = NULL;
 void slref_settle_set_trace(float* t) { g_trace = t; }
@@ -1525,7 +1554,7 @@ typedef struct {
     pmanifold* pm;
     pplane* pp;            /* [bodies of the scene] */
     int step, n_hulls, nb;
-    unsigned cap_hits[4];
+    unsigned cap_hits[5];
 } scene_keep;
 typedef struct { uint32_t n_scenes; scene_keep* k; } settle_state;
 
@@ -1613,7 +1642,7 @@ int slref_settle_ex(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_b
                 t[0] = (float)asleep; t[1] = (f ? t[1 - 4] : 0.0f) + (moved ? 1.0f : 0.0f); t[2] = (float)active; t[3] = vmax;
             }
         }
-        if (g_caps) { g_caps[4 * s] = ws->cap_hits[0]; g_caps[4 * s + 1] = ws->cap_hits[1]; g_caps[4 * s + 2] = ws->cap_hits[2]; g_caps[4 * s + 3] = ws->cap_hits[3]; }
+        if (g_caps) { for (int q = 0; q < 5; ++q) g_caps[5 * s + q] = ws->cap_hits[q]; }
         K->step = ws->step;
         memcpy(K->pp, ws->pp, sizeof(pplane) * nb);
         memcpy(K->cap_hits, ws->cap_hits, sizeof(ws->cap_hits));

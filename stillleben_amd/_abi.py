@@ -271,7 +271,7 @@ def lib():
     L.slhip_records_count.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.slhip_records_build_render.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                              C.c_uint32, C.c_void_p, C.c_uint32]
-    L.slhip_settle_caps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64 * 7), C.c_void_p]
+    L.slhip_settle_caps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64 * 8), C.c_void_p]
     L.slhip_settle_timing_enable.argtypes = [C.c_int]
     L.slhip_settle_timings.argtypes = [C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32 * 5)]
     L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]

@@ -36,9 +36,13 @@ PARAMS_DTYPE = np.dtype([
     ("redrop_z", np.float32), ("stuck_separation", np.float32), ("stuck_frames", np.int32), ("tabletop", np.uint32),
     ("max_bodies_per_scene", np.uint32), ("max_hull_verts_per_scene", np.uint32), ("max_hulls_per_scene", np.uint32),
     ("max_hull_pairs_per_scene", np.uint32), ("max_contacts_per_scene", np.uint32),
-    ("resume", np.uint32),
+    ("pair_contact_budget", np.uint32), ("resume", np.uint32),
 ])
-assert PARAMS_DTYPE.itemsize == 112
+assert PARAMS_DTYPE.itemsize == 116
+
+# slhip_settle_params.pair_contact_budget (0: every point goes to the solver, as in PhysX): a body pair touching through more hull
+# pairs keeps the deepest ones -- nested concave shapes otherwise put several hundred one-point manifolds into ONE Gauss-Seidel chain
+PAIR_CONTACT_BUDGET = 64
 
 BODY_STATIC = 1
 BODY_ASLEEP = 2
@@ -65,6 +69,7 @@ def default_params(tabletop=True, dt=None, frames=None, substeps=None):
     p["stuck_separation"] = -0.01                          # scene.cpp:748
     p["stuck_frames"] = 10                                 # 0.4 s * 25 FPS (scene.cpp:750)
     p["tabletop"] = 1 if tabletop else 0
+    p["pair_contact_budget"] = PAIR_CONTACT_BUDGET
     return p
 
 

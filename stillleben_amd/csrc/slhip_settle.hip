@@ -21,7 +21,7 @@ namespace {
 
 static_assert(sizeof(slhip_body) == 288, "slhip_body layout");
 static_assert(sizeof(slhip_hull) == 64, "slhip_hull layout");
-static_assert(sizeof(slhip_settle_params) == 112, "slhip_settle_params layout");
+static_assert(sizeof(slhip_settle_params) == 116, "slhip_settle_params layout");
 
 constexpr int kMaxContactsPerHP = 4;
 constexpr int kLdsContacts = SLHIP_LDS_CONTACTS;   // the solver's LDS-resident contacts per scene; the rest of the list is swept from global memory
@@ -1199,9 +1199,12 @@ struct ContactList {
     Contact* glb;
     __device__ __forceinline__ Contact load(int i) const { return i < kLdsContacts ? lds[i] : glb[i]; }
     __device__ __forceinline__ Contact* at(int i) const { return i < kLdsContacts ? lds + i : glb + i; }
+    __device__ __forceinline__ float ln(int i) const { return i < kLdsContacts ? lds[i].ln : glb[i].ln; }
 };
 
-__device__ void solve_group(const ContactList ac, int begin, int end, int ia, int ib, int side, WBody* wbs, float inv_dt,
+// (the group lies in the LDS-resident part of the list: every row reads its contact where it needs it -- LDS latency is short, and
+// carrying a prefetched contact around the loop costs eighteen register moves per row)
+__device__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib, int side, WBody* wbs, float inv_dt,
                             bool biased, float plane_mu_s, float plane_mu_d)
 {
     if (begin >= end) return;
@@ -1224,24 +1227,10 @@ __device__ void solve_group(const ContactList ac, int begin, int end, int ia, in
     // first two contacts -- against their share of the patch's accumulated normal impulse.
     float nsum = 0.0f;
     int p0 = begin;
-    // what the friction rows need of the patch's (at most two) anchors -- its first two contacts -- is kept from the moment they pass
-    // through the normal rows: no second fetch (beyond the LDS-resident part that would be an exposed round trip to the L2 per patch)
-    v3 a0r = V(0, 0, 0), a0n = V(0, 0, 0), a1r = V(0, 0, 0), a1n = V(0, 0, 0);
-    float a0til = 1.0f, a0kt1 = 0.0f, a0kt2 = 0.0f, a0lt1 = 0.0f, a0lt2 = 0.0f;
-    float a1til = 1.0f, a1kt1 = 0.0f, a1kt2 = 0.0f, a1lt1 = 0.0f, a1lt2 = 0.0f;
-    // (the next contact is fetched while this one's row runs: beyond the LDS-resident part it comes from global memory)
-    Contact nxt = ac.load(begin);
     for (int ci = begin; ci < end; ++ci) {
-        const Contact c = nxt;
-        const bool more = ci + 1 < end;
-        if (more) nxt = ac.load(ci + 1);
+        const Contact c = ac[ci];
+        if (c.til < 0.0f) { nsum = 0.0f; p0 = ci; }
         const v3 r = side ? c.rb : c.ra;
-        if (c.til < 0.0f) {
-            nsum = 0.0f; p0 = ci;
-            a0r = r; a0n = c.n; a0til = c.til; a0kt1 = c.kt1; a0kt2 = c.kt2; a0lt1 = c.lt1; a0lt2 = c.lt2;
-        } else if (ci == p0 + 1) {
-            a1r = r; a1n = c.n; a1til = c.til; a1kt1 = c.kt1; a1kt2 = c.kt2; a1lt1 = c.lt1; a1lt2 = c.lt2;
-        }
         v3 pv = add(M.v, cross(M.w, r));
         v3 d = sub(pv, pair_swap(pv));              // side 0: a - b, side 1: b - a
         const float vn = sgn * dot(d, c.n);
@@ -1251,22 +1240,21 @@ __device__ void solve_group(const ContactList ac, int begin, int end, int ia, in
         if (ln < 0.0f) ln = 0.0f;
         dl = ln - c.ln;
         apply_mine(M, r, scale(c.n, sgn * dl));
-        if (side == 0) ac.at(ci)->ln = ln;
+        if (side == 0) ac[ci].ln = ln;
         nsum = nsum + ln;
-        const bool last = !more || nxt.til < 0.0f;
+        const bool last = ci + 1 == end || ac[ci + 1].til < 0.0f;
         if (!last) continue;
         const int anchors = ci - p0 >= 1 ? 2 : 1;
         const float share = anchors == 2 ? 0.5f * nsum : nsum;
         for (int ai = 0; ai < anchors; ++ai) {
-            const v3 rq = ai ? a1r : a0r, qn = ai ? a1n : a0n;
-            const float qtil = ai ? a1til : a0til, qkt1 = ai ? a1kt1 : a0kt1, qkt2 = ai ? a1kt2 : a0kt2;
-            const float qlt1 = ai ? a1lt1 : a0lt1, qlt2 = ai ? a1lt2 : a0lt2;
+            const Contact q = ac[p0 + ai];
+            const v3 rq = side ? q.rb : q.ra;
             pv = add(M.v, cross(M.w, rq));
             d = sub(pv, pair_swap(pv));
             v3 t1, t2;
-            tangents_cached(qn, fabsf(qtil), &t1, &t2);
-            float l1 = qlt1 - (sgn * dot(d, t1)) * qkt1;
-            float l2 = qlt2 - (sgn * dot(d, t2)) * qkt2;
+            tangents_cached(q.n, fabsf(q.til), &t1, &t2);
+            float l1 = q.lt1 - (sgn * dot(d, t1)) * q.kt1;
+            float l2 = q.lt2 - (sgn * dot(d, t2)) * q.kt2;
             const float mag2 = fmaf(l2, l2, l1 * l1);
             const float lim_s = mu_s * share;
             if (mag2 > lim_s * lim_s) {
@@ -1274,9 +1262,95 @@ __device__ void solve_group(const ContactList ac, int begin, int end, int ia, in
                 const float k = (mu_d * share) / mag;
                 l1 *= k; l2 *= k;
             }
-            const float d1 = l1 - qlt1, d2 = l2 - qlt2;
+            const float d1 = l1 - q.lt1, d2 = l2 - q.lt2;
             apply_mine(M, rq, madd(scale(t1, sgn * d1), t2, sgn * d2));
-            if (side == 0) { Contact* w = ac.at(p0 + ai); w->lt1 = l1; w->lt2 = l2; }
+            if (side == 0) { ac[p0 + ai].lt1 = l1; ac[p0 + ai].lt2 = l2; }
+        }
+    }
+    if (M.dynamic) { wbs[mine].v = M.v; wbs[mine].w = M.w; }
+}
+
+// what the friction rows need of a patch's anchor contact, kept from the moment it passes through its normal row (no second
+// fetch: beyond the LDS-resident part that would be an exposed round trip to the L2 per patch)
+struct Anchor { v3 r, n; float til, kt1, kt2, lt1, lt2; };
+
+__device__ void solve_group(const ContactList ac, int begin, int end, int ia, int ib, int side, WBody* wbs, float inv_dt,
+                            bool biased, float plane_mu_s, float plane_mu_d)
+{
+    if (begin >= end) return;
+    if (end <= kLdsContacts) { solve_group_lds(ac.lds, begin, end, ia, ib, side, wbs, inv_dt, biased, plane_mu_s, plane_mu_d); return; }
+    const bool has_b = ib >= 0;
+    const int mine = side ? ib : ia;
+    BodyRegs M;
+    if (mine >= 0) load_regs(wbs[mine], M);
+    else {   // the idle lane of a plane group: +0 velocities, so a - b == a exactly
+        M.v = V(0, 0, 0); M.w = V(0, 0, 0); M.inv_mass = 0.0f; M.dynamic = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) M.Iinv.m[k] = 0.0f;
+    }
+    const bool other_dynamic = pair_swap(M.dynamic ? 1.0f : 0.0f) != 0.0f;
+    if (!M.dynamic && !other_dynamic) return;  // the oracle invalidates such contacts in prep
+    const float mu_s = 0.5f * (wbs[ia].mu_s + (has_b ? wbs[ib].mu_s : plane_mu_s));
+    const float mu_d = 0.5f * (wbs[ia].mu_d + (has_b ? wbs[ib].mu_d : plane_mu_d));
+    const float sgn = side ? -1.0f : 1.0f;
+    // Friction patches (oracle solve_patch; PhysX's ePATCH model): the contacts of one manifold are contiguous, the first one
+    // carries the head mark.  Normal rows in order; when the patch ends, the friction rows of its (at most two) anchors -- its
+    // first two contacts -- against their share of the patch's accumulated normal impulse.  The loop walks patch by patch; the
+    // next contact is fetched while the current row runs (beyond the LDS-resident part it comes from global memory).
+    Contact nxt = ac.load(begin);
+    int ci = begin;
+    bool more = true;
+    float nsum = 0.0f;
+    auto normal_row = [&](Anchor* keep) {
+        const Contact c = nxt;
+        more = ci + 1 < end;
+        if (more) nxt = ac.load(ci + 1);
+        const v3 r = side ? c.rb : c.ra;
+        if (keep) { keep->r = r; keep->n = c.n; keep->til = c.til; keep->kt1 = c.kt1; keep->kt2 = c.kt2; keep->lt1 = c.lt1; keep->lt2 = c.lt2; }
+        const v3 pv = add(M.v, cross(M.w, r));
+        const v3 d = sub(pv, pair_swap(pv));        // side 0: a - b, side 1: b - a
+        const float vn = sgn * dot(d, c.n);
+        const float target = biased ? c.err : c.bounce;   // prep_contact
+        float dl = (target - vn) * c.kn;
+        float ln = c.ln + dl;
+        if (ln < 0.0f) ln = 0.0f;
+        dl = ln - c.ln;
+        apply_mine(M, r, scale(c.n, sgn * dl));
+        if (side == 0) ac.at(ci)->ln = ln;
+        nsum = nsum + ln;
+        ++ci;
+    };
+    auto friction_rows = [&](const Anchor& q, int at, float share) {
+        const v3 pv = add(M.v, cross(M.w, q.r));
+        const v3 d = sub(pv, pair_swap(pv));
+        v3 t1, t2;
+        tangents_cached(q.n, fabsf(q.til), &t1, &t2);
+        float l1 = q.lt1 - (sgn * dot(d, t1)) * q.kt1;
+        float l2 = q.lt2 - (sgn * dot(d, t2)) * q.kt2;
+        const float mag2 = fmaf(l2, l2, l1 * l1);
+        const float lim_s = mu_s * share;
+        if (mag2 > lim_s * lim_s) {
+            const float mag = sqrtf(mag2);
+            const float k = (mu_d * share) / mag;
+            l1 *= k; l2 *= k;
+        }
+        const float d1 = l1 - q.lt1, d2 = l2 - q.lt2;
+        apply_mine(M, q.r, madd(scale(t1, sgn * d1), t2, sgn * d2));
+        if (side == 0) { Contact* w = ac.at(at); w->lt1 = l1; w->lt2 = l2; }
+    };
+    while (ci < end) {
+        const int p0 = ci;
+        nsum = 0.0f;
+        Anchor a0, a1;
+        normal_row(&a0);
+        if (more && !(nxt.til < 0.0f)) {
+            normal_row(&a1);
+            while (more && !(nxt.til < 0.0f)) normal_row(nullptr);
+            const float share = 0.5f * nsum;
+            friction_rows(a0, p0, share);
+            friction_rows(a1, p0 + 1, share);
+        } else {
+            friction_rows(a0, p0, nsum);
         }
     }
     if (M.dynamic) { wbs[mine].v = M.v; wbs[mine].w = M.w; }
@@ -1678,13 +1752,15 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         int spw = 1;
         if (const char* e = getenv("SLHIP_SOLVE_SPW")) { spw = atoi(e); if (spw != 2 && spw != 4) spw = 1; }
         if (spw * SL.total > 160 * 1024) spw = 1;
+        // LDS a solver wave asks for: what it needs, or more (SLHIP_SOLVE_LDS_KB) -- the padding is never touched, it only limits how
+        // many solver waves a CU takes at a time, i.e. how much of the CU's registers and wave slots the render stream keeps
+        int solve_lds = spw * SL.total;
+        if (const char* e = getenv("SLHIP_SOLVE_LDS_KB")) { const int kb = atoi(e) * 1024; if (kb > solve_lds && kb <= 160 * 1024) solve_lds = kb; }
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_begin), hipFuncAttributeMaxDynamicSharedMemorySize, BL.total));
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_finish), hipFuncAttributeMaxDynamicSharedMemorySize, FL.total));
-        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SL.total));
-        if (2 * SL.total <= 160 * 1024)
-            SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL.total));
-        if (4 * SL.total <= 160 * 1024)
-            SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SL.total));
+        if (spw == 1) SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, solve_lds));
+        if (spw == 2) SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, solve_lds));
+        if (spw == 4) SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<4>), hipFuncAttributeMaxDynamicSharedMemorySize, solve_lds));
         // a resumed call finds everything the prologue would set up -- and the contact state it would clear -- in the scratch
         if (params->resume == 0u) k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, pc);
         // the compacted narrowphase passes walk their work lists with a grid stride: enough waves for a step's typical list
@@ -1716,13 +1792,13 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                 k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL, pc, step + 1u);
                 if (timed) (void)hipEventRecord(ev[4], stream);
                 if (spw == 4)
-                    k_w_solve<4><<<(n_scenes + 3) / 4, 64, 4 * SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
+                    k_w_solve<4><<<(n_scenes + 3) / 4, 64, solve_lds, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
                                                                                      sub + 1 == params->substeps ? 1 : 0, n_scenes);
                 else if (spw == 2)
-                    k_w_solve<2><<<(n_scenes + 1) / 2, 64, 2 * SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
+                    k_w_solve<2><<<(n_scenes + 1) / 2, 64, solve_lds, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
                                                                                      sub + 1 == params->substeps ? 1 : 0, n_scenes);
                 else
-                    k_w_solve<1><<<n_scenes, 64, SL.total, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
+                    k_w_solve<1><<<n_scenes, 64, solve_lds, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
                                                                       sub + 1 == params->substeps ? 1 : 0, n_scenes);
                 if (timed) {
                     (void)hipEventRecord(ev[5], stream);
@@ -1739,14 +1815,14 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
 // contacts (nothing lost), contacts / hull pairs DROPPED beyond the capacities the caller sized (the contract is zero), the
 // scenes concerned, the most a step offered.  The reference's PhysX has no caps (scene.cpp:738-739).
 extern "C" int slhip_settle_caps(const void* d_scratch, uint32_t n_scenes, const slhip_settle_params* params,
-                                 uint64_t counts[7], void* stream_)
+                                 uint64_t counts[8], void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d_scratch || !params || !counts) {
         slhip::set_error("slhip_settle_caps: null argument");
         return -1;
     }
-    for (int k = 0; k < 7; ++k) counts[k] = 0;
+    for (int k = 0; k < 8; ++k) counts[k] = 0;
     if (n_scenes == 0) return 0;
     const SettleDims D = settle_dims(params);
     const char* base = reinterpret_cast<const char*>(d_scratch) + settle_fixed_bytes(n_scenes, D) + settle_cache_bytes(n_scenes, D);
@@ -1761,6 +1837,7 @@ extern "C" int slhip_settle_caps(const void* d_scratch, uint32_t n_scenes, const
         if (c[kCapSpillSteps]) ++counts[4];
         if (c[kCapMaxContacts] > counts[5]) counts[5] = c[kCapMaxContacts];
         if (c[kCapMaxPairs] > counts[6]) counts[6] = c[kCapMaxPairs];
+        counts[7] += c[kCapReducedSteps];
     }
     return 0;
 }

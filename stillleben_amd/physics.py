@@ -104,11 +104,12 @@ class SettleEngine:
         """What the list capacities cost since the last cold start on the stream's scratch (slhip_settle_caps), as a dict:
         spill_steps (scene-steps whose contacts went beyond the solver's LDS-resident part: swept from global memory, nothing
         lost), contact_drop_steps / pair_drop_steps (scene-steps that DROPPED contacts / hull pairs beyond the capacities:
-        the contract is zero), scenes_dropped, scenes_spilled, max_contacts, max_hull_pairs (the most a step offered)."""
+        the contract is zero), scenes_dropped, scenes_spilled, max_contacts, max_hull_pairs (the most a step offered),
+        reduced_steps (scene-steps in which pair_contact_budget reduced some body pair's points)."""
         eng = self.eng
         if stream is None:
             stream = torch.cuda.current_stream(eng.device).cuda_stream
-        out = (C.c_uint64 * 7)()
+        out = (C.c_uint64 * 8)()
         if prm is None:
             prm = self._keep[stream][1]
         if scratch is None:
@@ -116,7 +117,8 @@ class SettleEngine:
         with torch.cuda.device(eng.device):
             st = eng.L.slhip_settle_caps(_abi_ptr(scratch), n_scenes, C.c_void_p(prm.ctypes.data), C.byref(out), C.c_void_p(stream))
         _abi.check(st, "slhip_settle_caps")
-        keys = ("spill_steps", "contact_drop_steps", "pair_drop_steps", "scenes_dropped", "scenes_spilled", "max_contacts", "max_hull_pairs")
+        keys = ("spill_steps", "contact_drop_steps", "pair_drop_steps", "scenes_dropped", "scenes_spilled", "max_contacts", "max_hull_pairs",
+                "reduced_steps")
         return {k: int(v) for k, v in zip(keys, out)}
 
     def run_with_caps(self, srec, bodies, params):

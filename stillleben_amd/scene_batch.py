@@ -13,6 +13,7 @@ camera intrinsics, light colour, seed); per scene nothing crosses PCIe.
     scene = batch.scene(17)                             # an ordinary sl.Scene rebuilt from the device records
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -163,6 +164,16 @@ class SceneBatch:
         sp["max_bodies_per_scene"] = self.n_objects
         sp["max_hulls_per_scene"] = table.bound(table.n_hulls, n_objects, distinct)
         sp["max_hull_verts_per_scene"] = table.bound(table.n_hull_verts, n_objects, distinct)
+        # list capacities of the scratch: no scene may lose a hull pair or a contact (settle_caps() says if one did).  The bound on
+        # the pairs is what the table's hull counts allow, capped where 16384 scenes of the 21 YCB-like classes never got (the most
+        # ever seen: 3 168 candidate pairs in a step -- mug in bowl on banana; 664 contacts with the default pair_contact_budget)
+        h = int(sp["max_hulls_per_scene"])
+        sp["max_hull_pairs_per_scene"] = max(64, min(4096, h * h // 2))
+        sp["max_contacts_per_scene"] = 1024
+        for key, env in (("max_hull_pairs_per_scene", "SLHIP_PAIR_CAP"), ("max_contacts_per_scene", "SLHIP_CONTACT_CAP"),
+                         ("pair_contact_budget", "SLHIP_PAIR_BUDGET")):      # developer knobs (tools/probes)
+            if os.environ.get(env):
+                sp[key] = int(os.environ[env])
         self.settle_params = sp
         dev = self.eng.device
         nb = self.n_scenes * self.n_objects

@@ -341,7 +341,7 @@ def _oracle_caps(oracle, srec, ref, hulls, verts, prm):
     import ctypes as C
 
     L = oracle.lib()
-    oc = np.zeros((len(srec), 4), np.uint32)
+    oc = np.zeros((len(srec), 5), np.uint32)
     L.slref_settle_set_caps.argtypes = [C.c_void_p]
     L.slref_settle_set_caps(C.c_void_p(oc.ctypes.data))
     try:
@@ -361,6 +361,7 @@ def test_no_contact_is_dropped(sl, oracle):
     se = physics.settle_engine()
     srec, bodies = SB.build_settle_batch(scs, se.pool, [(True, TABLE)] * len(scs))
     prm = SB.default_params(frames=40)
+    prm["pair_contact_budget"] = 0                                                   # every point goes to the solver, as in PhysX
     prm["max_hull_pairs_per_scene"], prm["max_contacts_per_scene"] = 16384, 4096     # (bunny on bunny: thousands of candidate hull pairs)
     gpu, caps = se.run_with_caps(srec, bodies.copy(), prm)
     hulls, verts = se.pool.arrays()
@@ -372,6 +373,16 @@ def test_no_contact_is_dropped(sl, oracle):
     assert caps["max_contacts"] == int(oc[:, 2].max()) and caps["max_hull_pairs"] == int(oc[:, 3].max())
     assert caps["max_contacts"] > 255                      # beyond round 3's cap ...
     assert caps["spill_steps"] > 0 and caps["scenes_spilled"] > 0      # ... and beyond the LDS-resident part: the case is exercised
+    assert caps["reduced_steps"] == 0
+    # the same pile with the default compound manifold reduction (pair_contact_budget): bunny on bunny offers hundreds of one-point
+    # manifolds per body pair, the deepest 64 go to the solver -- counted, and identical on both sides
+    prm["pair_contact_budget"] = SB.PAIR_CONTACT_BUDGET
+    gpu, caps = se.run_with_caps(srec, bodies.copy(), prm)
+    ref = bodies.copy()
+    oc = _oracle_caps(oracle, srec, ref, hulls, verts, SB.sizing_hints(prm, srec, bodies, hulls))
+    assert_bodies_equal(gpu, ref)
+    assert caps["reduced_steps"] == int(oc[:, 4].sum()) > 0
+    assert caps["scenes_dropped"] == 0
 
 
 def test_undersized_capacities_are_counted(sl, oracle):
@@ -383,6 +394,7 @@ def test_undersized_capacities_are_counted(sl, oracle):
     se = physics.settle_engine()
     srec, bodies = SB.build_settle_batch(scs, se.pool, [(True, TABLE)] * len(scs))
     prm = SB.default_params(frames=30)
+    prm["pair_contact_budget"] = 0
     prm["max_hull_pairs_per_scene"], prm["max_contacts_per_scene"] = 300, 150
     gpu, caps = se.run_with_caps(srec, bodies.copy(), prm)
     hulls, verts = se.pool.arrays()
@@ -394,9 +406,11 @@ def test_undersized_capacities_are_counted(sl, oracle):
     assert caps["scenes_dropped"] == int(((oc[:, 0] + oc[:, 1]) > 0).sum())
     # the host path grows the capacities by itself: the result is the one of lists that never ran out
     prm0 = SB.default_params(frames=30)
+    prm0["pair_contact_budget"] = 0
     prm0["max_hull_pairs_per_scene"], prm0["max_contacts_per_scene"] = 300, 150
     grown = se.run(srec, bodies.copy(), prm0)
     big = SB.default_params(frames=30)
+    big["pair_contact_budget"] = 0
     big["max_hull_pairs_per_scene"], big["max_contacts_per_scene"] = 32768, 8192
     ref2 = bodies.copy()
     oracle.settle(srec, ref2, hulls, verts, big)

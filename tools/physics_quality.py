@@ -46,7 +46,7 @@ def settle_range(args):
     frames = int(prm["frames"])
     sub = ss[lo:hi].copy()
     trace = np.zeros((hi - lo, frames, 4), np.float32)
-    caps = np.zeros((hi - lo, 4), np.uint32)
+    caps = np.zeros((hi - lo, 5), np.uint32)
     L.slref_settle_set_trace.argtypes = [C.c_void_p]
     L.slref_settle_set_caps.argtypes = [C.c_void_p]
     L.slref_settle_set_trace(C.c_void_p(trace.ctypes.data))
@@ -74,7 +74,7 @@ def measure(n=64, seed0=900000, n_objects=20, threads=8, quiet=False):
         res = [settle_range(j) for j in jobs]
     frames = int(prm["frames"])
     trace = np.zeros((n, frames, 4), np.float32)
-    caps = np.zeros((n, 4), np.uint32)
+    caps = np.zeros((n, 5), np.uint32)
     for lo, hi, b, t, c in res:
         b0, b1 = int(ss[lo]["body_begin"]), int(ss[hi - 1]["body_end"])
         bodies[b0:b1] = b
@@ -101,6 +101,7 @@ def measure(n=64, seed0=900000, n_objects=20, threads=8, quiet=False):
         "contact_drop_steps": int(caps[:, 0].sum()),      # scene-steps that dropped contacts / hull pairs beyond the default capacities
         "pair_drop_steps": int(caps[:, 1].sum()),
         "max_contacts_offered": int(caps[:, 2].max()), "max_hull_pairs_found": int(caps[:, 3].max()),
+        "pair_budget_reduced_steps": int(caps[:, 4].sum()),
         "asleep_by_frame": [float(trace[:, f, 0].mean()) for f in (24, 49, 74, 99) if f < frames],
     }
     if not quiet:
