@@ -1,17 +1,15 @@
 """Convex collision shapes for a mesh (reference Mesh::loadPhysics, src/mesh.cpp:304-533).
 
 The reference runs V-HACD twice (single hull, then concavity 0.002) and uses the decomposition
-only when its volume is < 75 % of the hull's (mesh.cpp:426-429).  Here:
-  * `lib/libslvhacd.so` -- the SAME library (the reference's vendored third-party V-HACD, built by
-    `__graft_entry__.build()` from the sources where they lie, behind our C shim
-    csrc/host/slvhacd.cpp) run with the same two parameter sets and the same selection rule: this
-    is the decomposition behind `hulls_for_mesh` whenever the library is present;
-  * `<mesh>.sl_hulls` caches the result with the reference's invalidation keys (below);
-  * `<mesh>.hulls.npz` fixtures (tests/fixtures: cube, bunny) carry hulls made by the same library
-    for boxes without it; they are validated against the mesh's geometry digests;
-  * without the library: the exact single hull (scipy/Qhull) and, for concave meshes, a built-in
-    approximate splitter -- with a RuntimeWarning, because those parts are NOT V-HACD's.
-Hull vertices are limited to 64 (VHACD.h:235)."""
+only when its volume is < 75 % of the hull's (mesh.cpp:426-429).  Here, in this order:
+  * `<mesh>.hulls.npz` fixtures (tests/fixtures: cube, bunny) and the shipped set of the synthetic YCB-like classes
+    (data/ycb_like_hulls_seed0.npz): decompositions made ONCE, in the build container, by the reference's own vendored
+    V-HACD as a TOOL (oracle/ref_build/gen_hulls.py + vhacd_driver.cpp; nothing of it is linked into or shipped with the
+    product); validated against the mesh's geometry digests;
+  * `<mesh>.sl_hulls`: the cache, with the reference's invalidation keys (below);
+  * the in-tree decomposition `acd.decompose` (voxelise, cut hierarchically by concavity, hulls limited to 64 vertices,
+    VHACD.h:235) under the reference's selection rule -- tests/test_host_acd.py holds it against the V-HACD fixtures
+    (same single-hull decisions, total hull volume within 10 %, hull counts within a factor of two)."""
 import os
 
 import numpy as np
@@ -88,39 +86,6 @@ def _mesh_volume(pos, idx):
     t = idx.reshape(-1, 3)
     p = pos.astype(np.float64)
     return float(np.abs(np.einsum("ij,ij->i", p[t[:, 0]], np.cross(p[t[:, 1]], p[t[:, 2]])).sum()) / 6.0)
-
-
-def _decompose(pos, tris, depth, max_depth=4):
-    """Recursive surface split along the longest bbox axis until each part is ~convex."""
-    used = np.unique(tris)
-    pts = pos[used]
-    hull = _reduce(pts)
-    if depth >= max_depth or len(tris) < 16:
-        return [hull]
-    # part "volume": sum of signed tets against the part centroid is ill-defined for open
-    # parts; use the ratio of surface-sampled hull thickness instead: split while the part's
-    # points are far inside their own hull on average
-    c = pts.mean(axis=0)
-    hv = hull.vertices.astype(np.float64)
-    ht = hull.triangles
-    n = np.cross(hv[ht[:, 1]] - hv[ht[:, 0]], hv[ht[:, 2]] - hv[ht[:, 0]])
-    ln = np.linalg.norm(n, axis=1)
-    keep = ln > 1e-20
-    n = n[keep] / ln[keep, None]
-    d = np.einsum("ij,ij->i", n, hv[ht[keep, 0]])
-    # distance of every surface point to the closest hull plane
-    dist = (d[None, :] - pts.astype(np.float64) @ n.T).min(axis=1)
-    ext = pts.max(axis=0) - pts.min(axis=0)
-    if dist.mean() < 0.02 * float(np.linalg.norm(ext)):
-        return [hull]
-    ax = int(np.argmax(ext))
-    cen = pos[tris].mean(axis=1)[:, ax]
-    cut = np.median(cen)
-    a, b = tris[cen <= cut], tris[cen > cut]
-    if len(a) == 0 or len(b) == 0:
-        return [hull]
-    del c
-    return _decompose(pos, a, depth + 1, max_depth) + _decompose(pos, b, depth + 1, max_depth)
 
 
 # ---- hull cache (reference mesh.cpp:94-172 readCacheFile, :490-511 write) ------------------------------
@@ -216,91 +181,26 @@ def write_cache(cache_file, data, flags, hulls):
         pass                              # read-only asset directory: the cache is an optimisation
 
 
-_VHACD = None
-VHACD_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libslvhacd.so")
-
-
-def vhacd_lib():
-    """ctypes handle of lib/libslvhacd.so, or None when it was not built (no /root/reference at build time)."""
-    global _VHACD
-    if _VHACD is None:
-        import ctypes as C
-
-        if not os.path.exists(VHACD_LIB):
-            _VHACD = False
-        else:
-            L = C.CDLL(VHACD_LIB)
-            L.slvhacd_decompose.restype = C.c_void_p
-            L.slvhacd_decompose.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]
-            L.slvhacd_free.argtypes = [C.c_void_p]
-            L.slvhacd_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-            L.slvhacd_hull_size.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-            L.slvhacd_hull_copy.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-            _VHACD = L
-    return _VHACD or None
-
-
-def vhacd_hulls(positions, indices, force_single=False):
-    """Mesh::loadPhysics' two V-HACD passes + selection rule (mesh.cpp:335-470) through lib/libslvhacd.so.
-    Returns (hulls, info) with info = dict(volume_single, volume_decomposition, used_decomposition), or None
-    when V-HACD could not build a hull with volume (the reference then hands the raw vertices to PhysX,
-    mesh.cpp:373-378 -- the caller falls back to the Qhull hull of the vertices)."""
-    import ctypes as C
-
-    L = vhacd_lib()
-    if L is None:
-        raise RuntimeError("lib/libslvhacd.so is not built")
-    v = np.ascontiguousarray(positions, dtype=np.float32)
-    t = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
-    r = L.slvhacd_decompose(v.ctypes.data, len(v), t.ctypes.data, len(t) // 3, 1 if force_single else 0)   # releases the GIL
-    if not r:
-        raise RuntimeError("V-HACD failed")
-    try:
-        info = (C.c_uint32 * 3)()
-        vol = (C.c_double * 2)()
-        L.slvhacd_info(r, info, vol)
-        if info[2]:
-            return None
-        hulls = []
-        for i in range(info[0]):
-            nv, nt, hv = C.c_uint32(), C.c_uint32(), C.c_double()
-            L.slvhacd_hull_size(r, i, C.byref(nv), C.byref(nt), C.byref(hv))
-            hv_ = np.empty((nv.value, 3), np.float32)
-            ht_ = np.empty((nt.value, 3), np.uint32)
-            L.slvhacd_hull_copy(r, i, hv_.ctypes.data, ht_.ctypes.data)
-            hulls.append(Hull(hv_, ht_.astype(np.int32)))
-        return hulls, {"volume_single": vol[0], "volume_decomposition": vol[1], "used_decomposition": bool(info[1])}
-    finally:
-        L.slvhacd_free(r)
-
-
-_warned_no_vhacd = False
-
-
 def _compute_hulls(data, force):
-    global _warned_no_vhacd
-    if vhacd_lib() is not None:
-        res = vhacd_hulls(data.positions, data.indices, force_single=force)
-        if res is None:
-            return [_reduce(data.positions)]      # mesh.cpp:373-378: raw vertices -> the cooker's own hull
-        return res[0]
+    """Mesh::loadPhysics' procedure (mesh.cpp:335-470) on the in-tree decomposition: the single hull when it is forced
+    (PHYSICS_FORCE_CONVEX_HULL), when the mesh has no volume (mesh.cpp:373-378: the raw vertices' hull), or when the
+    decomposition would keep 75 % or more of the hull's volume (mesh.cpp:426-429)."""
+    from . import acd
+
     single = _reduce(data.positions)
     if force:
         return [single]
-    tris = data.indices.reshape(-1, 3).astype(np.int64)
     hv = single.volume()
     if hv < 1e-9:
         return [single]
-    parts = _decompose(data.positions, tris, 0)
-    # the reference's criterion on what we have: sum of the parts' hull volumes against the single hull (mesh.cpp:426-429)
+    # the parts of a decomposition cover the solid: when the solid itself fills 75 % of its hull, the rule's answer is known
+    # before any cut is made (volume from the voxel grid: robust for meshes that are not closed)
+    occ, _, h = acd.voxelize(data.positions, data.indices, resolution=100000)
+    if float(occ.sum()) * h ** 3 >= 0.80 * hv:
+        return [single]
+    parts = [Hull(v, t) for v, t in acd.decompose(data.positions, data.indices)]
     if len(parts) <= 1 or sum(p.volume() for p in parts) / hv >= 0.75:
         return [single]
-    if not _warned_no_vhacd:
-        import warnings
-
-        warnings.warn("lib/libslvhacd.so is not built (run __graft_entry__.build() where /root/reference is present): concave "
-                      "meshes are split by the built-in approximate splitter, NOT by V-HACD as the reference does", RuntimeWarning)
-        _warned_no_vhacd = True
     return parts
 
 

@@ -4,9 +4,9 @@ reference examples/ycb.py:21-30 is approximated by a compound of convex primitiv
 (cans = cylinders, boxes, bowl/mug = rings of wall segments, banana = bent chain, drill/clamps =
 box compounds), tessellated to ~8192 vertices / ~16384 triangles with a seeded 1024^2 noise
 texture.  Collision hulls: like every mesh of the reference these go through Mesh::loadPhysics' V-HACD
-procedure (hulls.vhacd_hulls: lib/libslvhacd.so, mesh.cpp:335-470); the result for the default set
-(seed 0, 8192 vertices) is shipped as data/ycb_like_hulls_seed0.npz, keyed by the meshes' geometry
-digests, so that a box without the library (or without minutes to spare) loads the very same hulls.
+procedure (mesh.cpp:335-470) -- run once in the build container with the reference's own V-HACD as a tool
+(oracle/ref_build/gen_hulls.py --ycb); the result for the default set (seed 0, 8192 vertices) is shipped as
+data/ycb_like_hulls_seed0.npz, keyed by the meshes' geometry digests.  Other seeds / sizes: the in-tree decomposition.
 `hulls="parts"` gives the by-construction hulls instead (one convex hull per primitive part)."""
 import math
 import os
@@ -242,50 +242,34 @@ def _shipped_hulls(seed, cms):
     return out
 
 
-def write_hull_data(seed=0, target_verts=8192):
-    """Developer step (needs lib/libslvhacd.so): runs V-HACD on the set and writes data/ycb_like_hulls_seed<seed>.npz."""
-    from concurrent.futures import ThreadPoolExecutor
-
+def _native_hulls(cm):
     from . import hulls as H
 
-    cms = [make_class_mesh(name, seed, target_verts, 64)[0] for name in YCB_CLASSES]
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:      # the C call releases the GIL
-        res = list(ex.map(lambda cm: H._compute_hulls(cm, False), cms))
-    out = {}
-    for name, cm, hs in zip(YCB_CLASSES, cms, res):
-        key = name + "/"
-        out[key + "digests"] = np.array(H._mesh_digests(cm), dtype=np.uint64)
-        out[key + "n"] = np.int32(len(hs))
-        for i, h in enumerate(hs):
-            out["%sv%d" % (key, i)], out["%st%d" % (key, i)] = h.vertices, h.triangles
-    os.makedirs(os.path.dirname(HULL_DATA), exist_ok=True)
-    np.savez_compressed(HULL_DATA % seed, **out)
-    return {n: len(h) for n, h in zip(YCB_CLASSES, res)}
+    return H._compute_hulls(cm, False)
 
 
 def ycb_like_meshes(seed=0, target_verts=8192, tex_size=1024, hulls="vhacd"):
     """21 sl.Mesh objects named after the YCB-Video classes, class_index = i + 1
-    (reference examples/ycb.py:46-48).  hulls: "vhacd" (the reference's procedure: shipped data when it
-    matches the geometry, else computed with lib/libslvhacd.so) or "parts" (by construction)."""
+    (reference examples/ycb.py:46-48).  hulls: "vhacd" (the decompositions the reference's V-HACD gave this very geometry,
+    shipped as data/ycb_like_hulls_seed<seed>.npz by oracle/ref_build/gen_hulls.py; for another seed / size the in-tree
+    decomposition of hulls._compute_hulls computes them), "native" (always the in-tree decomposition) or "parts" (by
+    construction: one hull per primitive part)."""
     from . import hulls as H
     from .mesh import Mesh
 
     made = [make_class_mesh(name, seed, target_verts, tex_size) for name in YCB_CLASSES]
     sets = [h for _, h in made]
-    if hulls == "vhacd":
-        shipped = _shipped_hulls(seed, [cm for cm, _ in made]) if target_verts == 8192 else None
+    if hulls in ("vhacd", "native"):
+        shipped = _shipped_hulls(seed, [cm for cm, _ in made]) if (hulls == "vhacd" and target_verts == 8192) else None
         if shipped is not None:
             sets = shipped
-        elif H.vhacd_lib() is not None:
-            from concurrent.futures import ThreadPoolExecutor
-
-            with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-                sets = list(ex.map(lambda m: H._compute_hulls(m[0], False), made))
         else:
-            raise RuntimeError("ycb_like_meshes(hulls='vhacd'): neither shipped hull data for this seed / size nor "
-                               "lib/libslvhacd.so is available; pass hulls='parts' for the by-construction hulls")
+            from concurrent.futures import ProcessPoolExecutor
+
+            with ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+                sets = list(ex.map(_native_hulls, [cm for cm, _ in made]))
     elif hulls != "parts":
-        raise ValueError("hulls must be 'vhacd' or 'parts'")
+        raise ValueError("hulls must be 'vhacd', 'native' or 'parts'")
     out = []
     for i, (name, (cm, _), hs) in enumerate(zip(YCB_CLASSES, made, sets)):
         m = Mesh.from_data(cm, hs, "synthetic://ycb/%s" % name)

@@ -113,30 +113,6 @@ def test_job_queue_returns_scenes_in_submission_order(sl, monkeypatch):
     q.stop()
 
 
-def test_vhacd_is_the_decomposition_behind_hulls_for_mesh(sl):
-    """Mesh::loadPhysics (reference src/mesh.cpp:335-470): with lib/libslvhacd.so (the reference's vendored V-HACD
-    behind our C shim) the bunny decomposes into the reference's 121 hulls / 1 428 vertices WITHOUT the fixture, the
-    cube stays one 8-vertex hull, PHYSICS_FORCE_CONVEX_HULL gives one hull; SURVEY.md 8a row S1."""
-    from stillleben_amd import _loaders, hulls
-
-    if hulls.vhacd_lib() is None:
-        pytest.skip("lib/libslvhacd.so not built on this box (needs /root/reference at build time)")
-    cm = _loaders.load_any(S.BUNNY)
-    hs, info = hulls.vhacd_hulls(cm.positions, cm.indices)
-    assert len(hs) == 121 and sum(len(h.vertices) for h in hs) == 1428 and info["used_decomposition"]
-    assert info["volume_decomposition"] / info["volume_single"] < 0.75
-    assert max(len(h.vertices) for h in hs) <= 64            # VHACD.h:235
-    fx = np.load(S.BUNNY + ".hulls.npz")                      # the committed fixture is this very output
-    assert int(fx["n_hulls"]) == 121 and all(np.array_equal(fx["v%d" % i], hs[i].vertices) for i in range(121))
-    single, info1 = hulls.vhacd_hulls(cm.positions, cm.indices, force_single=True)
-    assert len(single) == 1 and not info1["used_decomposition"]
-    cube = _loaders.load_any(S.CUBE)
-    hc, ic = hulls.vhacd_hulls(cube.positions, cube.indices)
-    assert len(hc) == 1 and len(hc[0].vertices) == 8 and ic["volume_single"] == pytest.approx(8.0)
-    # and hulls_for_mesh routes through it: a copy of the cube WITHOUT fixture / cache next to it
-    assert len(hulls._compute_hulls(cube, False)) == 1
-
-
 def test_hull_fixture_is_rejected_after_a_geometry_edit(sl, tmp_path):
     import shutil
 
