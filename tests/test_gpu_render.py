@@ -101,6 +101,21 @@ def test_hdr_colour_within_1e3_relative(sl, oracle, eng, ssao):
     assert np.array_equal(hdr[..., 3], r[..., 3])             # alpha is exact
 
 
+def test_fronto_parallel_lambert_known_answer(sl, eng):
+    """The analytic radiance of tests/test_oracle_render.py (computed by hand from render_shader.frag:272-373: no oracle involved)
+    on the kernels' float image."""
+    from test_oracle_render import lambert_kat_expected, lambert_kat_scene
+
+    scene = lambert_kat_scene(sl)
+    W, H = scene.viewport
+    bufs = eng.render([scene], _abi.OUT_ALL, ssao=False, shadows=False, keep_hdr=True)
+    torch.cuda.synchronize()
+    hdr = bufs._keepalive[0]["hdr"].view(torch.float32)[: H * W * 4].reshape(H, W, 4).cpu().numpy()
+    want = lambert_kat_expected()
+    assert np.allclose(hdr[H // 2, W // 2, :3], want, rtol=1e-4), (hdr[H // 2, W // 2], want)
+    assert hdr[H // 2, W // 2, 3] == 1.0
+
+
 def test_cube_lookat(sl, oracle, eng):
     scene = S.cube_lookat_scene(sl)
     bufs, ref = both(eng, oracle, [scene])

@@ -90,3 +90,22 @@ def test_ssao_random_stream_is_libstdcxx(golden, oracle):
     st = bits.view(np.float32)
     assert np.array_equal(noise[:, 0], np.float32(2.0) * st[0:32:2] - np.float32(1.0))
     assert g["kernel_size_cpp"] == g["kernel_size"] == 64 and g["lerp"] == [0.1, 1.0] and g["scale_divisor"] == 64.0
+
+
+@pytest.mark.parametrize("rel", ["oracle/synth_ref.c", "stillleben_amd/csrc/slhip_synth.hip", "stillleben_amd/csrc/slhip_records.cpp",
+                                 "stillleben_amd/_shadow.py"])
+def test_shadow_matrix_literals_match_the_reference(golden, rel):
+    """computeFrustumCorners / computeShadowMapMatrix (reference src/render_pass.cpp:69-211) in its four restatements -- the oracle,
+    the placement kernel, the host C++ record builder, the per-scene Python mirror: the frustum's NDC z range and clamp, the
+    light-space z margin (x 5 to both sides of the mean) and the shadow map's size are the reference's."""
+    s = _src(rel)
+    g = golden["shadow_matrix"]
+    assert g["ndc_near_far"] == [-1.0, 1.0] and g["mean_divisor"] == 2.0
+    far_m = _f(r"far\w* = mean_z \+ (?:f32\()?%s\)? \* spread" % NUM, s)
+    near_m = _f(r"near\w* = mean_z - (?:f32\()?%s\)? \* spread" % NUM, s)
+    assert [far_m, near_m] == g["z_margin"]
+    assert _f(r"mean_z = \(near\w* \+ far\w*\) / (?:f32\()?%s" % NUM, s) == g["mean_divisor"]
+    assert _f(r"max\w*\((?:std::)?f?max\w*\((?:f32\()?%s\)?, near_obj\)" % NUM, s) == g["ndc_near_clamp"]
+    from stillleben_amd import _engine
+
+    assert [_engine.SHADOW_RES] * 2 == g["map_size"]

@@ -155,3 +155,76 @@ def test_head_on_collision_conserves_momentum(sl, oracle):
     assert float(v[0] + v[1]) == pytest.approx(0.0, abs=1e-4)
     assert float(v[1] - v[0]) == pytest.approx(0.1 * 3.0, rel=0.35, abs=0.05)       # now separating
     assert np.abs(b["lin_vel"][:, 1:3]).max() < 1e-3 and np.abs(b["ang_vel"]).max() < 0.05
+
+
+def box_mesh(sl, half):
+    """An axis-aligned box with the given half extents (one 8-vertex hull)."""
+    from scipy.spatial import ConvexHull
+
+    from stillleben_amd import _loaders
+    from stillleben_amd.hulls import Hull
+
+    pts = np.array([[sx * half[0], sy * half[1], sz * half[2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], np.float32)
+    faces = ConvexHull(pts.astype(np.float64)).simplices.copy()
+    n = np.cross(pts[faces[:, 1]] - pts[faces[:, 0]], pts[faces[:, 2]] - pts[faces[:, 0]])
+    flip = np.einsum("ij,ij->i", n, pts[faces[:, 0]]) < 0
+    faces[flip] = faces[flip][:, [0, 2, 1]]
+    cm = _loaders.ConsolidatedMesh()
+    cm.positions = pts
+    cm.normals = (pts / np.linalg.norm(pts, axis=1)[:, None]).astype(np.float32)
+    cm.uvs = np.zeros((len(pts), 2), np.float32)
+    cm.colors = np.ones((len(pts), 4), np.float32)
+    cm.indices = np.ascontiguousarray(faces).reshape(-1).astype(np.uint32)
+    cm.textures = []
+    cm._tex_alpha = []
+    cm.materials = [_loaders.Material(base_color=(0.8, 0.8, 0.8, 1))]
+    cm.submeshes = [_loaders.SubMesh(0, len(cm.indices), 0)]
+    return sl.Mesh.from_data(cm, hulls=[Hull(pts, faces.astype(np.int32))], filename="memory://box%g_%g_%g" % tuple(half))
+
+
+@pytest.mark.parametrize("tan_theta,topples", [(0.26, False), (0.30, False), (0.37, True), (0.39, True)])
+def test_tall_box_topples_beyond_its_base_to_height_ratio(sl, oracle, tan_theta, topples):
+    """A box of base half-width a and half-height 3 a on an incline (gravity tilted) topples iff the line of gravity leaves its
+    base: tan(theta) > a / (3 a) = 1/3 -- below the static friction of 0.4, so it does not slide first.  Rigid-body statics: no
+    constant of the solver enters."""
+    a = 0.02
+    th = math.atan(tan_theta)
+    scene = sl.Scene((64, 48))
+    o = sl.Object(box_mesh(sl, (a, a, 3 * a)))
+    scene.add_object(o)
+    o.set_pose(torch.from_numpy(at(0, 0, TABLE + 3 * a + 0.0015)))
+    pool = SB.HullPool()
+    srec, bodies = SB.build_settle_batch([scene], pool, [(True, TABLE)])
+    hulls, verts = pool.arrays()
+    state = (srec, bodies, hulls, verts)
+    step(oracle, state, 30, gravity=(0.0, 0.0, -G * math.cos(th)))         # come to rest on the table first
+    b = step(oracle, state, 150, gravity=(G * math.sin(th), 0.0, -G * math.cos(th)))
+    R = b[0]["pose"].reshape(4, 4)[:3, :3]
+    tilt = math.degrees(math.acos(max(-1.0, min(1.0, float(R[2, 2])))))
+    if topples:
+        assert tilt > 45.0, tilt                                            # it went over
+    else:
+        assert tilt < 1.0 and abs(float(b[0]["pose"][3])) < 2e-3, (tilt, b[0]["pose"][3])      # neither tipped nor slid
+
+
+def test_wall_of_cubes_stands(sl, oracle):
+    """A wall three cubes wide and four high (running bond is not needed: columns side by side with a 1 mm gap) stands for 4 s:
+    persistent manifolds + warm start (PhysX: PCM + eENABLE_STABILIZATION, scene.cpp:156-163)."""
+    h = half_edge()
+    poses = [at((c - 1) * (2 * h + 0.001), 0, TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(4) for c in range(3)]
+    state = build(sl, poses)
+    b = step(oracle, state, 400)
+    z = b["pose"][:, 11]
+    want = np.array([p[2, 3] for p in poses])
+    assert np.allclose(z, want, atol=4e-3), z
+    assert np.abs(b["lin_vel"]).max() < 0.02
+
+
+def test_resting_cube_sleeps_within_a_second(sl, oracle):
+    """A cube set down at rest falls asleep after the 0.4 s wake counter [ext] (plus the few frames its contact needs to stop
+    ringing): asleep, velocities exactly zero, within 100 steps of 10 ms."""
+    h = half_edge()
+    state = build(sl, [at(0, 0, TABLE + h + 0.0015)])
+    b = step(oracle, state, 100)
+    assert b[0]["flags"] & SB.BODY_ASLEEP
+    assert not np.any(b[0]["lin_vel"]) and not np.any(b[0]["ang_vel"])

@@ -276,3 +276,43 @@ def test_gl_comparison_harness_separates_silhouette_from_interior(sl, oracle, tm
     tool = os.path.join(os.path.dirname(__file__), "..", "tools", "compare_gl.py")
     assert subprocess.run([sys.executable, tool, str(tmp_path / "a.npz"), str(tmp_path / "a.npz")], capture_output=True).returncode == 0
     assert subprocess.run([sys.executable, tool, str(tmp_path / "a.npz"), str(tmp_path / "b.npz")], capture_output=True).returncode == 1
+
+
+def lambert_kat_scene(sl, size=(640, 480)):
+    """The cube of reference tests/basic.cpp:375-453 seen from (4, 0, 0): its face x = +1 is fronto-parallel at camera z = 3.
+    ONE directional light shining straight along the view axis (colour 3, no shadows), the object forced to roughness 1 /
+    metallic 0, ambient 0.25."""
+    scene = S.cube_lookat_scene(sl, size)
+    obj = scene.objects[0]
+    obj.metallic, obj.roughness = 0.0, 1.0
+    scene.light_directions = torch.tensor([[-1.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    scene.light_colors = torch.tensor([[3.0, 3.0, 3.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    scene.ambient_light = torch.tensor([0.25, 0.25, 0.25])
+    scene.manual_exposure = 1.0
+    return scene
+
+
+def lambert_kat_expected(albedo=0.8, light=3.0, ambient=0.25):
+    """render_shader.frag:272-373 by hand for N = V = L (the centre of the face): with roughness 1 the GGX lobe is flat
+    (alpha^2 = 1: D = 1 / pi), Smith's G = 1 at N.V = N.L = 1 (k = (1 + 1)^2 / 8 = 1/2: x / (x / 2 + 1/2)), Schlick's term
+    vanishes at normal incidence (F = F0 = 0.04), the specular denominator is 4; kD = 1 - F for a dielectric."""
+    F = 0.04
+    specular = (1.0 / math.pi) * 1.0 * F / 4.0
+    return ((1.0 - F) * albedo / math.pi + specular) * light * 1.0 + ambient * albedo
+
+
+def test_fronto_parallel_lambert_known_answer(sl, oracle):
+    """A radiance that can be computed by hand (no part of it is this repository's choice): the HDR value the fragment
+    shader writes at the centre of a fronto-parallel matte face lit along the view axis."""
+    scene = lambert_kat_scene(sl)
+    r = oracle_render(oracle, [scene], flags=_abi.OUT_ALL, want_hdr=True)
+    W, H = scene.viewport
+    px = r.hdr[0, H // 2, W // 2]
+    want = lambert_kat_expected()
+    assert r.instance[0, H // 2, W // 2, 0] == 1
+    assert np.allclose(px[:3], want, rtol=2e-5), (px, want)          # (the pixel centre is half a pixel off the axis: 1e-6)
+    assert px[3] == 1.0
+    # across the face N.L = 1 stays, N.V falls off with the view angle: the corner of the silhouette is darker by Fresnel / G only
+    cov = r.instance[0, :, :, 0] == 1
+    face = r.hdr[0][cov][:, 0]
+    assert face.max() <= want * (1 + 1e-3) and face.min() > 0.97 * want

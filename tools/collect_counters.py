@@ -79,6 +79,22 @@ def main():
     # 3. SQ counters of the settle kernel (8 SQ slots per pass)
     sq, n_sq = pmc(out, "sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
                                "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"], BENCH + PMC_SHAPE)
+    # LDS pipe and residency (the north star names both): bank conflicts against the cycles the LDS is busy, waves per SIMD =
+    # SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / the SIMDs; a pass of its own (8 SQ slots per pass)
+    try:
+        lds, _ = pmc(out, "lds", ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+                                  "SQ_INST_LEVEL_LDS"], BENCH + PMC_SHAPE)
+    except Exception as e:      # a counter this build of rocprofv3 does not know: say so, keep the rest
+        print("LDS counter pass failed: %r" % (e,), flush=True)
+        lds = {}
+    # the fetch factor once more on a 4 B / lane kernel (the guide's factor 2.0 is quoted for 16 B / lane streams)
+    cal4_cmd = ["python", os.path.join(ROOT, "tools", "pmc_calibrate.py"), "4"]
+    try:
+        cal4_f, _ = pmc(out, "cal4_fetch", ["FETCH_SIZE"], cal4_cmd)
+        f_fac4 = N_CAL / (cal4_f["cal"]["FETCH_SIZE"] * 1024.0)
+    except Exception as e:
+        print("4 B / lane calibration failed: %r" % (e,), flush=True)
+        f_fac4 = None
     sq_cal, _ = pmc(out, "sq_cal", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES"], cal_cmd)
     full = sq_cal["cal"]["SQ_THREAD_CYCLES_VALU"] / sq_cal["cal"]["SQ_ACTIVE_INST_VALU"]   # the ratio of a kernel with all 64 lanes on
     kernels = {}
@@ -110,6 +126,16 @@ def main():
             "wait_any_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c else None,
             "wait_inst_share": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in c else None,
         })
+    for k, c in lds.items():
+        if k == "cal" or k not in kernels:
+            continue
+        kernels[k]["lds"] = {
+            "counters": c,
+            "bank_conflict_share_of_lds_cycles": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
+            # SQ_WAVE_CYCLES counts 4-cycle quads per resident wave, SQ_BUSY_CYCLES the quads the SQ is busy (summed over the XCDs' SQs):
+            # their ratio is the average number of waves resident while the kernel runs; / 1024 SIMDs
+            "waves_resident_avg": (c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CYCLES"]) if c.get("SQ_BUSY_CYCLES") else None,
+        }
     notes = {"active_lanes": "64 x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of the kernel) / (the same ratio of an elementwise kernel with all "
                              "64 lanes on, measured in the same session: %.1f)" % full}
     res = {
@@ -120,8 +146,9 @@ def main():
         },
         "shape": {"scenes_per_settle_launch": batch, "scenes_per_render_launch": chunk},
         "units": "FETCH_SIZE / WRITE_SIZE are KiB; bytes = counter x 1024 x the factor measured on the known-byte kernel",
-        "calibration": {"fetch_factor": f_fac, "write_factor": w_fac,
-                        "expected": "fetch factor 2.0 for 16 B/lane streaming reads (MI355X_MICROARCH.md HBM section), write factor ~1.0"},
+        "calibration": {"fetch_factor": f_fac, "write_factor": w_fac, "fetch_factor_4B_per_lane": f_fac4,
+                        "expected": "fetch factor 2.0 for 16 B/lane streaming reads (MI355X_MICROARCH.md HBM section), write factor ~1.0; "
+                                    "the 16 B / lane factor is the one applied (the kernels' bulk reads are dwordx4)"},
         "notes": notes,
         "kernels": kernels,
     }
