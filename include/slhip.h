@@ -348,7 +348,7 @@ typedef struct {
        every point.  B >= 16: a body pair that touches through more than B hull pairs -- nested concave shapes: a mug in a bowl offers
        several hundred one-point manifolds, one Gauss-Seidel chain of that length -- keeps the B hull pairs with the deepest points
        (ties: list order); the others stay filed as manifolds (no impulse) and return when they are among the deepest.  Counted per
-       (scene, step) by slhip_settle_caps.  On the 20-object workload a budget of 64 leaves the share of bodies at rest, the redrops
+       (scene, step) by slhip_settle_caps.  On the 20-object workload a budget of 32 or 64 leaves the share of bodies at rest, the redrops
        and the deepest penetrations where they are without it.                                            */
     uint32_t pair_contact_budget;
     /* 0: the call starts from a cold contact state (it initialises the scratch).  N > 0: the call CONTINUES the N steps that earlier

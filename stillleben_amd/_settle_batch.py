@@ -42,7 +42,7 @@ assert PARAMS_DTYPE.itemsize == 116
 
 # slhip_settle_params.pair_contact_budget (0: every point goes to the solver, as in PhysX): a body pair touching through more hull
 # pairs keeps the deepest ones -- nested concave shapes otherwise put several hundred one-point manifolds into ONE Gauss-Seidel chain
-PAIR_CONTACT_BUDGET = 64
+PAIR_CONTACT_BUDGET = 32
 
 BODY_STATIC = 1
 BODY_ASLEEP = 2

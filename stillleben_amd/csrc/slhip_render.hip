@@ -709,15 +709,29 @@ struct MainTarget {
     }
 };
 
+#ifndef SLHIP_SHADOW_WINDOW
+#define SLHIP_SHADOW_WINDOW 64     // texels per side of the LDS window of k_shadow_raster (0: every fragment is a global atomic)
+#endif
 struct ShadowTarget {
     unsigned* sm;  // [S,S] float bits
     int W;
+    // per-chunk depth resolve in LDS (the north star's "LDS per-tile bins"): fragments inside the block's window take an LDS
+    // atomic; the window is written to the map once, row by row (k_shadow_raster).  win == nullptr: no window (k_shadow_large)
+    unsigned* win;
+    int wx0, wy0;
     __device__ __forceinline__ void emit(const Setup& t, int px, int py, const float* l) const
     {
         const float z = interp(l, t.z[0], t.z[1], t.z[2]);
         if (!(z >= 0.0f && z <= 1.0f)) return;
-        unsigned* slot = sm + (size_t)py * W + px;
         const unsigned bits = __float_as_uint(z);  // z >= 0: uint order == float order
+#if SLHIP_SHADOW_WINDOW
+        const unsigned ux = (unsigned)(px - wx0), uy = (unsigned)(py - wy0);
+        if (win != nullptr && ux < (unsigned)SLHIP_SHADOW_WINDOW && uy < (unsigned)SLHIP_SHADOW_WINDOW) {
+            atomicMin(win + uy * SLHIP_SHADOW_WINDOW + ux, bits);
+            return;
+        }
+#endif
+        unsigned* slot = sm + (size_t)py * W + px;
         // fire-and-forget: front faces are culled, so almost every fragment wins anyway; a
         // pre-read would only serialise the loop on a memory round trip
         atomicMin(slot, bits);
@@ -1063,29 +1077,64 @@ __global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_shadow_raster(slhip_
     const unsigned tri = ch.first_tri + (have_tri ? threadIdx.x : 0u);
     const unsigned* ip = pool.d_idx + dr->idx_base + 3 * (size_t)tri;
     const unsigned i0 = ip[0], i1 = ip[1], i2 = ip[2];
+#if SLHIP_SHADOW_WINDOW
+    // The chunk's triangles are neighbours on the mesh: most of their fragments fall into one small patch of the map.  A
+    // SLHIP_SHADOW_WINDOW^2-texel window of LDS is placed at the corner of the chunk's pixel boxes; fragments inside it are
+    // resolved there (LDS atomics), and the touched texels go to the map once, 64 consecutive texels per atomic instruction --
+    // the same minimum per texel, whatever the order.
+    constexpr int kWin = SLHIP_SHADOW_WINDOW;
+    __shared__ unsigned win[kWin * kWin];
+    __shared__ int worg[2];
+#endif
     // one block per chunk, the (few) active lights in a loop: the index fetch is shared and no
     // workgroups are launched for lights that are off
     for (int light = 0; light < nl; ++light) {    // (lights beyond the nl maps the caller provided cast no shadow)
-        if (!light_active(sc, light)) continue;
-        if (!have_tri) continue;
+        if (!light_active(sc, light)) continue;   // block-uniform
         const float4* plane = clipbuf + (size_t)(1 + light) * n_clip_verts + dr->clip_base;
         Setup t;
         const uint4* sp = reinterpret_cast<const uint4*>(plane);   // k_vertex_xform stores the light's clip positions as window coordinates
-        if (!setup_from_screen(sp[i0], sp[i1], sp[i2], S, S, t)) continue;
-        if (t.flipped) continue;  // front face culled
-        // tiles of the triangle's pixel box (a 16k-triangle object: almost always one tile, at most a handful)
-        if (words <= kShadowMaxWords) {
-            const int tx0 = t.xmin / kShadowTile, tx1 = t.xmax / kShadowTile, ty0 = t.ymin / kShadowTile, ty1 = t.ymax / kShadowTile;
-            for (int ty = ty0; ty <= ty1; ++ty)
-                for (int tx = tx0; tx <= tx1; ++tx) {
-                    const int tile = ty * tx_n + tx;
-                    atomicOr(&bm[light][tile >> 5], 1u << (tile & 31));
-                }
+        bool draw = have_tri && setup_from_screen(sp[i0], sp[i1], sp[i2], S, S, t);
+        if (draw && t.flipped) draw = false;  // front face culled
+#if SLHIP_SHADOW_WINDOW
+        if (threadIdx.x < 2) worg[threadIdx.x] = 0x7fffffff;
+        for (int k = (int)threadIdx.x; k < kWin * kWin; k += 256) win[k] = 0x3F800000u;      // 1.0: the cleared map
+        __syncthreads();
+        if (draw) { atomicMin(&worg[0], t.xmin); atomicMin(&worg[1], t.ymin); }
+        __syncthreads();
+        const int wx0 = worg[0], wy0 = worg[1];
+#endif
+        if (draw) {
+            // tiles of the triangle's pixel box (a 16k-triangle object: almost always one tile, at most a handful)
+            if (words <= kShadowMaxWords) {
+                const int tx0 = t.xmin / kShadowTile, tx1 = t.xmax / kShadowTile, ty0 = t.ymin / kShadowTile, ty1 = t.ymax / kShadowTile;
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    for (int tx = tx0; tx <= tx1; ++tx) {
+                        const int tile = ty * tx_n + tx;
+                        atomicOr(&bm[light][tile >> 5], 1u << (tile & 31));
+                    }
+            }
+            ShadowTarget tgt;
+            tgt.sm = shadow + ((size_t)ch.scene * nl + light) * S * S;
+            tgt.W = S;
+#if SLHIP_SHADOW_WINDOW
+            tgt.win = win; tgt.wx0 = wx0; tgt.wy0 = wy0;
+#else
+            tgt.win = nullptr; tgt.wx0 = 0; tgt.wy0 = 0;
+#endif
+            raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene | ((unsigned)light << 24), small_area);
         }
-        ShadowTarget tgt;
-        tgt.sm = shadow + ((size_t)ch.scene * nl + light) * S * S;
-        tgt.W = S;
-        raster_or_enqueue(t, tgt, queue, capacity, ch.draw, tri, ch.scene | ((unsigned)light << 24), small_area);
+#if SLHIP_SHADOW_WINDOW
+        __syncthreads();
+        if (wx0 != 0x7fffffff) {
+            unsigned* sm = shadow + ((size_t)ch.scene * nl + light) * S * S;
+            for (int k = (int)threadIdx.x; k < kWin * kWin; k += 256) {
+                const unsigned v = win[k];
+                const int x = wx0 + (k % kWin), y = wy0 + (k / kWin);
+                if (v != 0x3F800000u && x < S && y < S) atomicMin(sm + (size_t)y * S + x, v);
+            }
+        }
+        __syncthreads();
+#endif
     }
     __syncthreads();
     for (int k = (int)threadIdx.x; k < SLHIP_NUM_LIGHTS * words; k += 256) {
@@ -1165,6 +1214,7 @@ __global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_shadow_large(slhip_m
         float l[3];
         if (!coverage(t, px, py, l)) continue;
         ShadowTarget tgt;
+        tgt.win = nullptr; tgt.wx0 = 0; tgt.wy0 = 0;
         tgt.sm = shadow + ((size_t)scene * nl + light) * S * S;
         tgt.W = S;
         tgt.emit(t, px, py, l);

@@ -1749,8 +1749,8 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         // itself, and what counts is how long its chain of launches takes next to the render: ONE scene per wave (up to eight
         // solver waves per CU, half the dependent rows per wave) settles a batch in 0.93 instead of 1.07 s alone and in
         // 1.47 instead of 1.61 s beside the render: 9 511 -> 9 789 scenes/s on one box.  SLHIP_SOLVE_SPW=2: two scenes per wave.
-        int spw = 1;
-        if (const char* e = getenv("SLHIP_SOLVE_SPW")) { spw = atoi(e); if (spw != 2 && spw != 4) spw = 1; }
+        int spw = 2;
+        if (const char* e = getenv("SLHIP_SOLVE_SPW")) { spw = atoi(e); if (spw != 1 && spw != 4) spw = 2; }
         if (spw * SL.total > 160 * 1024) spw = 1;
         // LDS a solver wave asks for: what it needs, or more (SLHIP_SOLVE_LDS_KB) -- the padding is never touched, it only limits how
         // many solver waves a CU takes at a time, i.e. how much of the CU's registers and wave slots the render stream keeps
