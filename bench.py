@@ -304,6 +304,7 @@ def run_other_config(args):
     bc.sl.init_cuda(0)
     cfg = args.config
     if cfg == "C1":
+        bc.c1(64)          # untimed: the process's one-off set-up (asset upload, scratch allocation, code load)
         r = bc.c1(4096)
         ms = r["settle_s_per_batch"] * 1e3 + r["render_ms_per_batch"]
         line = {"metric": "scenes/sec (settle + 320x240 instance-mask render), 4 cubes", "value": 4096 / (ms * 1e-3), "unit": "scenes/s",
@@ -312,6 +313,7 @@ def run_other_config(args):
                                        "physics.settle_batch (host glue included) + one 320x240 instance-mask render launch sequence"},
                 "roofline": None}
     elif cfg == "C3":
+        bc.c1(64)          # untimed: the process's one-off set-up
         r = bc.c3()
         ms = r["settle_s_incl_host_glue"] * 1e3 + r["render_ms"]
         line = {"metric": "scenes/sec (settle + 640x480 6-ch GT render), 512 C2 scenes through the per-object API", "value": 512 / (ms * 1e-3),

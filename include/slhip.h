@@ -255,7 +255,12 @@ int slhip_render(const slhip_mesh_pool* pool,
 int slhip_timing_enable(int on);
 int slhip_render_timings(float* ms_out);
 
-/* Bytes of each scratch buffer for a batch (host helper, no GPU needed).                    */
+/* Bytes of each scratch buffer for a batch (host helper, no GPU needed).  `hdr` is sized for TWO float4 planes per scene: plane 0
+ * = the fragment shader's linear colour (always written when rgb is asked for), plane 1 = the same after ambient occlusion, the
+ * image the tone map consumes -- written ONLY under SLHIP_RENDER_KEEP_HDR (the fused blur + tone-map pass does not materialise it
+ * otherwise; a caller that does not keep it may pass half the size).  Colour parity bar of the path (tests/test_gpu_render.py): the
+ * float image within 1e-3 relative of the CPU restatement; the 8-bit rgb within 1 LSB on all but 1e-4 of the values, never more
+ * than 2 (the tone map's divisions and the blur's exponentials go through the hardware's rcp / exp2).                          */
 int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uint32_t height,
                                uint32_t shadow_res, uint32_t queue_capacity,
                                uint64_t bytes_out[7]);   /* vis, hdr, ao, shadow, queue, lum, shadow_tiles */
