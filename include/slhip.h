@@ -372,7 +372,7 @@ typedef struct {
                                           pair's persistent manifold) is a dense [hulls]^2 table, beyond it an open-addressing hash
                                           table keyed by the hull pair -- same contents, same results                         */
 #ifndef SLHIP_LDS_CONTACTS          /* (build-time tuning knob, results do not depend on it) */
-#define SLHIP_LDS_CONTACTS 96       /* the solver keeps a scene's first contacts of the step in LDS and sweeps the rest from global
+#define SLHIP_LDS_CONTACTS 136      /* the solver keeps a scene's first contacts of the step in LDS and sweeps the rest from global
                                        memory: the list itself has no cap but the scratch's capacity                        */
 #endif
 
