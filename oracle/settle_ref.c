@@ -163,6 +163,7 @@ typedef struct {
 typedef struct {
     /* capacities of the per-step lists (slhip_settle_params.max_hull_pairs_per_scene / max_contacts_per_scene) and bodies */
     int P, C, NB;
+    int G;                               /* groups: NB table groups + min(body pairs, P, 12 NB + 64) (the kernels' wide_g_cap) */
     /* hull pair list */
     int n_hp;
     int *hp_ba, *hp_bb;                  /* [P] bodies */
@@ -204,6 +205,12 @@ static scene_ws* ws_alloc(int P, int C, int NB)
     scene_ws* ws = (scene_ws*)calloc(1, sizeof(scene_ws));
     if (!ws) return NULL;
     ws->P = P; ws->C = C; ws->NB = NB;
+    {
+        long long pairs = (long long)NB * (NB - 1) / 2;
+        if (pairs > P) pairs = P;
+        if (pairs > 12ll * NB + 64) pairs = 12ll * NB + 64;
+        ws->G = NB + (int)pairs;
+    }
     const size_t G = (size_t)P + NB;
     ws->hp_ba = (int*)malloc(sizeof(int) * P); ws->hp_bb = (int*)malloc(sizeof(int) * P);
     ws->hp_ha = (int*)malloc(sizeof(int) * P); ws->hp_hb = (int*)malloc(sizeof(int) * P);
@@ -1313,6 +1320,11 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
                     int k = ws->n_hp++;
                     ws->hp_ba[k] = i; ws->hp_bb[k] = j; ws->hp_ha[k] = (int)ha; ws->hp_hb[k] = (int)hb;
                 }
+            if (ws->n_hp > first && ws->n_groups >= ws->G) { /* no room for another group: the body pair is dropped, counted */
+                ws->hp_overflow = 1;
+                if (pairs_found <= ws->P) pairs_found = ws->P + 1;
+                ws->n_hp = first;
+            }
             if (ws->n_hp > first) {
                 int g = ws->n_groups++;
                 ws->g_a[g] = i; ws->g_b[g] = j;

@@ -357,6 +357,10 @@ def step_scene(scene, plane, **prm_kw):
                 break
     if st is None:
         st = scene._phys_state = SceneState()
+    if len(bodies) == 0:            # nothing to step (PxScene::simulate of an empty scene)
+        st.steps = (st.steps if resume else 0) + int(prm["frames"]) * int(prm["substeps"])
+        st.sig, st.bodies, st.refs = sig, bodies, []
+        return bodies
     if resume:
         # what only the stepper knows about a body travels in the records: wake counter, sleep flag
         keep = st.bodies

@@ -243,3 +243,35 @@ def test_fragment_at_the_far_plane_loses(sl, oracle, eng):
     z = ref.cam_coord[0, :, :, 2]
     assert z[(z < 2000.0)].max() > 9.9995     # the far plane (10 m) is in view ...
     assert (z > 2000.0).any()                 # ... and cuts the plane: background beyond it
+
+
+def test_long_lived_scene_edge_cases(sl):
+    """Scene.simulate on an empty scene, on a scene of static bodies only, after an object was added (cold start), and with a
+    velocity set from outside between two calls (the body wakes, the contact state stays)."""
+    cube = scaled(sl, S.CUBE, 0.1)
+    empty = sl.Scene((64, 48))
+    empty.simulate(0.01)
+    empty.simulate(0.01)
+    assert empty._phys_state.steps == 2
+    st = sl.Scene((64, 48))
+    o = sl.Object(cube)
+    o.static = True
+    st.add_object(o)
+    st.simulate(0.01)
+    st.simulate(0.01)
+    assert np.array_equal(o.pose().numpy(), np.eye(4, dtype=np.float32))
+    free = sl.Object(cube)
+    p = torch.eye(4)
+    p[2, 3] = 0.3
+    free.set_pose(p)
+    st.add_object(free)
+    st.simulate(0.01)
+    assert st._phys_state.steps == 1                         # the scene changed: cold start
+    for _ in range(60):
+        st.simulate(0.01)
+    assert st._phys_state.steps == 61
+    z = float(free.pose()[2, 3])
+    assert 0.058 < z < 0.064                                 # at rest on the static cube: one edge of 0.0577 m + the rest offsets above its centre
+    free.linear_velocity = torch.tensor([0.0, 0.0, 1.0])     # kicked from outside: wakes, keeps the state
+    st.simulate(0.01)
+    assert st._phys_state.steps == 62 and float(free.linear_velocity[2]) > 0.5
