@@ -32,43 +32,26 @@ def _stream(eng):
     return C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
 
 
+def _native():
+    """libstillleben_diff_python: the reference's extension module for these two functions (bridge_diff.cpp:160-180), here
+    pybind11 host C++ over the C-ABI (csrc/py/diff_module.cpp).  No fallback: a missing build is an error."""
+    try:
+        from .lib import libstillleben_diff_python as m
+    except ImportError as e:
+        raise NotImplementedError("stillleben_amd.lib.libstillleben_diff_python is not built (run __graft_entry__.build()): %s" % e)
+    return m
+
+
 def generate_sobel_valid_mask(instance_indices, depth_image):
     """bridge_diff.cpp:13-69: int16[H,W], float[H,W] -> bool[H,W]."""
-    if instance_indices.dim() != 2 or depth_image.dim() != 2:
-        raise ValueError("input tensors should be two-dimensional")
-    if instance_indices.shape != depth_image.shape:
-        raise ValueError("instance_indices and depth_image should be of same height and width")
-    eng = engine()
-    out_dev = instance_indices.device
-    H, W = instance_indices.shape
-    inst = instance_indices.to(eng.device, torch.int16).contiguous()
-    depth = depth_image.to(eng.device, torch.float32).contiguous()
-    valid = torch.empty((H, W), dtype=torch.uint8, device=eng.device)
-    with torch.cuda.device(eng.device):
-        _abi.check(eng.L.slhip_diff_sobel_valid(_p(inst), _p(depth), 1, H, W, _p(valid), _stream(eng)), "slhip_diff_sobel_valid")
-    return valid.bool().to(out_dev)
+    engine()                       # the HIP context of the process (sl.init_cuda): raises when there is none
+    return _native().generate_sobel_valid_mask(instance_indices, depth_image)
 
 
 def dilate_object_mask(object_mask, sobel_valid_mask, coordinates):
     """bridge_diff.cpp:71-157: bool[H,W], bool[H,W], float[H,W,3] -> (bool[H,W], float[H,W,3])."""
-    if object_mask.dim() != 2 or sobel_valid_mask.dim() != 2:
-        raise ValueError("object_mask &  sobel_valid_mask should be two-dimensional")
-    if coordinates.dim() != 3:
-        raise ValueError("coordinates should be three-dimensional")
-    if object_mask.shape != sobel_valid_mask.shape or object_mask.shape != coordinates.shape[:2]:
-        raise ValueError("object_mask, sobel_valid_mask, and coordinates should be of same height and width")
-    eng = engine()
-    out_dev = object_mask.device
-    H, W = object_mask.shape
-    m = object_mask.to(eng.device, torch.uint8).contiguous()
-    v = sobel_valid_mask.to(eng.device, torch.uint8).contiguous()
-    c = coordinates.to(eng.device, torch.float32).contiguous()
-    om = torch.empty((H, W), dtype=torch.uint8, device=eng.device)
-    oc = torch.empty((H, W, 3), dtype=torch.float32, device=eng.device)
-    with torch.cuda.device(eng.device):
-        _abi.check(eng.L.slhip_diff_dilate(_p(m), _p(v), _p(c), int(c.shape[2]), H, W, _p(om), _p(oc), _stream(eng)),
-                   "slhip_diff_dilate")
-    return om.bool().to(out_dev), oc.to(out_dev)
+    engine()
+    return _native().dilate_object_mask(object_mask, sobel_valid_mask, coordinates)
 
 
 def compute_image_space_gradients(scene, render_result):

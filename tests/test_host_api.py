@@ -402,3 +402,23 @@ def test_pools_pin_the_objects_their_caches_are_keyed_by():
     data = np.concatenate(pool.tex)
     for off, i in seen.items():
         assert (data[off:off + 64] == i).all()
+
+
+def test_pybind11_diff_module_is_the_reference_boundary():
+    """python/src/bridge_diff.cpp:160-180: `libstillleben_diff_python` with generate_sobel_valid_mask / dilate_object_mask,
+    importable the way the reference's diff.py:22-30 imports it; argument errors are ValueError (std::invalid_argument) with the
+    reference's texts; without a HIP device a compute call raises (no CPU path)."""
+    import torch
+
+    from stillleben.lib import libstillleben_diff_python as m
+
+    assert callable(m.generate_sobel_valid_mask) and callable(m.dilate_object_mask)
+    with pytest.raises(ValueError, match="two-dimensional"):
+        m.generate_sobel_valid_mask(torch.zeros(4, dtype=torch.int16), torch.zeros(4, 4))
+    with pytest.raises(ValueError, match="same height and width"):
+        m.generate_sobel_valid_mask(torch.zeros(4, 4, dtype=torch.int16), torch.zeros(4, 5))
+    with pytest.raises(ValueError, match="three-dimensional"):
+        m.dilate_object_mask(torch.zeros(4, 4, dtype=torch.bool), torch.zeros(4, 4, dtype=torch.bool), torch.zeros(4, 4))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            m.generate_sobel_valid_mask(torch.zeros(4, 4, dtype=torch.int16), torch.zeros(4, 4))
