@@ -267,6 +267,7 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
         (K.build(sl, [K.at(0, 0, 1.0)], plane=False, vel=[(0.3, -0.2, 0.1)], ang=[(300.0, 0.0, 400.0)]), dict(frames=50, gravity=(0.0, 0.0, 0.0))),
         (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(6)]), dict(frames=400)),   # the column of six: warm start + persistent manifolds
         (K.build(sl, [K.at(-h - 0.02, 0, 1.0), K.at(h + 0.02, 0, 1.0)], plane=False, vel=[(1.5, 0, 0), (-1.5, 0, 0)]), dict(frames=30, dt=0.002, gravity=(0.0, 0.0, 0.0))),
+        (K.build(sl, [K.at((c - 1) * (2 * h + 0.001), 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(4) for c in range(3)]), dict(frames=400)),   # the wall
     ]
     for (srec, bodies, hulls, verts), kw in cases:
         prm = SB.default_params(tabletop=False, dt=kw.get("dt", 0.01), frames=kw["frames"], substeps=1)
@@ -282,19 +283,36 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
         for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "wake_counter"):
             a, b = np.ascontiguousarray(gpu[name]), np.ascontiguousarray(ref[name])
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
+    # the 3 : 1 box on an incline, just beyond its toppling threshold (tan = 0.37 > 1/3): it goes over on the device as well
+    a_ = 0.02
+    th = math.atan(0.37)
+    scene = sl.Scene((64, 48))
+    o = sl.Object(K.box_mesh(sl, (a_, a_, 3 * a_)))
+    scene.add_object(o)
+    o.set_pose(torch.from_numpy(K.at(0, 0, K.TABLE + 3 * a_ + 0.0015)))
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(True, K.TABLE)])
+    prm = SB.default_params(tabletop=False, dt=0.01, frames=180, substeps=1)
+    prm["gravity"] = (K.G * math.sin(th), 0.0, -K.G * math.cos(th))
+    gpu = se.run(srec, bodies.copy(), prm)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    oracle.settle(srec, ref, hulls, verts, prm)
+    assert_bodies_equal(gpu, ref)
+    assert math.degrees(math.acos(max(-1.0, min(1.0, float(gpu[0]["pose"][10]))))) > 45.0
 
 
 def test_solver_wave_packing_and_odd_batches(sl, oracle, monkeypatch):
-    """The lockstep pipeline on a batch of mixed scenes (tabletop settle): one scene per solver wave (default) and two give the
-    oracle's bits, also when the last two-scene solver wave holds a single scene."""
+    """The lockstep pipeline on a batch of mixed scenes (tabletop settle): two cost-sorted scenes per solver wave (default), one
+    and four give the oracle's bits, also when the last multi-scene solver wave holds a single scene."""
     cube = scaled(sl, S.CUBE, 0.15)
     bunny = scaled(sl, S.BUNNY, 0.2)
     scs = [heap(sl, 300 + i, 4 + 3 * i, cube, bunny) for i in range(6)]
     gpu, ref = run_both(oracle, scs, frames=60)
     assert_bodies_equal(gpu, ref)
-    monkeypatch.setenv("SLHIP_SOLVE_SPW", "2")        # two cost-sorted scenes per wave instead of one
-    gpu2s, _ = run_both(oracle, scs, frames=60)
-    assert_bodies_equal(gpu2s, ref)
+    for spw in ("1", "4"):
+        monkeypatch.setenv("SLHIP_SOLVE_SPW", spw)
+        gpu2s, _ = run_both(oracle, scs, frames=60)
+        assert_bodies_equal(gpu2s, ref)
     gpu2, ref2 = run_both(oracle, scs + [heap(sl, 310, 9, cube, bunny)], frames=60)   # odd number: the last solver wave holds one scene
     assert_bodies_equal(gpu2, ref2)
 
