@@ -501,11 +501,11 @@ def main():
             "scenes_whose_contacts_left_the_lds_part": cp["scenes_spilled"], "share_of_scenes_spilled": cp["scenes_spilled"] / args.batch,
             "spill_step_rate": cp["spill_steps"] / scene_steps,
             "most_contacts_in_a_step": cp["max_contacts"], "most_hull_pairs_in_a_step": cp["max_hull_pairs"],
-            "lds_contacts": _header_define("SLHIP_LDS_CONTACTS"),
+            "solver_wave_lds_bytes": 32768,
             "contact_capacity": int(b_last.settle_params["max_contacts_per_scene"]) or _header_define("SLHIP_DEFAULT_CONTACTS"),
             "hull_pair_capacity": int(b_last.settle_params["max_hull_pairs_per_scene"]) or _header_define("SLHIP_DEFAULT_HULL_PAIRS"),
             "note": "one settle of the step's scenes after the timed region (slhip_settle_caps): the solver takes every contact a step "
-                    "offers -- the first `lds_contacts` from LDS, the rest swept from global memory (`spilled`: nothing lost); a "
+                    "offers -- from LDS as far as the scene's solver wave holds them (waves of 1 / 2 / 4 scenes by need), the rest swept from global memory (`spilled`: nothing lost); a "
                     "drop happens only beyond the capacities the scratch was sized with and must be zero"}
     # the exchange step alone: the same shard gathered synchronously after the timed region (inside it the collective runs
     # beside the next chunks' render on its own stream)

@@ -371,10 +371,6 @@ typedef struct {
 #define SLHIP_PAIR_CACHE_DENSE_HULLS 256 /* up to this many convex hulls per scene the pair cache (cached simplex + the way to the
                                           pair's persistent manifold) is a dense [hulls]^2 table, beyond it an open-addressing hash
                                           table keyed by the hull pair -- same contents, same results                         */
-#ifndef SLHIP_LDS_CONTACTS          /* (build-time tuning knob, results do not depend on it) */
-#define SLHIP_LDS_CONTACTS 136      /* the solver keeps a scene's first contacts of the step in LDS and sweeps the rest from global
-                                       memory: the list itself has no cap but the scratch's capacity                        */
-#endif
 
 /* Steps every scene of the batch `frames * substeps` times without a host round trip -- a short sequence of kernel launches per
  * step over the whole batch (broadphase; GJK / portal refinement per hull pair; tilted runs for NEW contact pairs; persistent
@@ -397,7 +393,7 @@ int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
 #define SLHIP_SETTLE_REFUSED_BODIES 1u   /* more bodies than max_bodies_per_scene (or than SLHIP_MAX_BODIES) */
 #define SLHIP_SETTLE_REFUSED_HULLS  2u   /* more hulls than max_hulls_per_scene, or > 1024 in one body */
 /* (below) What the capacities cost since the last cold start on `d_scratch` (synchronises `stream`; same `params` as those calls).
- * counts[0] (scene, step) pairs whose contacts went beyond the solver's LDS-resident part (SLHIP_LDS_CONTACTS: swept from global
+ * counts[0] (scene, step) pairs whose contacts went beyond what the scene's solver wave holds in LDS (swept from global
  * memory, nothing lost), [1] (scene, step) pairs in which contacts beyond max_contacts_per_scene were DROPPED, [2] (scene, step)
  * pairs in which hull pairs beyond max_hull_pairs_per_scene were DROPPED, [3] scenes with a non-zero [1] or [2], [4] scenes whose
  * contacts ever went beyond the LDS-resident part, [5] the most contacts and [6] the most hull pairs a step of any scene offered,

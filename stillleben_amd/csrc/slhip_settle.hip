@@ -24,7 +24,6 @@ static_assert(sizeof(slhip_hull) == 64, "slhip_hull layout");
 static_assert(sizeof(slhip_settle_params) == 116, "slhip_settle_params layout");
 
 constexpr int kMaxContactsPerHP = 4;
-constexpr int kLdsContacts = SLHIP_LDS_CONTACTS;   // the solver's LDS-resident contacts per scene; the rest of the list is swept from global memory
 constexpr float kInf = 3.0e38f;
 constexpr float kDepthWeight = 30.0f;
 
@@ -1192,14 +1191,15 @@ __device__ __forceinline__ void apply_mine(BodyRegs& m, v3 r, v3 J)
     }
 }
 
-// The step's contact list: entries [0, kLdsContacts) live in LDS (`lds`), the rest are read from (and their impulses written to)
+// The step's contact list: entries [0, n_lds) live in LDS (`lds`), the rest are read from (and their impulses written to)
 // the scene's list in global memory (`glb`, indexed like the list): no cap but the capacity of the scratch.
 struct ContactList {
     Contact* lds;
     Contact* glb;
-    __device__ __forceinline__ Contact load(int i) const { return i < kLdsContacts ? lds[i] : glb[i]; }
-    __device__ __forceinline__ Contact* at(int i) const { return i < kLdsContacts ? lds + i : glb + i; }
-    __device__ __forceinline__ float ln(int i) const { return i < kLdsContacts ? lds[i].ln : glb[i].ln; }
+    int n_lds;
+    __device__ __forceinline__ Contact load(int i) const { return i < n_lds ? lds[i] : glb[i]; }
+    __device__ __forceinline__ Contact* at(int i) const { return i < n_lds ? lds + i : glb + i; }
+    __device__ __forceinline__ float ln(int i) const { return i < n_lds ? lds[i].ln : glb[i].ln; }
 };
 
 // (the group lies in the LDS-resident part of the list: every row reads its contact where it needs it -- LDS latency is short, and
@@ -1278,7 +1278,7 @@ __device__ void solve_group(const ContactList ac, int begin, int end, int ia, in
                             bool biased, float plane_mu_s, float plane_mu_d)
 {
     if (begin >= end) return;
-    if (end <= kLdsContacts) { solve_group_lds(ac.lds, begin, end, ia, ib, side, wbs, inv_dt, biased, plane_mu_s, plane_mu_d); return; }
+    if (end <= ac.n_lds) { solve_group_lds(ac.lds, begin, end, ia, ib, side, wbs, inv_dt, biased, plane_mu_s, plane_mu_d); return; }
     const bool has_b = ib >= 0;
     const int mine = side ? ib : ia;
     BodyRegs M;
@@ -1731,36 +1731,28 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         pc.base = reinterpret_cast<int4*>(base);
         pc.stride = D.cache_stride;
         pc.hashed = D.cache_hashed;
-        const WideBufs W = wide_carve(base + settle_cache_bytes(n_scenes, D), n_scenes, nb_cap, D.lh_cap, D.p_cap, D.c_cap);
+        WideBufs W = wide_carve(base + settle_cache_bytes(n_scenes, D), n_scenes, nb_cap, D.lh_cap, D.p_cap, D.c_cap);
         if (((uint64_t)n_scenes << W.pair_bits) > (1ull << 32)) {
             slhip::set_error("slhip_settle: n_scenes x max_hull_pairs_per_scene exceeds the 32-bit work list entries");
             return -1;
         }
         const BeginLds BL = begin_layout(nb_cap, D.lh_cap);
         const FinishLds FL = finish_layout(nb_cap, W.g_cap);
-        const SolveLds SL = solve_layout(nb_cap, W.g_cap);
-        if (BL.total > 160 * 1024 || FL.total > 160 * 1024 || SL.total > 160 * 1024) {
+        // LDS of a solver wave: 32 KB (five waves per CU), more when a scene of the batch's largest shape needs it.  Its quarters and
+        // halves are the wave classes of k_w_finish (SLHIP_SOLVE_SPW = 1 / 2: at most one / two scenes per wave)
+        int solve_lds = 32 * 1024;
+        if (solve_min_lds(nb_cap, W.g_cap) > solve_lds) solve_lds = (solve_min_lds(nb_cap, W.g_cap) + 1023) & ~1023;
+        if (const char* e = getenv("SLHIP_SOLVE_LDS_KB")) { const int kb = atoi(e) * 1024; if (kb >= solve_min_lds(nb_cap, W.g_cap) && kb <= 160 * 1024) solve_lds = kb; }
+        int max_class = 2;
+        if (const char* e = getenv("SLHIP_SOLVE_SPW")) { const int v = atoi(e); max_class = v == 1 ? 0 : v == 2 ? 1 : 2; }
+        W.solve_lds = solve_lds; W.solve_max_class = max_class;
+        if (BL.total > 160 * 1024 || FL.total > 160 * 1024 || solve_lds > 160 * 1024) {
             slhip::set_error("slhip_settle: scenes of %d bodies / %d hulls do not fit the kernels' LDS", nb_cap, D.lh_cap);
             return -1;
         }
-        // Scenes per solver wave.  Two (cost-sorted neighbours side by side, 32 lanes each, same bits) cost a quarter fewer VALU
-        // instructions per scene and won in round 2, when the render stream was the pipeline's critical path and took the issue
-        // slots the solver left (7 730 against 7 370 scenes/s).  Since the end of round 3 the critical path is the settle stream
-        // itself, and what counts is how long its chain of launches takes next to the render: ONE scene per wave (up to eight
-        // solver waves per CU, half the dependent rows per wave) settles a batch in 0.93 instead of 1.07 s alone and in
-        // 1.47 instead of 1.61 s beside the render: 9 511 -> 9 789 scenes/s on one box.  SLHIP_SOLVE_SPW=2: two scenes per wave.
-        int spw = 2;
-        if (const char* e = getenv("SLHIP_SOLVE_SPW")) { spw = atoi(e); if (spw != 1 && spw != 4) spw = 2; }
-        if (spw * SL.total > 160 * 1024) spw = 1;
-        // LDS a solver wave asks for: what it needs, or more (SLHIP_SOLVE_LDS_KB) -- the padding is never touched, it only limits how
-        // many solver waves a CU takes at a time, i.e. how much of the CU's registers and wave slots the render stream keeps
-        int solve_lds = spw * SL.total;
-        if (const char* e = getenv("SLHIP_SOLVE_LDS_KB")) { const int kb = atoi(e) * 1024; if (kb > solve_lds && kb <= 160 * 1024) solve_lds = kb; }
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_begin), hipFuncAttributeMaxDynamicSharedMemorySize, BL.total));
         SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_finish), hipFuncAttributeMaxDynamicSharedMemorySize, FL.total));
-        if (spw == 1) SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, solve_lds));
-        if (spw == 2) SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, solve_lds));
-        if (spw == 4) SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve<4>), hipFuncAttributeMaxDynamicSharedMemorySize, solve_lds));
+        SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_solve), hipFuncAttributeMaxDynamicSharedMemorySize, solve_lds));
         // a resumed call finds everything the prologue would set up -- and the contact state it would clear -- in the scratch
         if (params->resume == 0u) k_w_prologue<<<n_scenes, 64, 0, stream>>>(d_scenes, d_bodies, d_hulls, W, prof_w, pc);
         // the compacted narrowphase passes walk their work lists with a grid stride: enough waves for a step's typical list
@@ -1791,15 +1783,8 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                 if (timed) (void)hipEventRecord(ev[3], stream);
                 k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL, pc, step + 1u);
                 if (timed) (void)hipEventRecord(ev[4], stream);
-                if (spw == 4)
-                    k_w_solve<4><<<(n_scenes + 3) / 4, 64, solve_lds, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
-                                                                                     sub + 1 == params->substeps ? 1 : 0, n_scenes);
-                else if (spw == 2)
-                    k_w_solve<2><<<(n_scenes + 1) / 2, 64, solve_lds, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
-                                                                                     sub + 1 == params->substeps ? 1 : 0, n_scenes);
-                else
-                    k_w_solve<1><<<n_scenes, 64, solve_lds, stream>>>(d_scenes, d_bodies, *params, W, SL, drive_w,
-                                                                      sub + 1 == params->substeps ? 1 : 0, n_scenes);
+                k_w_solve<<<n_scenes, 64, solve_lds, stream>>>(d_scenes, d_bodies, *params, W, drive_w,
+                                                               sub + 1 == params->substeps ? 1 : 0, n_scenes);
                 if (timed) {
                     (void)hipEventRecord(ev[5], stream);
                     for (int k = 0; k < 5; ++k) g_settle_timing.pending.push_back({k, ev[k], ev[k + 1]});
