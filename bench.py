@@ -449,7 +449,7 @@ def main():
     pipe.eng.L.slhip_settle_timings(C.byref(st_ms), C.byref(st_n))     # lockstep kernels: average launch duration inside the timed region
     pipe.eng.L.slhip_settle_timing_enable(0)
     settle_kernels = {n: {"avg_ms_per_launch": float(st_ms[i]), "timed_launches": int(st_n[i])}
-                      for i, n in enumerate(("k_w_begin", "k_w_gjk_first+k_w_gjk_rest", "k_w_gjk_tilt", "k_w_finish", "k_w_solve"))}
+                      for i, n in enumerate(("k_w_begin", "k_w_gjk_first+k_w_gjk_rest", "k_w_manifold", "k_w_finish", "k_w_solve"))}
     t_settle = float(np.mean([r["ev0"].elapsed_time(r["ev1"]) for r in recs]))
     t_stage = float(np.mean([r["t_stage0"].elapsed_time(r["ev0"]) for r in recs]))
     t_place = float(np.mean([r["ev1"].elapsed_time(r["placed"]) for r in recs]))

@@ -373,7 +373,7 @@ typedef struct {
                                           table keyed by the hull pair -- same contents, same results                         */
 
 /* Steps every scene of the batch `frames * substeps` times without a host round trip -- a short sequence of kernel launches per
- * step over the whole batch (broadphase; GJK / portal refinement per hull pair; tilted runs for NEW contact pairs; persistent
+ * step over the whole batch (broadphase; GJK / portal refinement per hull pair; the face manifold of NEW contact pairs and of those that lost a point; persistent
  * manifolds, contact list and colouring; the warm-started 4 + 4 Gauss-Seidel sweeps, integration, sleeping), including the redrop
  * heuristic when params->tabletop.  State that PhysX keeps from step to step lives in the scratch: the cached simplex, the
  * persistent contact manifold and its impulses per hull pair, the table contacts per body -- and stays valid after the call:
@@ -406,7 +406,7 @@ int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_st
 /* Optional live timing of the phases of a lockstep step (bench.py's roofline leg): HIP events on the launch's stream
  * around every phase of every 8th step.  slhip_settle_timings synchronises the recorded events and returns, since the last
  * call, the average duration [ms] and the number of timed launches of 0 k_w_begin (integrate, table contacts, broadphase),
- * 1 k_w_gjk_first + k_w_gjk_rest (the two passes of the main GJK), 2 k_w_gjk_tilt, 3 k_w_finish (manifolds, groups, prep,
+ * 1 k_w_gjk_first + k_w_gjk_rest (the two passes of the main GJK), 2 k_w_manifold (face manifolds), 3 k_w_finish (contact list, groups, prep,
  * colouring, cost class), 4 k_w_solve.                                                                                  */
 int slhip_settle_timing_enable(int on);
 int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5]);

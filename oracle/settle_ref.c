@@ -148,7 +148,7 @@ typedef struct {
 typedef struct {
     int stamp;             /* step that wrote it (1-based); valid for the step after */
     int count;
-    v3 nb;                 /* contact normal in B's object frame */
+    v3 nb;                 /* the contact normal the manifold was BUILT with, in B's object frame */
     v3 la[4], lb[4];       /* contact points in A's / B's object frame */
     float ln[4];           /* accumulated normal impulses at the end of the step */
 } pmanifold;
@@ -277,10 +277,7 @@ static inline v3 support(const shape* s, v3 d)
 /* simplex vertex: w = a - b; idx = vertex of A | vertex of B << 16 (hulls have < 65536 vertices) */
 typedef struct { v3 w, a, b; int idx; } sv;
 
-/* The vertices of a converged simplex.  The tilted runs of the perturbation manifold start from the
-   main run's simplex (same vertex numbers, re-evaluated in the tilted pose) instead of from scratch:
-   the tilt is small, so the closest features are the same or adjacent ones and the run converges
-   in 2-3 iterations instead of 6-7. */
+/* The vertices of a converged simplex: what the pair cache hands the next step's run (temporal coherence). */
 typedef struct gjk_seed_s { int n; int idx[3]; } gjk_seed;
 
 /* closest point to the origin on segment / triangle; returns barycentric weights and the mask
@@ -396,12 +393,7 @@ static int reduce_simplex(sv* s, int n, float* lam, v3* v)
    for any direction v, min over the Minkowski difference of v.x = v.w bounds the distance from
    below by v.w/|v|). */
 #define GJK_MAX_ITER 32
-/* The tilted runs of the perturbation manifold only need a point of each hull near the tilted closest
-   features: after the warm start they get 4 iterations (86 % converge within them; an unconverged
-   witness pair is still a pair of hull points, and the manifold filter below rejects far ones).  Over 96
-   C2 scenes the settled state is statistically the same as with 32 (at rest 0.82, asleep 0.67). */
 static uint64_t* g_stats; /* statistics hook, see slref_settle_set_stats */
-#define GJK_TILT_MAX_ITER 4
 static int g_last_gjk_iters = 0; /* support evaluations of the last run (statistics only) */
 static int gjk_distance_seeded(const shape* A, const shape* B, v3 init_dir, float margin, v3* pa, v3* pb, float* dist,
                                const gjk_seed* seed_in, gjk_seed* seed_out, int max_iter)
@@ -677,60 +669,217 @@ static void fill_contact(contact* c, int a, int b, const wbody* wa, const wbody*
                                     edge of a slightly tilted box has to stay in the manifold as a speculative contact, or the
                                     push-out of the near edge rocks the box for ever) */
 
-/* the four tilted runs of the perturbation manifold around normal n: candidates appended to (cp, cq, cs) */
-static int tilt_candidates(const wbody* wa, const wbody* wb, const slhip_hull* ha, const slhip_hull* hb, const shape* A,
-                           const shape* B, v3 ca, v3 cb, v3 n, float margin, const slhip_settle_params* prm,
-                           const gjk_seed* seed, v3* cp, v3* cq, float* cs, int nc)
+/* ------------------------------------------------------------------------------------------ */
+/* Face manifold of a hull pair in ONE step (PhysX: PCM full contact generation -- the incident polygon clipped against the     */
+/* reference polygon, <= 4 points kept [ext]; scene.cpp:156-163 runs PhysX with its default PCM narrowphase).  Hulls are vertex */
+/* clouds here, so the two polygons are the hulls' SUPPORT FEATURES along the contact normal n (from B to A): the vertices      */
+/* within a band of the hull's extreme vertex along n, reduced to the <= 8 of them that are extreme in eight tangent            */
+/* directions 45 degrees apart -- an ordered (counter-clockwise about n) convex polygon inscribed in the feature, exact for      */
+/* triangles, rectangles and every polygon whose vertices each own one of the directions; a segment or a point for edge and      */
+/* vertex features.  In tangent coordinates (u along t1, w along t2, h along n) the clipped polygon's corners are               */
+/*   (i)   vertices of A's polygon inside B's      (height on B from B's polygon plane),                                        */
+/*   (ii)  vertices of B's polygon inside A's      (height on A from A's polygon plane),                                        */
+/*   (iii) crossings of an edge of A with an edge of B (heights along the two edges).                                           */
+/* Every candidate has a fixed number -- 0..3 the points the pair's manifold kept from the previous step (with their impulses),  */
+/* 4 the closest-point (deepest-point) pair, 5 + (i: 0..7, ii: 8..15, iii: 16 + 8 i + j) the clipped corners -- and the four     */
+/* that stay are chosen by the rule of reduce4 (the deepest, the farthest from it, the two area extremes) as arg-min / arg-max   */
+/* over (value, number), the lower number winning ties: independent of the order of evaluation (the kernel spreads the           */
+/* candidates over sixteen lanes).                                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+#define FM_BAND_OFFSETS 1.0f     /* thickness of a support feature in contact offsets ... */
+#define FM_BAND_EXTENT 0.25f     /* ... and at most this share of the hull's extent along n (a thin piece of a shell must not offer both sides) */
+#define FM_AREA_MIN 1.0e-6f      /* twice the area [m^2] below which a polygon counts as a segment or a point (nothing is "inside") */
+#define FM_INSIDE_TOL 1.0e-6f    /* a vertex this far [m^2: edge length x distance] outside an edge still counts as inside */
+#define FM_PARALLEL2 1.0e-6f     /* edges whose sin^2 of the enclosed angle is below this do not cross (the vertices cover aligned shapes) */
+#define FM_DEEPER_OFFSETS 0.05f  /* the closest-point pair joins only when it is deeper than every other candidate by this many contact
+                                    offsets -- and a manifold whose points are all shallower than that no longer holds the pair's deepest
+                                    feature: it is rebuilt */
+#define FM_DEEP_OFFSETS 2.5f     /* no clipped corners for hulls that overlap by more than this many contact offsets */
+#define FM_CANDIDATES 85
+typedef struct { float u[8], w[8], h[8]; float nu, nw, nh, cu, cw, ch; } fm_poly;
+static uint64_t* g_fm_stats = NULL; /* [8]: manifolds built for new pairs, rebuilt, kept; points of the built ones; closest-point pairs that joined */
+void slref_settle_set_fm_stats(uint64_t* h) { g_fm_stats = h; }
+
+static void fm_feature(const shape* S, v3 n, v3 t1, v3 t2, int lowest, float band, fm_poly* P)
 {
-    int tilt_a = ha->sphere[3] <= hb->sphere[3];
-    float radius = tilt_a ? ha->sphere[3] : hb->sphere[3];
-    float ang = 2.0f * prm->contact_offset / radius; /* lifts the far rim by ~ the contact band */
-    if (ang > 0.2f) ang = 0.2f;
-    float lift = radius * ang;
-    float sh = 0.5f * ang;               /* sin(ang/2) ~ ang/2 */
-    float ch = sqrtf(1.0f - sh * sh);
+    const v3 nl = m3_tmul(&S->R, n), l1 = m3_tmul(&S->R, t1), l2 = m3_tmul(&S->R, t2);
+    const float on = dot(S->t, n), o1 = dot(S->t, t1), o2 = dot(S->t, t2);
+    float lo = 0.0f, hi = 0.0f;
+    for (int i = 0; i < S->count; ++i) {
+        const float h = dot(V(S->verts[4 * i], S->verts[4 * i + 1], S->verts[4 * i + 2]), nl) + on;
+        if (i == 0 || h < lo) lo = h;
+        if (i == 0 || h > hi) hi = h;
+    }
+    const float ext = lowest ? lo : hi;
+    if (band > FM_BAND_EXTENT * (hi - lo)) band = FM_BAND_EXTENT * (hi - lo);
+    float best[8];
+    int have = 0;
+    for (int i = 0; i < S->count; ++i) {
+        const v3 v = V(S->verts[4 * i], S->verts[4 * i + 1], S->verts[4 * i + 2]);
+        const float h = dot(v, nl) + on;
+        if (lowest ? h > ext + band : h < ext - band) continue;
+        const float u = dot(v, l1) + o1, w = dot(v, l2) + o2;
+        float s[8];
+        s[0] = u; s[1] = u + w; s[2] = w; s[3] = w - u;
+        s[4] = -s[0]; s[5] = -s[1]; s[6] = -s[2]; s[7] = -s[3];
+        for (int k = 0; k < 8; ++k)
+            if (!have || s[k] > best[k]) { best[k] = s[k]; P->u[k] = u; P->w[k] = w; P->h[k] = h; }
+        have = 1;
+    }
+    /* plane of the polygon (Newell, relative to slot 0) through the mean of its slots */
+    float nu = 0.0f, nw = 0.0f, nh = 0.0f, su = 0.0f, sw = 0.0f, sh = 0.0f;
+    for (int k = 0; k < 8; ++k) {
+        const int k1 = (k + 1) & 7;
+        const float au = P->u[k] - P->u[0], aw = P->w[k] - P->w[0], ah = P->h[k] - P->h[0];
+        const float bu = P->u[k1] - P->u[0], bw = P->w[k1] - P->w[0], bh = P->h[k1] - P->h[0];
+        nu = nu + (aw * bh - ah * bw);
+        nw = nw + (ah * bu - au * bh);
+        nh = nh + (au * bw - aw * bu);
+        su = su + au; sw = sw + aw; sh = sh + ah;
+    }
+    P->nu = nu; P->nw = nw; P->nh = nh;
+    P->cu = su * 0.125f; P->cw = sw * 0.125f; P->ch = sh * 0.125f;
+}
+
+static inline float fm_plane_h(const fm_poly* P, float u, float w)
+{
+    const float du = (u - P->u[0]) - P->cu, dw = (w - P->w[0]) - P->cw;
+    return (P->h[0] + P->ch) - (P->nu * du + P->nw * dw) / P->nh;
+}
+
+static inline int fm_inside(const fm_poly* Q, float u, float w)
+{
+    if (!(Q->nh > FM_AREA_MIN)) return 0;
+    for (int k = 0; k < 8; ++k) {
+        const int k1 = (k + 1) & 7;
+        const float eu = Q->u[k1] - Q->u[k], ew = Q->w[k1] - Q->w[k];
+        const float cr = eu * (w - Q->w[k]) - ew * (u - Q->u[k]);
+        if (cr < -FM_INSIDE_TOL) return 0;
+    }
+    return 1;
+}
+
+/* clipped corner c (0..79) -> (u, w, hA, hB); returns 0 when it does not exist */
+static int fm_corner(const fm_poly* A, const fm_poly* B, int c, float* u, float* w, float* ha, float* hb)
+{
+    if (c < 8) {
+        *u = A->u[c]; *w = A->w[c]; *ha = A->h[c];
+        if (!fm_inside(B, *u, *w)) return 0;
+        *hb = fm_plane_h(B, *u, *w);
+        return 1;
+    }
+    if (c < 16) {
+        *u = B->u[c - 8]; *w = B->w[c - 8]; *hb = B->h[c - 8];
+        if (!fm_inside(A, *u, *w)) return 0;
+        *ha = fm_plane_h(A, *u, *w);
+        return 1;
+    }
+    const int i = (c - 16) >> 3, j = (c - 16) & 7, i1 = (i + 1) & 7, j1 = (j + 1) & 7;
+    const float eau = A->u[i1] - A->u[i], eaw = A->w[i1] - A->w[i];
+    const float ebu = B->u[j1] - B->u[j], ebw = B->w[j1] - B->w[j];
+    const float den = eau * ebw - eaw * ebu;
+    const float la = eau * eau + eaw * eaw, lb = ebu * ebu + ebw * ebw;
+    if (!(den * den > FM_PARALLEL2 * (la * lb))) return 0;
+    const float du = B->u[j] - A->u[i], dw = B->w[j] - A->w[i];
+    const float s = (du * ebw - dw * ebu) / den, t = (du * eaw - dw * eau) / den;
+    if (!(s >= 0.0f && s <= 1.0f && t >= 0.0f && t <= 1.0f)) return 0;
+    *u = fmaf(s, eau, A->u[i]); *w = fmaf(s, eaw, A->w[i]);
+    *ha = fmaf(s, A->h[i1] - A->h[i], A->h[i]);
+    *hb = fmaf(t, B->h[j1] - B->h[j], B->h[j]);
+    return 1;
+}
+
+/* Builds the pair's manifold: <= 4 points (cp on A, cq on B, separation cs, carried impulse cw); returns their number.
+   (op, oq, os, ow)[no]: the points the previous manifold kept; (pa, pb, sep_new): the closest-point / deepest-point pair --
+   no pair of points of the two hulls is closer (deeper) than it: a clipped corner's separation below it is an artefact of
+   the plane fit and is raised to it. */
+static int face_manifold(const shape* A, const shape* B, v3 n, float margin, float dup2, const slhip_settle_params* prm,
+                         int no, const v3* op, const v3* oq, const float* os, const float* ow, v3 pa, v3 pb, float sep_new,
+                         v3* cp, v3* cq, float* cs, float* cw, int* gjk_joined)
+{
     v3 t1, t2;
     tangents(n, &t1, &t2);
-    const wbody* wt = tilt_a ? wa : wb;
+    fm_poly PA, PB;
+    const float band = FM_BAND_OFFSETS * prm->contact_offset;
+    fm_feature(A, n, t1, t2, 1, band, &PA);
+    fm_feature(B, n, t1, t2, 0, band, &PB);
+    float cu[FM_CANDIDATES], cv[FM_CANDIDATES], cha[FM_CANDIDATES], chb[FM_CANDIDATES], csep[FM_CANDIDATES], cimp[FM_CANDIDATES];
+    int ok[FM_CANDIDATES];
+    /* 0..3 the kept points, 4 the closest points: in tangent coordinates like the corners */
+    for (int c = 0; c < 5; ++c) {
+        ok[c] = c < no || c == 4;
+        const v3 a = c < 4 ? (c < no ? op[c] : V(0, 0, 0)) : pa;
+        cu[c] = dot(a, t1); cv[c] = dot(a, t2); cha[c] = dot(a, n);
+        csep[c] = c < 4 ? (c < no ? os[c] : 0.0f) : sep_new;
+        chb[c] = cha[c] - csep[c];
+        cimp[c] = c < no ? ow[c] : 0.0f;
+    }
+    float cmin = 3.0e38f;
+    for (int c = 0; c < no; ++c) if (csep[c] < cmin) cmin = csep[c];
+    /* hulls that overlap deeper than their support features reach have no face manifold: the kept points and the deepest points */
+    const int deep = sep_new < -FM_DEEP_OFFSETS * prm->contact_offset;
+    for (int c = 5; c < FM_CANDIDATES; ++c) {
+        cimp[c] = 0.0f;
+        ok[c] = deep ? 0 : fm_corner(&PA, &PB, c - 5, &cu[c], &cv[c], &cha[c], &chb[c]);
+        if (!ok[c]) continue;
+        float sep = cha[c] - chb[c];
+        if (sep < sep_new) { sep = sep_new; chb[c] = cha[c] - sep; }
+        csep[c] = sep;
+        if (sep > margin) { ok[c] = 0; continue; }
+        if (sep < cmin) cmin = sep;
+    }
+    /* the closest points join when nothing else is there, or when they are deeper than everything else */
+    int any = 0;
+    for (int c = 0; c < FM_CANDIDATES; ++c) if (c != 4 && ok[c]) any = 1;
+    ok[4] = !any || sep_new < cmin - FM_DEEPER_OFFSETS * prm->contact_offset;
+    *gjk_joined = ok[4];
+    /* a corner that coincides with a kept point or with the closest points is dropped (the kept point has the impulse) */
+    for (int c = 5; c < FM_CANDIDATES; ++c) {
+        if (!ok[c]) continue;
+        for (int k = 0; k < 5; ++k) {
+            if (!ok[k]) continue;
+            const float du = cu[c] - cu[k], dw = cv[c] - cv[k], dh = cha[c] - cha[k];
+            if (fmaf(dh, dh, fmaf(dw, dw, du * du)) < dup2) ok[c] = 0;
+        }
+    }
+    /* the deepest */
+    int i0 = -1;
+    for (int c = 0; c < FM_CANDIDATES; ++c) if (ok[c] && (i0 < 0 || csep[c] < csep[i0])) i0 = c;
+    /* the farthest from it (not a duplicate of it), a metre of extra separation costing DEPTH_WEIGHT metres of reach */
+    int i1 = -1; float best = 0.0f;
+    for (int c = 0; c < FM_CANDIDATES; ++c) {
+        if (!ok[c] || c == i0) continue;
+        const float du = cu[c] - cu[i0], dw = cv[c] - cv[i0], dh = cha[c] - cha[i0];
+        const float d2 = fmaf(dh, dh, fmaf(dw, dw, du * du));
+        if (d2 < dup2) continue;
+        const float score = sqrtf(d2) - DEPTH_WEIGHT * (csep[c] - csep[i0]);
+        if (i1 < 0 || score > best) { best = score; i1 = c; }
+    }
+    int i2 = -1, i3 = -1;
+    if (i1 >= 0) {
+        const float eu = cu[i1] - cu[i0], ew = cv[i1] - cv[i0];
+        const float el = sqrtf(fmaf(ew, ew, eu * eu));
+        float mx = 0.0f, mn = 0.0f;
+        for (int c = 0; c < FM_CANDIDATES; ++c) {
+            if (!ok[c] || c == i0 || c == i1) continue;
+            const float a = eu * (cv[c] - cv[i0]) - ew * (cu[c] - cu[i0]);
+            const float pen = DEPTH_WEIGHT * (csep[c] - csep[i0]) * el;
+            if (a - pen > mx) { mx = a - pen; i2 = c; }
+            if (a + pen < mn) { mn = a + pen; i3 = c; }
+        }
+    }
+    const int sel[4] = {i0, i1, i2, i3};
+    int nc = 0;
     for (int k = 0; k < 4; ++k) {
-        v3 ax = (k == 0) ? t1 : (k == 1) ? t2 : (k == 2) ? neg(t1) : neg(t2);
-        quat dq = {ax.x * sh, ax.y * sh, ax.z * sh, ch};
-        quat q2 = quat_normalize(quat_mul(dq, wt->q));
-        shape T = tilt_a ? *A : *B;
-        quat_to_m3(q2, &T.R);
-        /* rotate about the shape's bounding-sphere centre so that the tilt is local */
-        v3 cl = tilt_a ? V(ha->sphere[0], ha->sphere[1], ha->sphere[2]) : V(hb->sphere[0], hb->sphere[1], hb->sphere[2]);
-        v3 cw = tilt_a ? ca : cb;
-        /* ... and back the tilted shape off along the normal by the rim lift so that the tilt
-           cannot create an overlap; separations are re-measured in the untilted pose below */
-        cw = madd(cw, n, tilt_a ? lift : -lift);
-        T.t = sub(cw, m3_mul(&T.R, cl));
-        v3 qa, qb;
-        float d2;
-        int ok = tilt_a ? gjk_distance_seeded(&T, B, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, NULL, GJK_TILT_MAX_ITER)
-                        : gjk_distance_seeded(A, &T, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, NULL, GJK_TILT_MAX_ITER);
-        if (g_stats) g_stats[1088 + (g_last_gjk_iters > 7 ? 7 : g_last_gjk_iters)]++; /* [1088, 1096): iterations of the tilt runs */
-        if (ok != 1) continue;
-        /* map the witness on the tilted shape back to the untilted pose */
-        if (tilt_a) {
-            v3 loc = m3_tmul(&T.R, sub(qa, T.t));
-            qa = add(m3_mul(&A->R, loc), A->t);
-        } else {
-            v3 loc = m3_tmul(&T.R, sub(qb, T.t));
-            qb = add(m3_mul(&B->R, loc), B->t);
+        const int c = sel[k];
+        if (c < 0) continue;
+        if (c < 4) { cp[nc] = op[c]; cq[nc] = oq[c]; }
+        else if (c == 4) { cp[nc] = pa; cq[nc] = pb; }
+        else {
+            const v3 base = madd(scale(t1, cu[c]), t2, cv[c]);
+            cp[nc] = madd(base, n, cha[c]); cq[nc] = madd(base, n, chb[c]);
         }
-        float s = dot(sub(qa, qb), n);
-        if (s > margin) continue;
-        /* lateral offset between the two witnesses must be small, else it is not a contact */
-        v3 lat = sub(sub(qa, qb), scale(n, s));
-        if (dot(lat, lat) > 4.0f * margin * margin) continue;
-        int dup = 0;
-        for (int j = 0; j < nc; ++j) {
-            v3 dd = sub(cp[j], qa);
-            if (dot(dd, dd) < 2.5e-3f * radius * radius) dup = 1;
-        }
-        if (dup) continue;
-        cp[nc] = qa; cq[nc] = qb; cs[nc] = s; ++nc;
+        cs[nc] = csep[c]; cw[nc] = cimp[c]; ++nc;
     }
     return nc;
 }
@@ -758,7 +907,7 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     float e = 0.5f * (bodies[ia].restitution + bodies[ib].restitution);
     gjk_seed seed;
     pmanifold prev;
-    prev.count = 0;
+    memset(&prev, 0, sizeof(prev));
     if (pm && pm->stamp == step - 1) prev = *pm;
     /* what a pair keeps from step to step lives as long as the pair stays a broadphase candidate (PhysX destroys a pair's contact
        manager and cache when its bounds stop overlapping [ext]): a pair that was not listed in the previous step starts cold */
@@ -772,8 +921,8 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     const float radius = ha->sphere[3] <= hb->sphere[3] ? ha->sphere[3] : hb->sphere[3];
     const float dup2 = 2.5e-3f * radius * radius;
 
-    v3 cp[5], cq[5];
-    float cs[5], cw[5];
+    v3 cp[4], cq[4];
+    float cs[4], cw[4];
     int nc = 0;
     float sep_new;
     if (code == 0) {
@@ -786,38 +935,43 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
         n = scale(sub(pa, pb), 1.0f / dist);
         sep_new = dist;
     }
-    if (prev.count == 0 && code == 1) {
-        /* a NEW contact pair: the closest-point pair + four tilted runs give its first manifold */
-        cp[0] = pa; cq[0] = pb; cs[0] = dist;
-        nc = tilt_candidates(wa, wb, ha, hb, &A, &B, ca, cb, n, margin, prm, &seed, cp, cq, cs, 1);
-        for (int j = 0; j < nc; ++j) cw[j] = 0.0f;
+    v3 built_nb = m3_tmul(&wb->R, n);   /* a manifold built in this step is filed with this step's normal */
+    /* the previous step's points in the new poses: separations along the new normal; a point whose witnesses drifted apart
+       laterally, or that left the contact band, is lost -- all of them when the normal turned by more than 10 degrees against B
+       since the manifold was built */
+    v3 op[4], oq[4];
+    float os[4], ow[4];
+    int no = 0, lost = 0;
+    if (prev.count > 0) {
+        const float lim = DRIFT_OFFSETS * prm->contact_offset;
+        float omin = 3.0e38f;
+        if (dot(n, m3_mul(&wb->R, prev.nb)) >= NORMAL_COS)
+            for (int i = 0; i < prev.count; ++i) {
+                v3 qa = add(m3_mul(&wa->R, prev.la[i]), wa->t);
+                v3 qb = add(m3_mul(&wb->R, prev.lb[i]), wb->t);
+                v3 d = sub(qa, qb);
+                float sp = dot(d, n);
+                if (sp > margin) continue;
+                v3 lat = sub(d, scale(n, sp));
+                if (dot(lat, lat) > lim * lim) continue;
+                op[no] = qa; oq[no] = qb; os[no] = sp; ow[no] = prev.ln[i]; ++no;
+                if (sp < omin) omin = sp;
+            }
+        /* ... and the manifold no longer holds the pair's deepest feature when the closest points are deeper than all of it */
+        lost = no < prev.count || sep_new < omin - FM_DEEPER_OFFSETS * prm->contact_offset;
+    }
+    if (prev.count == 0 || lost) {
+        /* a NEW contact pair, or one whose manifold lost a point: the face manifold in one step -- the points that stayed (with
+           their impulses), the clipped support features, the closest points when they are deeper than all of those */
+        int joined = 0;
+        nc = face_manifold(&A, &B, n, margin, dup2, prm, no, op, oq, os, ow, pa, pb, sep_new, cp, cq, cs, cw, &joined);
+        if (g_fm_stats) { g_fm_stats[prev.count == 0 ? 0 : 1]++; g_fm_stats[3] += (uint64_t)nc; g_fm_stats[4] += (uint64_t)joined; }
     } else {
-        /* refresh the previous step's points in the new poses: separations along the new normal; a point whose witnesses
-           drifted apart laterally, or that left the contact band, is dropped */
-        if (prev.count > 0) {
-            v3 npw = m3_mul(&wb->R, prev.nb);
-            const float lim = DRIFT_OFFSETS * prm->contact_offset;
-            if (dot(n, npw) >= NORMAL_COS)
-                for (int i = 0; i < prev.count; ++i) {
-                    v3 qa = add(m3_mul(&wa->R, prev.la[i]), wa->t);
-                    v3 qb = add(m3_mul(&wb->R, prev.lb[i]), wb->t);
-                    v3 d = sub(qa, qb);
-                    float sp = dot(d, n);
-                    if (sp > margin) continue;
-                    v3 lat = sub(d, scale(n, sp));
-                    if (dot(lat, lat) > lim * lim) continue;
-                    cp[nc] = qa; cq[nc] = qb; cs[nc] = sp; cw[nc] = prev.ln[i]; ++nc;
-                }
-        }
-        /* the new closest-point (or deepest-point) pair: replaces the old point it coincides with (which keeps its impulse),
-           else joins as a fifth candidate */
-        int dup = -1;
-        for (int j = 0; j < nc && dup < 0; ++j) {
-            v3 dd = sub(cp[j], pa);
-            if (dot(dd, dd) < dup2) dup = j;
-        }
-        if (dup >= 0) { cp[dup] = pa; cq[dup] = pb; cs[dup] = sep_new; }
-        else { cp[nc] = pa; cq[nc] = pb; cs[nc] = sep_new; cw[nc] = 0.0f; ++nc; }
+        /* the manifold as it was built, its points where the bodies carried them */
+        if (g_fm_stats) g_fm_stats[2]++;
+        for (int i = 0; i < no; ++i) { cp[i] = op[i]; cq[i] = oq[i]; cs[i] = os[i]; cw[i] = ow[i]; }
+        nc = no;
+        built_nb = prev.nb;
     }
     int keep[4];
     int nk = reduce4(nc, cp, cs, n, keep);
@@ -835,7 +989,7 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     }
     if (pm) {
         pm->count = nk;
-        pm->nb = m3_tmul(&wb->R, n);
+        pm->nb = built_nb;
     }
     return mins;
 }

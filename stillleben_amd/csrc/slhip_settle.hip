@@ -7,8 +7,9 @@
 //     bodies      -> force integration, pose integration, sleep bookkeeping
 //     body pairs  -> bounding-sphere broadphase, survivors compacted IN ORDER with a
 //                    wave ballot + popcount prefix (no atomics, deterministic)
-//     hull pairs  -> GJK distance (portal refinement when the hulls overlap); NEW contact pairs get 4 tilted GJK runs for their
-//                    first manifold, the others refresh the persistent manifold the previous step filed
+//     hull pairs  -> GJK distance (portal refinement when the hulls overlap); a contact pair that is new or whose manifold lost a
+//                    point gets its face manifold in one step (the two support features clipped against each other), the others
+//                    keep the manifold the previous step filed, its points refreshed
 //     groups      -> warm-started Gauss-Seidel contact solve, one colour at a time (groups of one colour
 //                    touch disjoint bodies, so lanes never race on a body's velocity)
 // Only + - * / sqrt and explicit fmaf are used and every reduction has a fixed order, so the
@@ -227,7 +228,7 @@ __device__ __forceinline__ v3 support(const Shape& s, const f3* __restrict__ hv,
 // simplex vertex: w = a - b; idx = vertex of A | vertex of B << 16
 struct SV { v3 w, a, b; int idx; };
 
-// vertices of a converged simplex: the tilted runs start from the main run's simplex (oracle gjk_seed)
+// vertices of a converged simplex (oracle gjk_seed): what the pair cache hands the next step.s run
 struct GjkSeed { int n; int i0, i1, i2; };
 static_assert(sizeof(GjkSeed) == 16, "GjkSeed is stored as one int4");
 
@@ -367,7 +368,6 @@ __device__ int reduce_simplex(Simplex& S, v3* v)
 }
 
 constexpr int kGjkMaxIter = 32;
-constexpr int kGjkTiltMaxIter = 4;   // oracle GJK_TILT_MAX_ITER: tilt runs after the warm start
 
 __device__ __forceinline__ bool same_w(const SV& a, const SV& b)
 {
@@ -608,149 +608,40 @@ __device__ __forceinline__ void make_shape(const WBody& wb, const HullRef& h, co
     s.t = wb.t;
 }
 
-// Manifold reduction over five FIXED candidate slots (slot 0 = the GJK witness pair, slots 1..4 =
-// the four tilt runs, in order) with a validity mask -- the register-resident equivalent of the
-// oracle's reduce4 over its compacted candidate list (same order, same first-index tie breaks).
-struct Cand5 {
-    v3 p[5], q[5];
-    float s[5];
-    float w[5];           // carried impulse of the candidate
-    unsigned ok;          // validity mask, bit j = slot j
-};
-
-// Selections are written component by component on VALUES: a conditional copy of a whole v3
-// (`cond ? a : b`, or a struct store under a branch) is lowered to a copy through a selected POINTER,
-// which pins Cand5 / RawContacts in scratch memory -- a global-memory round trip per move.
+// Selections are written component by component on VALUES: a conditional copy of a whole v3 (`cond ? a : b`, or a struct store under
+// a branch) is lowered to a copy through a selected POINTER, which pins the structs in scratch memory.
 __device__ __forceinline__ v3 vsel(bool c, v3 a, v3 b) { return V(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 
-__device__ __forceinline__ v3 pick_p(const Cand5& c, int i)
-{
-    v3 r = c.p[0];
-#pragma unroll
-    for (int j = 1; j < 5; ++j) r = vsel(j == i, c.p[j], r);
-    return r;
-}
-__device__ __forceinline__ v3 pick_q(const Cand5& c, int i)
-{
-    v3 r = c.q[0];
-#pragma unroll
-    for (int j = 1; j < 5; ++j) r = vsel(j == i, c.q[j], r);
-    return r;
-}
-__device__ __forceinline__ float pick_s(const Cand5& c, int i)
-{
-    float r = c.s[0];
-#pragma unroll
-    for (int j = 1; j < 5; ++j) r = j == i ? c.s[j] : r;
-    return r;
-}
-__device__ __forceinline__ float pick_w(const Cand5& c, int i)
-{
-    float r = c.w[0];
-#pragma unroll
-    for (int j = 1; j < 5; ++j) r = j == i ? c.w[j] : r;
-    return r;
-}
-
-__device__ __forceinline__ void emit(RawContacts& out, int& k, const Cand5& c, int i)
-{
-    const v3 pp = pick_p(c, i), qq = pick_q(c, i);
-    const float ss = pick_s(c, i), ww = pick_w(c, i);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        out.pa[t] = vsel(t == k, pp, out.pa[t]);
-        out.pb[t] = vsel(t == k, qq, out.pb[t]);
-        out.sep[t] = t == k ? ss : out.sep[t];
-        out.w[t] = t == k ? ww : out.w[t];
-    }
-    ++k;
-}
-
-// (always inlined BEFORE the optimiser runs: optimised on its own, its value selections over `c` would be
-// folded into loads through a selected address, which keeps Cand5 in scratch once inlined)
-__device__ __forceinline__ float reduce_candidates(const Cand5& c, v3 nrm, RawContacts& out)
-{
-    int n = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) n += (int)((c.ok >> j) & 1u);
-    int k = 0;
-    float mins = kInf;
-    if (n <= 4) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-            if ((c.ok >> j) & 1u) { emit(out, k, c, j); if (c.s[j] < mins) mins = c.s[j]; }
-        out.count = k;
-        return mins;
-    }
-    // all five valid: the winners are carried as VALUES (index + point + separation) while the fixed
-    // slots are scanned -- no run-time indexed reads of `c`; same comparisons, same first-index ties
-    int i0 = 0;
-    float s0 = c.s[0], w0 = c.w[0];
-    v3 p0 = c.p[0], q0 = c.q[0];
-#pragma unroll
-    for (int j = 1; j < 5; ++j) {
-        const bool b = c.s[j] < s0;
-        i0 = b ? j : i0; s0 = b ? c.s[j] : s0; w0 = b ? c.w[j] : w0; p0 = vsel(b, c.p[j], p0); q0 = vsel(b, c.q[j], q0);
-    }
-    int i1 = -1; float best = -3.0e38f;
-    float s1 = 0.0f, w1 = 0.0f;
-    v3 p1 = V(0, 0, 0), q1 = V(0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const v3 d = sub(c.p[j], p0);
-        const float pen = kDepthWeight * (c.s[j] - s0);
-        const float score = sqrtf(dot(d, d)) - pen;
-        const bool b = j != i0 && score > best;
-        best = b ? score : best; i1 = b ? j : i1; s1 = b ? c.s[j] : s1; w1 = b ? c.w[j] : w1; p1 = vsel(b, c.p[j], p1); q1 = vsel(b, c.q[j], q1);
-    }
-    int i2 = -1, i3 = -1; float mx = 0.0f, mn = 0.0f;
-    float s2 = 0.0f, s3 = 0.0f, w2 = 0.0f, w3 = 0.0f;
-    v3 p2 = V(0, 0, 0), q2 = V(0, 0, 0), p3 = V(0, 0, 0), q3 = V(0, 0, 0);
-    const v3 e = sub(p1, p0);
-    const float el = sqrtf(dot(e, e));
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const bool skip = j == i0 || j == i1;
-        const float a = dot(cross(e, sub(c.p[j], p0)), nrm);
-        const float pen = kDepthWeight * (c.s[j] - s0) * el;
-        const bool b2 = !skip && a - pen > mx, b3 = !skip && a + pen < mn;
-        mx = b2 ? a - pen : mx; i2 = b2 ? j : i2; s2 = b2 ? c.s[j] : s2; w2 = b2 ? c.w[j] : w2; p2 = vsel(b2, c.p[j], p2); q2 = vsel(b2, c.q[j], q2);
-        mn = b3 ? a + pen : mn; i3 = b3 ? j : i3; s3 = b3 ? c.s[j] : s3; w3 = b3 ? c.w[j] : w3; p3 = vsel(b3, c.p[j], p3); q3 = vsel(b3, c.q[j], q3);
-    }
-    out.pa[0] = p0; out.pb[0] = q0; out.sep[0] = s0; out.w[0] = w0; mins = fminf(mins, s0);
-    out.pa[1] = p1; out.pb[1] = q1; out.sep[1] = s1; out.w[1] = w1; if (s1 < mins) mins = s1;
-    k = 2;
-    const bool h2 = i2 >= 0, h3 = i3 >= 0;
-    // slot 2: candidate i2, or i3 when there is no i2; slot 3: candidate i3 when both exist
-    out.pa[2] = vsel(h2, p2, p3); out.pb[2] = vsel(h2, q2, q3); out.sep[2] = h2 ? s2 : s3; out.w[2] = h2 ? w2 : w3;
-    out.pa[3] = p3; out.pb[3] = q3; out.sep[3] = s3; out.w[3] = w3;
-    if (h2) { ++k; if (s2 < mins) mins = s2; }
-    if (h3) { ++k; if (s3 < mins) mins = s3; }
-    out.count = k;
-    return mins;
-}
-
-// ---- narrowphase of one hull pair, split in three stages so that the four tilt runs of every
-// ---- contact pair can execute on separate lanes (same arithmetic as the oracle's
-// ---- hull_pair_contacts, which runs them one after the other)
-struct MainResult {       // stage 1: plain GJK (+ portal refinement when the hulls overlap)
-    int type;             // 0 none; 1 NEW contact pair (tilt runs follow); 2 new pair found overlapping (its single contact);
-                          // 3 pair with a manifold from the previous step (refreshed by pair_persist)
+// ---- narrowphase of one hull pair in three stages (same arithmetic as the oracle's hull_pair_contacts, which runs them one
+// ---- after the other): (1) GJK / portal refinement + the previous manifold's points refreshed in the new poses (lane = pair),
+// ---- (2) pairs that are new or lost a point: the face manifold, sixteen lanes per pair, (3) contact list (wave = scene)
+struct MainResult {       // stage 1
+    int type;             // 0 no contact; 1 contact pair whose manifold is BUILT in this step (new pair, or its manifold lost a point);
+                          // 3 pair whose manifold of the previous step stays as it was built (its points refreshed)
     v3 n, pa, pb;
     float dist;           // distance, or the (negative) separation of an overlap
-    GjkSeed seed;         // type 1: the converged simplex, start of the tilt runs; type 3: seed.n = the previous step's pair slot
+    GjkSeed seed;         // while stage 1 runs: the converged simplex (the pair cache takes it); in the result slot: n = the previous
+                          // step's pair slot, i0 = 1 when that step left a manifold, i1 = points parked in the pair's stage slots
+                          // (stage 1: the refreshed ones; after stage 2: the built manifold)
 };
 
-// constants of the contact persistence (oracle/settle_ref.c WARM_START, DRIFT_OFFSETS, NORMAL_COS, PLANE_DEPTH_WEIGHT)
+// constants of the contact persistence (oracle/settle_ref.c WARM_START, DRIFT_OFFSETS, NORMAL_COS, PLANE_DEPTH_WEIGHT, FM_*)
 constexpr float kWarmStart = 0.8f;
 constexpr float kDriftOffsets = 2.0f;
 constexpr float kNormalCos = 0.9848f;
 constexpr float kPlaneDepthWeight = 5.0f;
+constexpr float kFmBandOffsets = 1.0f;
+constexpr float kFmBandExtent = 0.25f;
+constexpr float kFmAreaMin = 1.0e-6f;
+constexpr float kFmInsideTol = 1.0e-6f;
+constexpr float kFmParallel2 = 1.0e-6f;
+constexpr float kFmDeeperOffsets = 0.05f;
+constexpr float kFmDeepOffsets = 2.5f;
 
-// `prev_ok`: the pair had a manifold with points in the previous step.  Returns whether the pair cache takes the new simplex.
+// Returns whether the pair cache takes the new simplex.
 __device__ __forceinline__ bool pair_main(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
                                           const f3* __restrict__ hv, const float4* __restrict__ gv, float margin, const GjkSeed cached,
-                                          bool prev_ok, MainResult& r, int max_iter = kGjkMaxIter, bool* unfinished = nullptr)
+                                          MainResult& r, int max_iter = kGjkMaxIter, bool* unfinished = nullptr)
 {
     r.type = 0;
     Shape A, B;
@@ -774,91 +665,18 @@ __device__ __forceinline__ bool pair_main(const WBody& wa, const WBody& wb, cons
             overlap_fallback(A, B, hv, ca, cb, &n, &sep, &pa, &pb);
             if (sep > 0.0f) sep = 0.0f;
         }
-        r.type = prev_ok ? 3 : 2; r.n = n; r.pa = pa; r.pb = pb; r.dist = sep;
+        r.type = 1; r.n = n; r.pa = pa; r.pb = pb; r.dist = sep;
         return false;   // overlap keeps the previous cache entry
     }
     if (dist > margin) return true;
-    r.type = prev_ok ? 3 : 1;
+    r.type = 1;
     r.n = scale(sub(pa, pb), 1.0f / dist);
     r.pa = pa; r.pb = pb; r.dist = dist;
     return true;
 }
 
-// stage 2: tilt run k (0..3) of a contact pair -> candidate (qa, qb, sp); returns false if rejected
-// before the duplicate test
-__device__ bool pair_tilt(const WBody& wa, const WBody& wb, const HullRef& ha, const HullRef& hb,
-                          const f3* __restrict__ hv, const float4* __restrict__ gv, const slhip_settle_params& prm, float margin, v3 n, const GjkSeed seed, int k, v3* qa_out,
-                          v3* qb_out, float* sp_out)
-{
-    Shape A, B;
-    make_shape(wa, ha, gv, A);
-    make_shape(wb, hb, gv, B);
-    const v3 ca = add(m3_mul(wa.R, ha.sc), wa.t);
-    const v3 cb = add(m3_mul(wb.R, hb.sc), wb.t);
-    const bool tilt_a = ha.sr <= hb.sr;
-    const float radius = tilt_a ? ha.sr : hb.sr;
-    float ang = 2.0f * prm.contact_offset / radius;
-    if (ang > 0.2f) ang = 0.2f;
-    const float lift = radius * ang;
-    const float sh = 0.5f * ang;
-    const float ch = sqrtf(1.0f - sh * sh);
-    v3 t1, t2;
-    tangents(n, &t1, &t2);
-    const WBody& wt = tilt_a ? wa : wb;
-    const v3 ax = (k == 0) ? t1 : (k == 1) ? t2 : (k == 2) ? neg(t1) : neg(t2);
-    quat dq; dq.x = ax.x * sh; dq.y = ax.y * sh; dq.z = ax.z * sh; dq.w = ch;
-    const quat q2 = quat_normalize(quat_mul(dq, wt.q));
-    Shape T = tilt_a ? A : B;
-    quat_to_m3(q2, T.R);
-    const v3 cl = tilt_a ? ha.sc : hb.sc;
-    v3 cw = tilt_a ? ca : cb;
-    cw = madd(cw, n, tilt_a ? lift : -lift);
-    T.t = sub(cw, m3_mul(T.R, cl));
-    v3 qa, qb;
-    float d2;
-    const int ok = tilt_a ? gjk_distance(T, B, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, nullptr, kGjkTiltMaxIter)
-                          : gjk_distance(A, T, hv, sub(ca, cb), margin + 2.0f * lift, &qa, &qb, &d2, seed, nullptr, kGjkTiltMaxIter);
-    if (ok != 1) return false;
-    if (tilt_a) {
-        const v3 loc = m3_tmul(T.R, sub(qa, T.t));
-        qa = add(m3_mul(A.R, loc), A.t);
-    } else {
-        const v3 loc = m3_tmul(T.R, sub(qb, T.t));
-        qb = add(m3_mul(B.R, loc), B.t);
-    }
-    const float sp = dot(sub(qa, qb), n);
-    if (sp > margin) return false;
-    const v3 lat = sub(sub(qa, qb), scale(n, sp));
-    if (dot(lat, lat) > 4.0f * margin * margin) return false;
-    *qa_out = qa; *qb_out = qb; *sp_out = sp;
-    return true;
-}
-
-// stage 3 (new pairs): duplicate rejection in slot order + manifold reduction
-__device__ __forceinline__ float pair_finish(const MainResult& m, Cand5& c, float radius, RawContacts& out)
-{
-    c.p[0] = m.pa; c.q[0] = m.pb; c.s[0] = m.dist; c.ok |= 1u;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) c.w[k] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (!((c.ok >> (k + 1)) & 1u)) continue;
-        bool dup = false;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            if (j > k) continue;
-            if (!((c.ok >> j) & 1u)) continue;
-            const v3 dd = sub(c.p[j], c.p[k + 1]);
-            if (dot(dd, dd) < 2.5e-3f * radius * radius) dup = true;
-        }
-        if (dup) c.ok &= ~(1u << (k + 1));
-    }
-    out.n = m.n;
-    return reduce_candidates(c, m.n, out);
-}
-
 // Persistent manifold of one hull pair as the previous step left it (oracle pmanifold; the impulses live in the step's
-// impulse array at c_off): contact points in the two bodies' object frames, the normal in B's frame.  128 bytes.
+// impulse array at c_off): contact points in the two bodies' object frames, the normal the manifold was BUILT with in B's frame.
 struct PM {
     int count, c_off;
     v3 nb;
@@ -867,21 +685,26 @@ struct PM {
 };
 static_assert(sizeof(PM) == 128, "PM layout");
 
-// stage 3 (pairs with a manifold): the old points refreshed in the new poses -- separations along the new normal; a point whose
-// witnesses drifted apart laterally or that left the contact band is dropped, all of them when the normal turned -- plus the
-// new closest-point (or deepest-point) pair, which replaces the old point it coincides with or joins as a fifth candidate.
-// Slots 0..3 = the old points in their order, slot 4 = the new one: the oracle's compacted list in the same order.
-__device__ __forceinline__ float pair_persist(const MainResult& m, const PM& prev, const float* __restrict__ ln_prev, const WBody& wa,
-                                              const WBody& wb, float margin, float contact_offset, float radius, RawContacts& out)
+// a contact point parked between the stages (and, in k_w_finish, until the contact list is written): witnesses on A and B,
+// separation, the impulse it carries (float bits)
+struct StagePt { v3 qa, qb; float sp; int imp; };
+static_assert(sizeof(StagePt) == 32, "StagePt layout");
+
+// stage 1, pairs with a manifold: the old points in the new poses -- separations along the new normal; a point whose witnesses
+// drifted apart laterally or that left the contact band is lost, all of them when the normal turned against B since the manifold
+// was built.  The points that stay are parked in `stage` in their order; returns their number and whether the manifold is LOST
+// (a point went, or the closest points are deeper than all of it: it no longer holds the pair's deepest feature).
+__device__ __forceinline__ int refresh_manifold(const MainResult& m, const PM& prev, const float* __restrict__ ln_prev, const WBody& wa,
+                                                const WBody& wb, float margin, float contact_offset, StagePt* __restrict__ stage,
+                                                bool& lost)
 {
-    Cand5 c;
-    c.ok = 0u;
     const v3 npw = m3_mul(wb.R, prev.nb);
     const float lim = kDriftOffsets * contact_offset;
     const bool same_normal = dot(m.n, npw) >= kNormalCos;
+    int no = 0;
+    float omin = kInf;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        c.p[i] = V(0, 0, 0); c.q[i] = V(0, 0, 0); c.s[i] = 0.0f; c.w[i] = 0.0f;
         if (i < prev.count && same_normal) {
             const v3 qa = add(m3_mul(wa.R, prev.la[i]), wa.t);
             const v3 qb = add(m3_mul(wb.R, prev.lb[i]), wb.t);
@@ -889,25 +712,17 @@ __device__ __forceinline__ float pair_persist(const MainResult& m, const PM& pre
             const float sp = dot(d, m.n);
             const v3 lat = sub(d, scale(m.n, sp));
             const bool keep = !(sp > margin) && !(dot(lat, lat) > lim * lim);
-            if (keep) { c.p[i] = qa; c.q[i] = qb; c.s[i] = sp; c.w[i] = ln_prev[i]; c.ok |= 1u << i; }
+            if (keep) {
+                StagePt t;
+                t.qa = qa; t.qb = qb; t.sp = sp; t.imp = __float_as_int(ln_prev[i]);
+                stage[no] = t;
+                ++no;
+                if (sp < omin) omin = sp;
+            }
         }
     }
-    const float dup2 = 2.5e-3f * radius * radius;
-    int dup = -1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const v3 dd = sub(c.p[j], m.pa);
-        if (dup < 0 && ((c.ok >> j) & 1u) && dot(dd, dd) < dup2) dup = j;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool r = j == dup;
-        c.p[j] = vsel(r, m.pa, c.p[j]); c.q[j] = vsel(r, m.pb, c.q[j]); c.s[j] = r ? m.dist : c.s[j];
-    }
-    c.p[4] = m.pa; c.q[4] = m.pb; c.s[4] = m.dist; c.w[4] = 0.0f;
-    if (dup < 0) c.ok |= 1u << 4;
-    out.n = m.n;
-    return reduce_candidates(c, m.n, out);
+    lost = no < prev.count || m.dist < omin - kFmDeeperOffsets * contact_offset;
+    return no;
 }
 
 // body vs table plane: four order-independent selections over all hull vertices in the band
@@ -1779,7 +1594,7 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                 k_w_gjk_first<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, pc, list_stride, step + 1u, n_scenes);
                 k_w_gjk_rest<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, pc, list_stride, step + 1u, n_scenes);
                 if (timed) (void)hipEventRecord(ev[2], stream);
-                k_w_gjk_tilt<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, list_stride);
+                k_w_manifold<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, list_stride);
                 if (timed) (void)hipEventRecord(ev[3], stream);
                 k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL, pc, step + 1u);
                 if (timed) (void)hipEventRecord(ev[4], stream);
