@@ -410,6 +410,11 @@ int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_st
  * colouring, cost class), 4 k_w_solve.                                                                                  */
 int slhip_settle_timing_enable(int on);
 int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5]);
+/* The same records step by step (profiles/rNN/solve_by_step.csv): slhip_settle_timing_every(k) times every k-th step (default 8);
+ * slhip_settle_timings_by_step synchronises the recorded events and writes, for up to `capacity` timed steps since the last read-out,
+ * ms_out[5 * i + kernel] and steps_out[i] (may be NULL) = the step's index within its settle call; *n_out = rows written.          */
+int slhip_settle_timing_every(uint32_t every);
+int slhip_settle_timings_by_step(float* ms_out, uint32_t* steps_out, uint32_t capacity, uint32_t* n_out);
 /* scratch for n_scenes scenes: accumulators + the per-scene pair cache, sized from the hints in
  * `params` (NULL or zero hints: the worst case)                                                      */
 int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out);

@@ -1467,7 +1467,7 @@ static uint64_t settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_param
 // kernel of every 8th step; slhip_settle_timings() synchronises them and returns the average launch duration per kernel.
 struct SettleTiming {
     bool on = false;
-    struct Rec { int kernel; hipEvent_t e0, e1; };
+    struct Rec { int kernel; hipEvent_t e0, e1; uint32_t step; };
     std::vector<Rec> pending;          // kernel k of a timed step ran between e0 and e1 (neighbours share an event)
     std::vector<hipEvent_t> events;    // every event once, destroyed after the read-out
 };
@@ -1479,20 +1479,30 @@ extern "C" int slhip_settle_timing_enable(int on)
     return 0;
 }
 
-extern "C" int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5])
+static uint32_t g_settle_timing_every = 8;
+
+// reads the pending records out: averages per kernel and, when by_step_ms is given, every timed step's five durations
+static int settle_timings_read(float avg_ms_out[5], uint32_t launches_out[5], float* by_step_ms, uint32_t* steps_out, uint32_t cap,
+                               uint32_t* n_out)
 {
     double acc[5] = {0, 0, 0, 0, 0};
     uint32_t n[5] = {0, 0, 0, 0, 0};
     bool failed = false;
+    uint32_t rows = 0;
     for (auto& r : g_settle_timing.pending) {
         float ms = 0.0f;
         if (failed || hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { failed = true; continue; }
         acc[r.kernel] += ms;
         ++n[r.kernel];
+        if (by_step_ms) {
+            if (r.kernel == 0 && rows < cap) { if (steps_out) steps_out[rows] = r.step; ++rows; }
+            if (rows > 0 && rows <= cap) by_step_ms[5 * (size_t)(rows - 1) + r.kernel] = ms;
+        }
     }
     for (hipEvent_t e : g_settle_timing.events) (void)hipEventDestroy(e);   // on the error path as well
     g_settle_timing.events.clear();
     g_settle_timing.pending.clear();
+    if (n_out) *n_out = rows;
     if (failed) {
         slhip::set_error("slhip_settle_timings: event readback failed");
         return -1;
@@ -1502,6 +1512,26 @@ extern "C" int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5
         if (launches_out) launches_out[k] = n[k];
     }
     return 0;
+}
+
+extern "C" int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5])
+{
+    return settle_timings_read(avg_ms_out, launches_out, nullptr, nullptr, 0, nullptr);
+}
+
+extern "C" int slhip_settle_timing_every(uint32_t every)
+{
+    g_settle_timing_every = every ? every : 1u;
+    return 0;
+}
+
+extern "C" int slhip_settle_timings_by_step(float* ms_out, uint32_t* steps_out, uint32_t capacity, uint32_t* n_out)
+{
+    if (!ms_out || !n_out) {
+        slhip::set_error("slhip_settle_timings_by_step: null output");
+        return -1;
+    }
+    return settle_timings_read(nullptr, nullptr, ms_out, steps_out, capacity, n_out);
 }
 
 extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out)
@@ -1579,7 +1609,7 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
             for (uint32_t sub = 0; sub < params->substeps; ++sub, ++step) {
                 // (a caller that never reads the timings must not grow the lists for ever: sampling stops at kMaxTimedEvents)
                 constexpr size_t kMaxTimedEvents = 1u << 16;
-                bool timed = g_settle_timing.on && step % 8u == 0u && g_settle_timing.events.size() < kMaxTimedEvents;
+                bool timed = g_settle_timing.on && step % g_settle_timing_every == 0u && g_settle_timing.events.size() < kMaxTimedEvents;
                 hipEvent_t ev[6];
                 if (timed)
                     for (int k = 0; k < 6; ++k)
@@ -1602,7 +1632,7 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                                                                sub + 1 == params->substeps ? 1 : 0, n_scenes);
                 if (timed) {
                     (void)hipEventRecord(ev[5], stream);
-                    for (int k = 0; k < 5; ++k) g_settle_timing.pending.push_back({k, ev[k], ev[k + 1]});
+                    for (int k = 0; k < 5; ++k) g_settle_timing.pending.push_back({k, ev[k], ev[k + 1], step});
                     for (int k = 0; k < 6; ++k) g_settle_timing.events.push_back(ev[k]);
                 }
             }
