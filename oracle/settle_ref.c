@@ -697,7 +697,7 @@ static void fill_contact(contact* c, int a, int b, const wbody* wa, const wbody*
 #define FM_DEEP_OFFSETS 2.5f     /* no clipped corners for hulls that overlap by more than this many contact offsets */
 #define FM_CANDIDATES 85
 typedef struct { float u[8], w[8], h[8]; float nu, nw, nh, cu, cw, ch; } fm_poly;
-static uint64_t* g_fm_stats = NULL; /* [8]: manifolds built for new pairs, rebuilt, kept; points of the built ones; closest-point pairs that joined */
+static uint64_t* g_fm_stats = NULL; /* [16]: (5.. rebuilt because: the normal turned, a point drifted, a point left the band, the closest points are deeper) manifolds built for new pairs, rebuilt, kept; points of the built ones; closest-point pairs that joined */
 void slref_settle_set_fm_stats(uint64_t* h) { g_fm_stats = h; }
 
 static void fm_feature(const shape* S, v3 n, v3 t1, v3 t2, int lowest, float band, fm_poly* P)
@@ -941,7 +941,7 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
        since the manifold was built */
     v3 op[4], oq[4];
     float os[4], ow[4];
-    int no = 0, lost = 0;
+    int no = 0, lost = 0, n_left = 0, n_drift = 0, n_turn = 0;
     if (prev.count > 0) {
         const float lim = DRIFT_OFFSETS * prm->contact_offset;
         float omin = 3.0e38f;
@@ -951,14 +951,16 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
                 v3 qb = add(m3_mul(&wb->R, prev.lb[i]), wb->t);
                 v3 d = sub(qa, qb);
                 float sp = dot(d, n);
-                if (sp > margin) continue;
+                if (sp > margin) { ++n_left; continue; }
                 v3 lat = sub(d, scale(n, sp));
-                if (dot(lat, lat) > lim * lim) continue;
+                if (dot(lat, lat) > lim * lim) { ++n_drift; continue; }
                 op[no] = qa; oq[no] = qb; os[no] = sp; ow[no] = prev.ln[i]; ++no;
                 if (sp < omin) omin = sp;
             }
+        else n_turn = 1;
         /* ... and the manifold no longer holds the pair's deepest feature when the closest points are deeper than all of it */
         lost = no < prev.count || sep_new < omin - FM_DEEPER_OFFSETS * prm->contact_offset;
+        if (g_fm_stats && lost) g_fm_stats[n_turn ? 5 : n_drift ? 6 : n_left ? 7 : 8]++;
     }
     if (prev.count == 0 || lost) {
         /* a NEW contact pair, or one whose manifold lost a point: the face manifold in one step -- the points that stayed (with

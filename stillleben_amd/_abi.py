@@ -274,8 +274,9 @@ def lib():
     L.slhip_settle_caps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64 * 8), C.c_void_p]
     L.slhip_settle_timing_enable.argtypes = [C.c_int]
     L.slhip_settle_timings.argtypes = [C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32 * 5)]
-    L.slhip_settle_timing_every.argtypes = [C.c_uint32]
-    L.slhip_settle_timings_by_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    if hasattr(L, "slhip_settle_timing_every"):      # (absent from older builds selected through SLHIP_LIB for A/B runs)
+        L.slhip_settle_timing_every.argtypes = [C.c_uint32]
+        L.slhip_settle_timings_by_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.slhip_settle_scratch_bytes.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
     L.slhip_overlap_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.slhip_light_map_floats.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint64 * 4)]
