@@ -210,7 +210,7 @@ def cpu_baseline(table_meshes, scenes_per_thread, ssao):
     W, H = RESOLUTION
     proto = sl.Scene(RESOLUTION)
     proto.set_camera_intrinsics(*INTRINSICS)
-    sp = SB.default_params(tabletop=True)
+    sp = SB.default_params(tabletop=True, pair_contact_budget=SB.PAIR_CONTACT_BUDGET)   # what sl.SceneBatch asks for
 
     def params(t):
         p = np.zeros((), dtype=_abi.SYNTH_PARAMS_DTYPE)

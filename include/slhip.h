@@ -33,9 +33,10 @@
 extern "C" {
 #endif
 
-#define SLHIP_ABI_VERSION 3   /* 2: slhip_render_scratch.d_shadow_tiles, slhip_render_scratch_bytes fills 7 sizes
+#define SLHIP_ABI_VERSION 4   /* 2: slhip_render_scratch.d_shadow_tiles, slhip_render_scratch_bytes fills 7 sizes
                                  3: slhip_render_scratch.d_vattr is REQUIRED (the post-transform vertex cache) and `_pad` became
                                     shadow_lights; d_clip holds 9 float4 planes per vertex; slhip_settle_params grew to 116 bytes
+                                 4: slhip_settle_params.max_body_pairs_per_scene (120 bytes); slhip_settle_caps fills ten counts
                                     (list capacities instead of caps, pair_contact_budget, resume: the contact state of a settle
                                     outlives the call); slhip_settle_caps fills counts[8]                                        */
 #define SLHIP_NUM_LIGHTS 3 /* reference include/stillleben/common.h:17 */
@@ -362,6 +363,11 @@ typedef struct {
        903-912, manipulation_sim.cpp:83-93) is taken from the scratch as the last call left it, d_bodies carries poses, velocities,
        wake counters and sleep flags.  k calls of one step give bit for bit what one call of k steps gives.                      */
     uint32_t resume;
+    /* Capacity of a scene's list of touching BODY pairs (one solver group each, beside one group per body against the table).
+       0: min(all body pairs, max_hull_pairs_per_scene, 12 x bodies + 64) -- enough for piles, where a body has a handful of
+       neighbours.  A body pair beyond the capacity is dropped with its hull pairs AND COUNTED (slhip_settle_caps counts[8]):
+       the caller settles again with a larger value, like for the other two lists.                                          */
+    uint32_t max_body_pairs_per_scene;
 } slhip_settle_params;
 
 /* per-scene scratch (device), sized by slhip_settle_scratch_bytes */
@@ -397,10 +403,12 @@ int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes,
  * memory, nothing lost), [1] (scene, step) pairs in which contacts beyond max_contacts_per_scene were DROPPED, [2] (scene, step)
  * pairs in which hull pairs beyond max_hull_pairs_per_scene were DROPPED, [3] scenes with a non-zero [1] or [2], [4] scenes whose
  * contacts ever went beyond the LDS-resident part, [5] the most contacts and [6] the most hull pairs a step of any scene offered,
- * [7] (scene, step) pairs in which pair_contact_budget reduced some body pair's points.
- * The reference has no caps (scene.cpp:738-739): [1] = [2] = 0 is the contract, a caller that sees otherwise re-sizes.          */
+ * [7] (scene, step) pairs in which pair_contact_budget reduced some body pair's points, [8] (scene, step) pairs in which body
+ * pairs beyond max_body_pairs_per_scene were DROPPED (such scenes count in [3] too), [9] the contacts the solver took, summed over
+ * all (scene, step) pairs (bench.py's byte model: contacts per scene-step).
+ * The reference has no caps (scene.cpp:738-739): [1] = [2] = [8] = 0 is the contract, a caller that sees otherwise re-sizes.     */
 int slhip_settle_caps(const void* d_scratch, uint32_t n_scenes, const slhip_settle_params* params,
-                      uint64_t counts[8], void* stream);
+                      uint64_t counts[10], void* stream);
 int slhip_settle_status(const void* d_scratch, uint32_t n_scenes, uint32_t* h_status, uint32_t* h_n_refused,
                         void* stream);
 /* Optional live timing of the phases of a lockstep step (bench.py's roofline leg): HIP events on the launch's stream

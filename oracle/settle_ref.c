@@ -163,7 +163,7 @@ typedef struct {
 typedef struct {
     /* capacities of the per-step lists (slhip_settle_params.max_hull_pairs_per_scene / max_contacts_per_scene) and bodies */
     int P, C, NB;
-    int G;                               /* groups: NB table groups + min(body pairs, P, 12 NB + 64) (the kernels' wide_g_cap) */
+    int G;                               /* groups: NB table groups + min(body pairs, P, max_body_pairs_per_scene or 12 NB + 64) (the kernels' wide_g_cap) */
     /* hull pair list */
     int n_hp;
     int *hp_ba, *hp_bb;                  /* [P] bodies */
@@ -183,8 +183,9 @@ typedef struct {
     pplane* pp;                          /* [NB] */
     int step;                            /* 1-based step number since the cold start */
     int hp_overflow;
-    unsigned cap_hits[5];                /* steps of this scene that dropped contacts beyond C / hull pairs beyond P; the most contacts /
-                                            hull pairs a step offered; steps in which pair_contact_budget reduced a body pair */
+    unsigned cap_hits[7];                /* steps of this scene that dropped contacts beyond C / hull pairs beyond P; the most contacts /
+                                            hull pairs a step offered; steps in which pair_contact_budget reduced a body pair; steps that
+                                            dropped body pairs beyond the group list; contacts the solver took, summed over the steps */
     int n_hulls;
     int* body_lh;                        /* [NB + 1] first hull ordinal of every body */
     int *order, *size;                   /* [P + NB] colouring scratch */
@@ -200,7 +201,7 @@ static void ws_free(scene_ws* ws)
     free(ws);
 }
 
-static scene_ws* ws_alloc(int P, int C, int NB)
+static scene_ws* ws_alloc(int P, int C, int NB, int BP)
 {
     scene_ws* ws = (scene_ws*)calloc(1, sizeof(scene_ws));
     if (!ws) return NULL;
@@ -208,7 +209,8 @@ static scene_ws* ws_alloc(int P, int C, int NB)
     {
         long long pairs = (long long)NB * (NB - 1) / 2;
         if (pairs > P) pairs = P;
-        if (pairs > 12ll * NB + 64) pairs = 12ll * NB + 64;
+        const long long lim = BP > 0 ? (long long)BP : 12ll * NB + 64;
+        if (pairs > lim) pairs = lim;
         ws->G = NB + (int)pairs;
     }
     const size_t G = (size_t)P + NB;
@@ -1429,7 +1431,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
     ws->n_hp = 0;
     ws->n_groups = 0;
     ws->hp_overflow = 0;
-    int pairs_found = 0;
+    int pairs_found = 0, g_overflow = 0;
     /* (b) plane contacts FIRST: one group per dynamic body near the table (their contacts have
        priority under the active-contact cap); slots live after the hull-pair slots */
     const int plane_base = ws->P * MAX_CONTACTS_PER_HP;
@@ -1477,8 +1479,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
                     ws->hp_ba[k] = i; ws->hp_bb[k] = j; ws->hp_ha[k] = (int)ha; ws->hp_hb[k] = (int)hb;
                 }
             if (ws->n_hp > first && ws->n_groups >= ws->G) { /* no room for another group: the body pair is dropped, counted */
-                ws->hp_overflow = 1;
-                if (pairs_found <= ws->P) pairs_found = ws->P + 1;
+                g_overflow = 1;
                 ws->n_hp = first;
             }
             if (ws->n_hp > first) {
@@ -1490,6 +1491,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         }
 
     if (ws->hp_overflow) ws->cap_hits[1]++;
+    if (g_overflow) ws->cap_hits[5]++;
     if (g_pairs_hist) g_pairs_hist[pairs_found > 8191 ? 8191 : pairs_found]++;
     if ((unsigned)pairs_found > ws->cap_hits[3]) ws->cap_hits[3] = (unsigned)pairs_found;
     /* (d) narrowphase per hull pair */
@@ -1559,6 +1561,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
             for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) offered += ws->c[i].valid ? 1 : 0;
         if (g_offered) g_offered[offered > 2047 ? 2047 : offered]++;
         if ((unsigned)offered > ws->cap_hits[2]) ws->cap_hits[2] = (unsigned)offered;
+        ws->cap_hits[6] += (unsigned)(offered > ws->C ? ws->C : offered);
         if (offered > ws->C) {
             ws->cap_hits[0]++;
             int active = 0;
@@ -1708,7 +1711,7 @@ static void redrop(const slhip_settle_scene* sc, slhip_body* bodies, int me, con
 
 /* optional per-frame trace for the tests: trace[(s * frames + f) * 4 + {0,1,2,3}] = bodies asleep, redrops so far,
    active contacts of the frame's last step, max |v| */
-static unsigned* g_caps = NULL; /* per scene [5]: {steps that dropped contacts, steps that dropped hull pairs, most contacts offered, most hull pairs found,
+static unsigned* g_caps = NULL; /* per scene [7] (+ steps that dropped body pairs, contacts the solver took in all steps): {steps that dropped contacts, steps that dropped hull pairs, most contacts offered, most hull pairs found,
                                    steps reduced by pair_contact_budget} */
 void slref_settle_set_caps(unsigned* c) { g_caps = c; }
 static float* g_trace = NULL;
@@ -1722,7 +1725,7 @@ typedef struct {
     pmanifold* pm;
     pplane* pp;            /* [bodies of the scene] */
     int step, n_hulls, nb;
-    unsigned cap_hits[5];
+    unsigned cap_hits[7];
 } scene_keep;
 typedef struct { uint32_t n_scenes; scene_keep* k; } settle_state;
 
@@ -1756,7 +1759,7 @@ int slref_settle_ex(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_b
         const int nb = (int)(scenes[s].body_end - scenes[s].body_begin);
         if (nb > nb_max) nb_max = nb;
     }
-    scene_ws* ws = nb_max <= SLHIP_MAX_BODIES ? ws_alloc(cap_pairs(prm), cap_contacts(prm), nb_max) : NULL;
+    scene_ws* ws = nb_max <= SLHIP_MAX_BODIES ? ws_alloc(cap_pairs(prm), cap_contacts(prm), nb_max, prm->max_body_pairs_per_scene > 65000u ? 65000 : (int)prm->max_body_pairs_per_scene) : NULL;
     int rc = ws ? 0 : (nb_max > SLHIP_MAX_BODIES ? -2 : -1);
     for (uint32_t s = 0; s < n_scenes && rc == 0; ++s) {
         const slhip_settle_scene* sc = &scenes[s];
@@ -1810,7 +1813,7 @@ int slref_settle_ex(const slhip_settle_scene* scenes, uint32_t n_scenes, slhip_b
                 t[0] = (float)asleep; t[1] = (f ? t[1 - 4] : 0.0f) + (moved ? 1.0f : 0.0f); t[2] = (float)active; t[3] = vmax;
             }
         }
-        if (g_caps) { for (int q = 0; q < 5; ++q) g_caps[5 * s + q] = ws->cap_hits[q]; }
+        if (g_caps) { for (int q = 0; q < 7; ++q) g_caps[7 * s + q] = ws->cap_hits[q]; }
         K->step = ws->step;
         memcpy(K->pp, ws->pp, sizeof(pplane) * nb);
         memcpy(K->cap_hits, ws->cap_hits, sizeof(ws->cap_hits));
@@ -1883,7 +1886,7 @@ int slref_debug_contacts(const slhip_settle_scene* sc, const slhip_body* bodies_
 {
     const slhip_body* bodies = bodies_all + sc->body_begin;
     const int nb = (int)(sc->body_end - sc->body_begin);
-    scene_ws* ws = ws_alloc(1, 1, nb);
+    scene_ws* ws = ws_alloc(1, 1, nb, 0);
     if (!ws) return 0;
     for (int i = 0; i < nb; ++i) load_body(&bodies[i], &ws->wb[i]);
     int rows = 0;

@@ -39,7 +39,7 @@ RENDER_SSAO = 0x100
 RENDER_SHADOWS = 0x200
 RENDER_SHADOW_RESET = 0x400
 RENDER_KEEP_HDR = 0x800
-ABI_VERSION = 3
+ABI_VERSION = 4
 DEFAULT_HULL_PAIRS, DEFAULT_CONTACTS = 2048, 1024   # SLHIP_DEFAULT_HULL_PAIRS / SLHIP_DEFAULT_CONTACTS of include/slhip.h
 COMM_ID_BYTES = 128
 
@@ -271,7 +271,7 @@ def lib():
     L.slhip_records_count.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.slhip_records_build_render.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                              C.c_uint32, C.c_void_p, C.c_uint32]
-    L.slhip_settle_caps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64 * 8), C.c_void_p]
+    L.slhip_settle_caps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64 * 10), C.c_void_p]
     L.slhip_settle_timing_enable.argtypes = [C.c_int]
     L.slhip_settle_timings.argtypes = [C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32 * 5)]
     if hasattr(L, "slhip_settle_timing_every"):      # (absent from older builds selected through SLHIP_LIB for A/B runs)

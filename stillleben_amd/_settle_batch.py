@@ -36,12 +36,13 @@ PARAMS_DTYPE = np.dtype([
     ("redrop_z", np.float32), ("stuck_separation", np.float32), ("stuck_frames", np.int32), ("tabletop", np.uint32),
     ("max_bodies_per_scene", np.uint32), ("max_hull_verts_per_scene", np.uint32), ("max_hulls_per_scene", np.uint32),
     ("max_hull_pairs_per_scene", np.uint32), ("max_contacts_per_scene", np.uint32),
-    ("pair_contact_budget", np.uint32), ("resume", np.uint32),
+    ("pair_contact_budget", np.uint32), ("resume", np.uint32), ("max_body_pairs_per_scene", np.uint32),
 ])
-assert PARAMS_DTYPE.itemsize == 116
+assert PARAMS_DTYPE.itemsize == 120
 
-# slhip_settle_params.pair_contact_budget (0: every point goes to the solver, as in PhysX): a body pair touching through more hull
-# pairs keeps the deepest ones -- nested concave shapes otherwise put several hundred one-point manifolds into ONE Gauss-Seidel chain
+# slhip_settle_params.pair_contact_budget (0: every point goes to the solver, as in PhysX -- the default of every per-scene entry point):
+# a body pair touching through more hull pairs keeps the deepest ones -- nested concave shapes otherwise put several hundred one-point
+# manifolds into ONE Gauss-Seidel chain.  This value is what sl.SceneBatch (the throughput path) asks for, and says so (settle_caps).
 PAIR_CONTACT_BUDGET = 32
 
 BODY_STATIC = 1
@@ -49,7 +50,7 @@ BODY_ASLEEP = 2
 MAX_BODIES = 256
 
 
-def default_params(tabletop=True, dt=None, frames=None, substeps=None):
+def default_params(tabletop=True, dt=None, frames=None, substeps=None, pair_contact_budget=0):
     """Constants of the reference's call sites."""
     p = np.zeros((), dtype=PARAMS_DTYPE)
     p["dt"] = (1.0 / 25.0 / 4.0) if dt is None else dt   # scene.cpp:681-684
@@ -69,7 +70,7 @@ def default_params(tabletop=True, dt=None, frames=None, substeps=None):
     p["stuck_separation"] = -0.01                          # scene.cpp:748
     p["stuck_frames"] = 10                                 # 0.4 s * 25 FPS (scene.cpp:750)
     p["tabletop"] = 1 if tabletop else 0
-    p["pair_contact_budget"] = PAIR_CONTACT_BUDGET
+    p["pair_contact_budget"] = pair_contact_budget
     return p
 
 

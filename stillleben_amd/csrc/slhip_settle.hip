@@ -22,7 +22,7 @@ namespace {
 
 static_assert(sizeof(slhip_body) == 288, "slhip_body layout");
 static_assert(sizeof(slhip_hull) == 64, "slhip_hull layout");
-static_assert(sizeof(slhip_settle_params) == 116, "slhip_settle_params layout");
+static_assert(sizeof(slhip_settle_params) == 120, "slhip_settle_params layout");
 
 constexpr int kMaxContactsPerHP = 4;
 constexpr float kInf = 3.0e38f;
@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(64) void k_overlap(const slhip_settle_scene* __rest
 
 // Capacities and layout of the scratch, from the hints of slhip_settle_params (the same function sizes and carves).
 struct SettleDims {
-    int nb_cap, lh_cap, p_cap, c_cap;
+    int nb_cap, lh_cap, p_cap, c_cap, bp_cap;   // bp_cap: body pairs (0 = the default rule of wide_g_cap)
     unsigned cache_stride;   // pair cache entries per scene
     int cache_hashed;
 };
@@ -1435,6 +1435,7 @@ static SettleDims settle_dims(const slhip_settle_params* params)
     D.c_cap = params && params->max_contacts_per_scene ? (int)params->max_contacts_per_scene : SLHIP_DEFAULT_CONTACTS;
     if (D.p_cap > 65535) D.p_cap = 65535;
     if (D.c_cap > 65535) D.c_cap = 65535;
+    D.bp_cap = params && params->max_body_pairs_per_scene ? (int)(params->max_body_pairs_per_scene > 65000u ? 65000u : params->max_body_pairs_per_scene) : 0;
     // pair cache: dense [hulls]^2 when the hint says the scenes are small, else hashed (8 slots per list entry, a power of two)
     const unsigned h = params ? params->max_hulls_per_scene : 0u;
     if (h != 0u && h <= SLHIP_PAIR_CACHE_DENSE_HULLS) { D.cache_stride = h * h; D.cache_hashed = 0; }
@@ -1460,7 +1461,7 @@ static uint64_t settle_cache_bytes(uint32_t n_scenes, const SettleDims& D)
 static uint64_t settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params)
 {
     const SettleDims D = settle_dims(params);
-    return settle_fixed_bytes(n_scenes, D) + settle_cache_bytes(n_scenes, D) + wide_bytes(n_scenes, D.nb_cap, D.lh_cap, D.p_cap, D.c_cap) + 256;
+    return settle_fixed_bytes(n_scenes, D) + settle_cache_bytes(n_scenes, D) + wide_bytes(n_scenes, D.nb_cap, D.lh_cap, D.p_cap, D.c_cap, D.bp_cap) + 256;
 }
 
 // Optional live timing of the lockstep kernels (bench.py's roofline leg): HIP events on the launch's stream around every
@@ -1576,7 +1577,7 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         pc.base = reinterpret_cast<int4*>(base);
         pc.stride = D.cache_stride;
         pc.hashed = D.cache_hashed;
-        WideBufs W = wide_carve(base + settle_cache_bytes(n_scenes, D), n_scenes, nb_cap, D.lh_cap, D.p_cap, D.c_cap);
+        WideBufs W = wide_carve(base + settle_cache_bytes(n_scenes, D), n_scenes, nb_cap, D.lh_cap, D.p_cap, D.c_cap, D.bp_cap);
         if (((uint64_t)n_scenes << W.pair_bits) > (1ull << 32)) {
             slhip::set_error("slhip_settle: n_scenes x max_hull_pairs_per_scene exceeds the 32-bit work list entries");
             return -1;
@@ -1645,29 +1646,31 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
 // contacts (nothing lost), contacts / hull pairs DROPPED beyond the capacities the caller sized (the contract is zero), the
 // scenes concerned, the most a step offered.  The reference's PhysX has no caps (scene.cpp:738-739).
 extern "C" int slhip_settle_caps(const void* d_scratch, uint32_t n_scenes, const slhip_settle_params* params,
-                                 uint64_t counts[8], void* stream_)
+                                 uint64_t counts[10], void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d_scratch || !params || !counts) {
         slhip::set_error("slhip_settle_caps: null argument");
         return -1;
     }
-    for (int k = 0; k < 8; ++k) counts[k] = 0;
+    for (int k = 0; k < 10; ++k) counts[k] = 0;
     if (n_scenes == 0) return 0;
     const SettleDims D = settle_dims(params);
     const char* base = reinterpret_cast<const char*>(d_scratch) + settle_fixed_bytes(n_scenes, D) + settle_cache_bytes(n_scenes, D);
-    const WideBufs W = wide_carve(const_cast<char*>(base), n_scenes, D.nb_cap, D.lh_cap, D.p_cap, D.c_cap);
+    const WideBufs W = wide_carve(const_cast<char*>(base), n_scenes, D.nb_cap, D.lh_cap, D.p_cap, D.c_cap, D.bp_cap);
     std::vector<unsigned> h((size_t)n_scenes * kCapWords);
     SLHIP_CHECK(hipMemcpyAsync(h.data(), W.caps, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     SLHIP_CHECK(hipStreamSynchronize(stream));
     for (uint32_t i = 0; i < n_scenes; ++i) {
         const unsigned* c = &h[(size_t)kCapWords * i];
         counts[0] += c[kCapSpillSteps]; counts[1] += c[kCapContactDropSteps]; counts[2] += c[kCapPairDropSteps];
-        if (c[kCapContactDropSteps] || c[kCapPairDropSteps]) ++counts[3];
+        if (c[kCapContactDropSteps] || c[kCapPairDropSteps] || c[kCapGroupDropSteps]) ++counts[3];
         if (c[kCapSpillSteps]) ++counts[4];
         if (c[kCapMaxContacts] > counts[5]) counts[5] = c[kCapMaxContacts];
         if (c[kCapMaxPairs] > counts[6]) counts[6] = c[kCapMaxPairs];
         counts[7] += c[kCapReducedSteps];
+        counts[8] += c[kCapGroupDropSteps];
+        counts[9] += c[kCapContactSum];
     }
     return 0;
 }

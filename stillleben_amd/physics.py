@@ -66,9 +66,18 @@ class SettleEngine:
             cur_c = int(prm["max_contacts_per_scene"].reshape(-1)[0]) or _abi.DEFAULT_CONTACTS
             if caps["pair_drop_steps"]:
                 prm["max_hull_pairs_per_scene"] = min(65535, max(2 * cur_p, caps["max_hull_pairs"] * 5 // 4))
-            if caps["contact_drop_steps"] or caps["pair_drop_steps"]:
+            if caps["contact_drop_steps"] or caps["pair_drop_steps"] or caps["group_drop_steps"]:
                 prm["max_contacts_per_scene"] = min(65535, max(2 * cur_c if caps["contact_drop_steps"] else cur_c, caps["max_contacts"] * 5 // 4))
-            if cur_p >= 65535 and cur_c >= 65535:
+            if caps["group_drop_steps"]:
+                # the list of touching body pairs (one solver group each): twice what it held, at most every pair of the largest scene
+                nb = max(int(r["body_end"]) - int(r["body_begin"]) for r in srec)
+                cur_g = int(prm["max_body_pairs_per_scene"].reshape(-1)[0]) or 12 * nb + 64
+                if cur_g >= nb * (nb - 1) // 2:
+                    raise RuntimeError("slhip_settle: body pairs were dropped although the list holds every pair (%r)" % (caps,))
+                prm["max_body_pairs_per_scene"] = min(nb * (nb - 1) // 2, 2 * cur_g)
+                prm["max_hull_pairs_per_scene"] = max(int(prm["max_hull_pairs_per_scene"].reshape(-1)[0]) or _abi.DEFAULT_HULL_PAIRS,
+                                                      int(prm["max_body_pairs_per_scene"].reshape(-1)[0]))
+            if cur_p >= 65535 and cur_c >= 65535 and not caps["group_drop_steps"]:
                 raise RuntimeError("slhip_settle: a scene offers more hull pairs / contacts per step than the 16-bit lists hold (%r)" % (caps,))
         else:
             raise RuntimeError("slhip_settle: list capacities still too small after eight attempts (%r)" % (caps,))
@@ -105,11 +114,12 @@ class SettleEngine:
         spill_steps (scene-steps whose contacts went beyond the solver's LDS-resident part: swept from global memory, nothing
         lost), contact_drop_steps / pair_drop_steps (scene-steps that DROPPED contacts / hull pairs beyond the capacities:
         the contract is zero), scenes_dropped, scenes_spilled, max_contacts, max_hull_pairs (the most a step offered),
-        reduced_steps (scene-steps in which pair_contact_budget reduced some body pair's points)."""
+        reduced_steps (scene-steps in which pair_contact_budget reduced some body pair's points), group_drop_steps (scene-steps
+        that dropped body pairs beyond max_body_pairs_per_scene), contact_sum (contacts the solver took over all scene-steps)."""
         eng = self.eng
         if stream is None:
             stream = torch.cuda.current_stream(eng.device).cuda_stream
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 10)()
         if prm is None:
             prm = self._keep[stream][1]
         if scratch is None:
@@ -118,7 +128,7 @@ class SettleEngine:
             st = eng.L.slhip_settle_caps(_abi_ptr(scratch), n_scenes, C.c_void_p(prm.ctypes.data), C.byref(out), C.c_void_p(stream))
         _abi.check(st, "slhip_settle_caps")
         keys = ("spill_steps", "contact_drop_steps", "pair_drop_steps", "scenes_dropped", "scenes_spilled", "max_contacts", "max_hull_pairs",
-                "reduced_steps")
+                "reduced_steps", "group_drop_steps", "contact_sum")
         return {k: int(v) for k, v in zip(keys, out)}
 
     def run_with_caps(self, srec, bodies, params):
@@ -342,18 +352,24 @@ def step_scene(scene, plane, **prm_kw):
     srec, bodies = SB.build_settle_batch([scene], se.pool, [plane])
     hulls = se.pool.arrays()[0]
     prm = SB.sizing_hints(SB.default_params(**prm_kw), srec, bodies, hulls)
-    # one scene's lists cost a few MB at most: sized so that no step of any realistic scene runs out (checked below)
-    prm["max_hull_pairs_per_scene"], prm["max_contacts_per_scene"] = 16384, 16384
+    # A long-lived scene keeps its contact state in ITS scratch, whose layout the capacities fix: they are sized once, from what the
+    # scene can offer at most -- every body pair, every hull pair of two different bodies, four points per hull pair and per body
+    # against the table -- so that no later step can run out (PhysX allocates as it goes, scene.cpp:738-739).  Scenes beyond the
+    # 16-bit lists (hundreds of hulls) get the largest lists there are; a step that still overflows them raises below.
+    hb = (bodies["hull_end"].astype(np.int64) - bodies["hull_begin"].astype(np.int64))
+    all_pairs = int((hb.sum() ** 2 - (hb ** 2).sum()) // 2)
+    nbod = len(bodies)
+    prm["max_hull_pairs_per_scene"] = min(65535, max(64, all_pairs))
+    prm["max_contacts_per_scene"] = min(65535, max(64, 4 * all_pairs + 4 * nbod))
+    prm["max_body_pairs_per_scene"] = max(1, nbod * (nbod - 1) // 2)
     sig = _signature(scene, srec, bodies, prm)
     st = scene._phys_state
     resume = st is not None and st.sig == sig and len(st.bodies) == len(bodies)
     if resume:
         for i, o in enumerate(scene._objects):
             r = st.refs[i]
-            if o._static:
-                continue
             if o._pose is not r[0]:
-                resume = False      # set_pose from outside: a teleport -- the contact state is not this arrangement's
+                resume = False      # set_pose from outside (static bodies too): a teleport -- the contact state is not this arrangement's
                 break
     if st is None:
         st = scene._phys_state = SceneState()

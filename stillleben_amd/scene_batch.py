@@ -160,7 +160,7 @@ class SceneBatch:
         self.shadows = bool(shadows)
         self._set_projection()
         # settle parameters with the sizing hints of the WORST scene the table can produce (no read-back)
-        sp = SB.default_params(tabletop=True)
+        sp = SB.default_params(tabletop=True, pair_contact_budget=SB.PAIR_CONTACT_BUDGET)   # (the compound manifold reduction: slhip.h)
         sp["max_bodies_per_scene"] = self.n_objects
         sp["max_hulls_per_scene"] = table.bound(table.n_hulls, n_objects, distinct)
         sp["max_hull_verts_per_scene"] = table.bound(table.n_hull_verts, n_objects, distinct)
@@ -245,8 +245,18 @@ class SceneBatch:
         self._settle_stream = stream
 
     def check_settled(self):
-        """Synchronises the settle stream; raises if the kernel refused a scene (sizing hints)."""
+        """Synchronises the settle stream; raises if the kernel refused a scene (sizing hints) or if a step of some scene offered
+        more hull pairs / contacts / body pairs than the lists of the scratch hold (slhip.h: nothing is ever dropped silently --
+        the reference has no caps, scene.cpp:738-739).  A caller that gets the second error settles again with larger
+        `settle_params` capacities (the batch is staged from counters, so stage() + settle() reproduce it)."""
         self.se.check_status(self.n_scenes, self._settle_stream)
+        caps = self.settle_caps()
+        if caps["scenes_dropped"]:
+            raise RuntimeError("SceneBatch.settle: %d scene(s) lost hull pairs / contacts / body pairs to the list capacities "
+                               "(max_hull_pairs_per_scene %d, max_contacts_per_scene %d; the most a step offered: %d / %d): raise "
+                               "them in settle_params and settle again (%r)"
+                               % (caps["scenes_dropped"], int(self._settle_keep["max_hull_pairs_per_scene"]),
+                                  int(self._settle_keep["max_contacts_per_scene"]), caps["max_hull_pairs"], caps["max_contacts"], caps))
 
     def settle_caps(self):
         """What the list capacities cost the last settle() (slhip_settle_caps, SettleEngine.caps; synchronises the settle stream)."""

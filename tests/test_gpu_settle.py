@@ -359,7 +359,7 @@ def _oracle_caps(oracle, srec, ref, hulls, verts, prm):
     import ctypes as C
 
     L = oracle.lib()
-    oc = np.zeros((len(srec), 5), np.uint32)
+    oc = np.zeros((len(srec), 7), np.uint32)
     L.slref_settle_set_caps.argtypes = [C.c_void_p]
     L.slref_settle_set_caps(C.c_void_p(oc.ctypes.data))
     try:
@@ -389,6 +389,7 @@ def test_no_contact_is_dropped(sl, oracle):
     assert caps["contact_drop_steps"] == 0 and caps["pair_drop_steps"] == 0 and caps["scenes_dropped"] == 0
     assert int(oc[:, 0].sum()) == 0 and int(oc[:, 1].sum()) == 0
     assert caps["max_contacts"] == int(oc[:, 2].max()) and caps["max_hull_pairs"] == int(oc[:, 3].max())
+    assert caps["contact_sum"] == int(oc[:, 6].astype(np.uint64).sum()) > 0 and caps["group_drop_steps"] == int(oc[:, 5].sum()) == 0
     assert caps["max_contacts"] > 255                      # beyond round 3's cap ...
     assert caps["spill_steps"] > 0 and caps["scenes_spilled"] > 0      # ... and beyond the LDS-resident part: the case is exercised
     assert caps["reduced_steps"] == 0
@@ -434,6 +435,36 @@ def test_undersized_capacities_are_counted(sl, oracle):
     oracle.settle(srec, ref2, hulls, verts, big)
     assert_bodies_equal(grown, ref2)
     assert se.caps(len(srec))["scenes_dropped"] == 0
+
+
+def test_body_pair_list_is_a_capacity_the_host_grows(sl, oracle):
+    """The list of touching body pairs (one solver group each) is sized by the caller (max_body_pairs_per_scene): a pair beyond it
+    is dropped AND counted in a word of its own -- identically on both sides -- and the host path settles again with a list
+    that holds what the scene offers: the result is the one of a list that never ran out."""
+    from stillleben_amd import physics
+
+    cube = scaled(sl, S.CUBE, 0.15)
+    scs = [heap(sl, 1300 + i, 9, cube) for i in range(4)]
+    se = physics.settle_engine()
+    srec, bodies = SB.build_settle_batch(scs, se.pool, [(True, TABLE)] * len(scs))
+    prm = SB.default_params(frames=25)
+    prm["max_body_pairs_per_scene"] = 3
+    gpu, caps = se.run_with_caps(srec, bodies.copy(), prm)
+    hulls, verts = se.pool.arrays()
+    ref = bodies.copy()
+    oc = _oracle_caps(oracle, srec, ref, hulls, verts, SB.sizing_hints(prm, srec, bodies, hulls))
+    assert_bodies_equal(gpu, ref)
+    assert caps["group_drop_steps"] == int(oc[:, 5].sum()) > 0
+    assert caps["pair_drop_steps"] == int(oc[:, 1].sum()) == 0           # ... and the hull-pair statistics stay what they are
+    assert caps["max_hull_pairs"] == int(oc[:, 3].max())
+    assert caps["scenes_dropped"] == int((oc[:, 5] > 0).sum()) > 0
+    small = SB.default_params(frames=25)
+    small["max_body_pairs_per_scene"] = 3
+    grown = se.run(srec, bodies.copy(), small)
+    ref2 = bodies.copy()
+    oracle.settle(srec, ref2, hulls, verts, SB.default_params(frames=25))
+    assert_bodies_equal(grown, ref2)
+    assert se.caps(len(srec))["scenes_dropped"] == 0 and int(np.asarray(se.last_params["max_body_pairs_per_scene"]).reshape(-1)[0]) >= 12
 
 
 # ---- the contact state outlives the call (slhip_settle_params.resume; PhysX: one PxScene per sl.Scene) ----------------------

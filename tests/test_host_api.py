@@ -26,7 +26,7 @@ def test_abi_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_abi.lib_path())
     for n in sorted(names):
         assert hasattr(L, n), "libslhip.so does not export %s" % n
-    assert _abi.lib().slhip_abi_version() == 3
+    assert _abi.lib().slhip_abi_version() == _abi.ABI_VERSION == 4
     assert _abi.lib().slhip_last_error() is not None
 
 

@@ -39,7 +39,7 @@ def export(path, meshes, n_scenes=8, n_objects=4, resolution=(320, 240), seed=11
     p["manual_exposure"] = 1.0
     p["light_color"][:3] = 300.0
     p["ambient"][:3] = 0.05
-    sp = SB.default_params(tabletop=True, frames=frames)
+    sp = SB.default_params(tabletop=True, frames=frames, pair_contact_budget=SB.PAIR_CONTACT_BUDGET)   # as sl.SceneBatch settles
     sp["max_bodies_per_scene"] = n_objects
     sp["max_hulls_per_scene"] = table.bound(table.n_hulls, n_objects, True)
     sp["max_hull_verts_per_scene"] = table.bound(table.n_hull_verts, n_objects, True)

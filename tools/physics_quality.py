@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (CPU, oracle): how well the settle comes to rest on the C2 workload -- share of bodies
 with |v| < 0.05 m/s after the 400 steps, share asleep, redrops per scene, deepest penetration, bodies below the table.
-    python tools/physics_quality.py [n_scenes] [first_seed] [n_objects] [threads]
+    python tools/physics_quality.py [n_scenes] [first_seed] [n_objects] [threads] [pair_contact_budget = 32, sl.SceneBatch's]
 Scenes are independent: they are settled on `threads` processes (fork)."""
 import os
 import sys
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def stage(n, seed0, n_objects):
+def stage(n, seed0, n_objects, budget=32):
     import bench
     import oracle
     import stillleben_amd as sl
@@ -33,7 +33,7 @@ def stage(n, seed0, n_objects):
     p["max_clip_verts_per_scene"] = table.bound(table.n_clip, n_objects, True) + 4
     p["plane_z"] = 0.04
     bodies, ss, objs, scs = oracle.synth_stage(p, table.records)
-    return bodies, ss, hull_recs, hull_verts, SB.default_params(tabletop=True)
+    return bodies, ss, hull_recs, hull_verts, SB.default_params(tabletop=True, pair_contact_budget=budget)
 
 
 def settle_range(args):
@@ -46,7 +46,7 @@ def settle_range(args):
     frames = int(prm["frames"])
     sub = ss[lo:hi].copy()
     trace = np.zeros((hi - lo, frames, 4), np.float32)
-    caps = np.zeros((hi - lo, 5), np.uint32)
+    caps = np.zeros((hi - lo, 7), np.uint32)
     L.slref_settle_set_trace.argtypes = [C.c_void_p]
     L.slref_settle_set_caps.argtypes = [C.c_void_p]
     L.slref_settle_set_trace(C.c_void_p(trace.ctypes.data))
@@ -60,10 +60,10 @@ def settle_range(args):
     return lo, hi, bodies[b0:b1].copy(), trace, caps
 
 
-def measure(n=64, seed0=900000, n_objects=20, threads=8, quiet=False):
+def measure(n=64, seed0=900000, n_objects=20, threads=8, budget=32, quiet=False):
     import multiprocessing as mp
 
-    bodies, ss, hull_recs, hull_verts, prm = stage(n, seed0, n_objects)
+    bodies, ss, hull_recs, hull_verts, prm = stage(n, seed0, n_objects, budget)
     threads = max(1, min(threads, n))
     cuts = np.linspace(0, n, threads + 1).astype(int)
     jobs = [(bodies, ss, hull_recs, hull_verts, prm, int(cuts[i]), int(cuts[i + 1])) for i in range(threads) if cuts[i + 1] > cuts[i]]
@@ -74,7 +74,7 @@ def measure(n=64, seed0=900000, n_objects=20, threads=8, quiet=False):
         res = [settle_range(j) for j in jobs]
     frames = int(prm["frames"])
     trace = np.zeros((n, frames, 4), np.float32)
-    caps = np.zeros((n, 5), np.uint32)
+    caps = np.zeros((n, 7), np.uint32)
     for lo, hi, b, t, c in res:
         b0, b1 = int(ss[lo]["body_begin"]), int(ss[hi - 1]["body_end"])
         bodies[b0:b1] = b
@@ -101,7 +101,8 @@ def measure(n=64, seed0=900000, n_objects=20, threads=8, quiet=False):
         "contact_drop_steps": int(caps[:, 0].sum()),      # scene-steps that dropped contacts / hull pairs beyond the default capacities
         "pair_drop_steps": int(caps[:, 1].sum()),
         "max_contacts_offered": int(caps[:, 2].max()), "max_hull_pairs_found": int(caps[:, 3].max()),
-        "pair_budget_reduced_steps": int(caps[:, 4].sum()),
+        "pair_budget": int(prm["pair_contact_budget"]), "pair_budget_reduced_steps": int(caps[:, 4].sum()),
+        "group_drop_steps": int(caps[:, 5].sum()), "contacts_per_scene_step": float(caps[:, 6].sum()) / (n * frames * int(prm["substeps"])),
         "asleep_by_frame": [float(trace[:, f, 0].mean()) for f in (24, 49, 74, 99) if f < frames],
     }
     if not quiet:
@@ -112,4 +113,4 @@ def measure(n=64, seed0=900000, n_objects=20, threads=8, quiet=False):
 
 if __name__ == "__main__":
     a = [int(x) for x in sys.argv[1:]]
-    measure(*(a + [64, 900000, 20, 8][len(a):]))
+    measure(*(a + [64, 900000, 20, 8, 32][len(a):]))

@@ -31,7 +31,7 @@ L.slref_settle_set_profile_dump(b"/tmp/profile.txt")
 h = np.zeros(1096, np.uint64)
 L.slref_settle_set_stats.argtypes=[C.c_void_p]
 L.slref_settle_set_stats(h.ctypes.data_as(C.c_void_p))
-oracle.settle(ss, bodies, hull_recs, hull_verts, SB.default_params(tabletop=True))
+oracle.settle(ss, bodies, hull_recs, hull_verts, SB.default_params(tabletop=True, pair_contact_budget=SB.PAIR_CONTACT_BUDGET))
 L.slref_settle_set_stats(None)
 L.slref_settle_set_profile_dump(None)
 # file: scene-major (scene 0 steps 0..399, scene 1 ...)

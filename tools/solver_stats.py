@@ -30,7 +30,7 @@ p["max_chunks_per_scene"] = table.bound(table.n_chunks, bench.N_OBJECTS, True) +
 p["max_clip_verts_per_scene"] = table.bound(table.n_clip, bench.N_OBJECTS, True) + 4
 p["plane_z"] = 0.04
 bodies, ss, objs, scs = oracle.synth_stage(p, table.records)
-st = oracle.settle_stats(ss, bodies, hull_recs, hull_verts, SB.default_params(tabletop=True))
+st = oracle.settle_stats(ss, bodies, hull_recs, hull_verts, SB.default_params(tabletop=True, pair_contact_budget=SB.PAIR_CONTACT_BUDGET))
 gi = st.pop("gjk_iters").astype(np.float64)
 print("main GJK runs per step and scene: %.1f; share by iterations:" % (gi.sum() / max(1.0, st["active"].sum())),
       " ".join("%d:%.3f" % (i, gi[i] / gi.sum()) for i in range(len(gi)) if gi[i] / gi.sum() >= 0.002))
