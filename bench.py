@@ -501,12 +501,18 @@ def main():
             "scenes_whose_contacts_left_the_lds_part": cp["scenes_spilled"], "share_of_scenes_spilled": cp["scenes_spilled"] / args.batch,
             "spill_step_rate": cp["spill_steps"] / scene_steps,
             "most_contacts_in_a_step": cp["max_contacts"], "most_hull_pairs_in_a_step": cp["max_hull_pairs"],
+            "body_pair_drop_steps": cp["group_drop_steps"],
+            "contacts_per_scene_step": cp["contact_sum"] / scene_steps,
+            "pair_contact_budget": int(b_last.settle_params["pair_contact_budget"]),
+            "reduced_steps": cp["reduced_steps"], "reduced_step_rate": cp["reduced_steps"] / scene_steps,
             "solver_wave_lds_bytes": 32768,
             "contact_capacity": int(b_last.settle_params["max_contacts_per_scene"]) or _header_define("SLHIP_DEFAULT_CONTACTS"),
             "hull_pair_capacity": int(b_last.settle_params["max_hull_pairs_per_scene"]) or _header_define("SLHIP_DEFAULT_HULL_PAIRS"),
             "note": "one settle of the step's scenes after the timed region (slhip_settle_caps): the solver takes every contact a step "
                     "offers -- from LDS as far as the scene's solver wave holds them (waves of 1 / 2 / 4 scenes by need), the rest swept from global memory (`spilled`: nothing lost); a "
-                    "drop happens only beyond the capacities the scratch was sized with and must be zero"}
+                    "drop happens only beyond the capacities the scratch was sized with and must be zero.  pair_contact_budget: the "
+                    "compound manifold reduction sl.SceneBatch asks for (NOT in the reference; 0 = every point, as in PhysX): a body pair "
+                    "touching through more hull pairs keeps the deepest ones -- `reduced_steps` scene-steps had such a pair"}
     # the exchange step alone: the same shard gathered synchronously after the timed region (inside it the collective runs
     # beside the next chunks' render on its own stream)
     exchange = None
@@ -533,7 +539,7 @@ def main():
     out = None
     if rank == 0:
         out = report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso,
-                     phases, iso, settle_kernels)
+                     phases, iso, settle_kernels, caps)
         out["caps"] = caps
         out["exchange"] = exchange
         if not args.no_cpu_baseline and world == 1:
@@ -547,21 +553,37 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def kernel_source_sha():
+    """Fingerprint of the kernel sources (stillleben_amd/csrc/*.hip|*.inc|*.h, include/slhip.h): tools/collect_counters.py files it
+    with the counters it takes, and the roofline below only multiplies a live time by a counter taken from THESE sources."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "stillleben_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/slhip.h"]:
+        if f.endswith((".hip", ".inc", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_counters():
     """SQ / HBM counters of the dominant kernels, collected by tools/collect_counters.py from separate rocprofv3 --pmc
-    passes at the bench shape and committed under profiles/ (the latest round's file wins)."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    passes at the bench shape and committed under profiles/ (the latest round's file wins).  `stale` says that the kernel
+    sources changed since the counters were taken: per-instruction figures are then not quoted."""
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "counters.json")
         if os.path.exists(path):
             with open(path) as f:
                 c = json.load(f)
             c["source"] = "profiles/%s/counters.json" % rnd
+            c["stale"] = c.get("kernel_source_sha") != kernel_source_sha()
             return c
     return {}
 
 
 def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso, phases, iso,
-           settle_kernels):
+           settle_kernels, caps=None):
     W, H = RESOLUTION
     P = W * H
     total_scenes = args.batch * world * args.steps
@@ -619,7 +641,8 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
     if lockstep:
         kname = "k_w_solve"
         sq = ck.get(kname, {})
-        contacts = sq.get("contacts_per_scene_step", 45.0)   # mean active contacts per scene and step (tools/solver_stats.py, round 3)
+        # mean contacts the solver took per scene and step: counted by the kernels themselves (slhip_settle_caps counts[9])
+        contacts = caps["contacts_per_scene_step"] if caps else sq.get("contacts_per_scene_step", 45.0)
         # per launch (= one step of every scene): the scene's working bodies (152 B) and prepared contacts (72 B) in, group /
         # colour lists in, the body records (288 B) out -- DESIGN.md section 4
         per_scene = N_OBJECTS * 152 + contacts * 72 + 1500 + N_OBJECTS * 288
@@ -635,12 +658,13 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
         launches_per_settle = 1
         measured = "HIP events on the launch's stream around every slhip_settle of the timed region"
     alg = per_scene * args.batch
-    valu_per_launch = sq.get("valu_insts_per_scene_launch")
+    stale = bool(cnt.get("stale", True))
+    valu_per_launch = None if stale else sq.get("valu_insts_per_scene_launch")
     # The dominant kernel is bound by VALU issue, not by HBM: `achieved` = wave64 VALU instructions issued per second (SQ_INSTS_VALU
     # of the counters file x scenes per launch / the launch duration measured live), `peak` = one instruction per 2.3 cycles and SIMD
     # -- the rate tools/probes/pk_probe.hip measured for streams of independent v_fma_f32 with several waves per SIMD (a single wave
     # issues every 4.5 cycles).  The HBM figures the schema names stay beside it under "hbm".
-    issue_peak = 1024 * 2.4e9 / 2.3 / 1e9
+    issue_peak = 1024 * 2.4e9 / 2.0 / 1e9     # the guide's figure: a wave64 v_fma_f32 occupies its SIMD for 2 cycles (MI355X_MICROARCH.md)
     hbm = {"achieved": alg / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else None, "peak": 8000.0, "unit": "GB/s",
            "algorithmic_bytes_per_launch": alg, "traffic": sq["hbm_bytes_per_scene"] * args.batch if "hbm_bytes_per_scene" in sq else None}
     if hbm["achieved"] is not None:
@@ -657,7 +681,9 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
                 "taken in the timed region, where the kernel shares the GPU with the render streams (the event pairs also bracket its "
                 "wait for free CU slots); *_alone: one settle with the GPU to itself after the timed region",
         "valu_insts_per_scene_launch": valu_per_launch,
-        "peak_source": "1024 SIMDs x 2.4 GHz / 2.3 cycles per wave64 VALU instruction (tools/probes/pk_probe.hip, 16 waves per CU)",
+        "peak_source": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md); tools/probes/pk_probe.hip "
+                       "measured 2.3 cycles for streams of independent v_fma_f32 at 16 waves per CU (peak 1068.5: the fraction would read 15 % higher)",
+        "counters_stale": stale, "counters_kernel_source_sha": cnt.get("kernel_source_sha"), "kernel_source_sha": kernel_source_sha(),
         "active_lanes": sq.get("active_lanes"),
         "ms_per_launch_alone": settle_kernels[kname].get("avg_ms_per_launch_alone") if lockstep else None,
         "counters_source": cnt.get("source"),
@@ -686,6 +712,7 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
                         "all four stages inside the timed region" % (args.batch, "off" if args.no_ssao else "on"),
             "scenes_per_gpu_per_step": args.batch, "render_chunk": args.render_chunk, "resolution": list(RESOLUTION),
             "objects": N_OBJECTS, "settle_streams": len(pipe.s_settle), "render_streams": len(pipe.s_render_all),
+            "pair_contact_budget": caps["pair_contact_budget"] if caps else None,   # (slhip.h; 0 = every contact point, as in PhysX)
             "parallelism": ("scenes sharded by rank, no data-path collective; exchange: RCCL all-gather of a %d-scene C3 shard per "
                             "rank and step (%.0f MB per rank) -- %d of the %d scenes a rank renders per step are exchanged"
                             % (pipe.gather_scenes, pipe.gather_scenes * P * 40 / 1e6, pipe.gather_scenes, args.batch)) if world > 1 else "1 GPU",

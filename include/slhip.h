@@ -217,7 +217,8 @@ typedef struct {
 typedef struct {
     uint64_t* d_vis;          /* u64 [B,H,W] visibility keys (depth24<<32 | prim id)         */
     float*    d_hdr;          /* f32 [B,H,W,4] HDR colour (ssaoRGBInput / postprocessInput)  */
-    float*    d_ao;           /* f32 [B,H,W] occlusion + f32 [B,H+2,W+2] camera-z plane (SSAO)  */
+    float*    d_ao;           /* f32 [B,H,W] occlusion + f32 [B,H+2,W+2] camera-z plane + per 8 x 8 tile a
+                                 float2 record and a skip byte (SSAO; slhip_render_scratch_bytes sizes it) */
     float*    d_shadow;       /* f32 [B,NUM_LIGHTS,S,S] shadow depth (only active lights)    */
     uint32_t* d_queue;        /* large-triangle work queue: [0]=count, then (prim,tile) pairs */
     float*    d_lum;          /* f32 [B,4] HDR sums for auto exposure                        */
@@ -255,6 +256,12 @@ int slhip_render(const slhip_mesh_pool* pool,
  * 7 tone map.  slhip_render_timings synchronises on the last render and fills ms_out[8].    */
 int slhip_timing_enable(int on);
 int slhip_render_timings(float* ms_out);
+/* The SSAO pass runs its 64 taps only where something can occlude: on the open background plane (every texel a tap can reach
+ * belongs to the plane or to the cleared background, no tap leaves the image) the occlusion is 1 exactly, and whole 8 x 8 tiles are
+ * written without the loop (viewports that are multiples of 32 x 16; slhip_render.hip k_ssao_mask).  This read-out of the last
+ * slhip_render on `scratch` (same n_scenes, width, height) returns counts[0] = tiles, counts[1] = tiles skipped; synchronises.  */
+int slhip_render_ssao_skipped(const slhip_render_scratch* scratch, uint32_t n_scenes, uint32_t width, uint32_t height,
+                              uint64_t counts[2], void* stream);
 
 /* Bytes of each scratch buffer for a batch (host helper, no GPU needed).  `hdr` is sized for TWO float4 planes per scene: plane 0
  * = the fragment shader's linear colour (always written when rgb is asked for), plane 1 = the same after ambient occlusion, the

@@ -271,6 +271,7 @@ def lib():
     L.slhip_records_count.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.slhip_records_build_render.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                              C.c_uint32, C.c_void_p, C.c_uint32]
+    L.slhip_render_ssao_skipped.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64 * 2), C.c_void_p]
     L.slhip_settle_caps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64 * 10), C.c_void_p]
     L.slhip_settle_timing_enable.argtypes = [C.c_int]
     L.slhip_settle_timings.argtypes = [C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32 * 5)]

@@ -117,6 +117,17 @@ class Engine:
         a.shadow_lights = shadow_lights
         return a, s
 
+    def ssao_skipped(self, buffers, W, H):
+        """(tiles, tiles skipped) of the SSAO pass of the render that filled `buffers` (slhip_render_ssao_skipped; synchronises)."""
+        keep = buffers._keepalive[0]
+        a = _abi.RenderScratch()
+        a.d_ao = _ptr(keep["ao"])
+        out = (C.c_uint64 * 2)()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _abi.check(self.L.slhip_render_ssao_skipped(C.byref(a), buffers.B, W, H, C.byref(out), C.c_void_p(stream)), "slhip_render_ssao_skipped")
+        return int(out[0]), int(out[1])
+
     # ---- render ----------------------------------------------------------------------------
     def upload_records(self, arr):
         raw = np.frombuffer(arr.tobytes(), dtype=np.uint8) if arr.size else np.zeros(16, np.uint8)

@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(256) SLHIP_SHADE_KERNEL void k_shade(slhip_mesh_poo
                                                slhip_render_out out, float* __restrict__ hdr,
                                                const float* __restrict__ shadow, float* __restrict__ lum_part,
                                                const float4* __restrict__ clipbuf, float* __restrict__ zplane,
-                                               const float4* __restrict__ vattr)
+                                               const float4* __restrict__ vattr, float2* __restrict__ ssao_tiles)
 {
     const int W = prm.W, H = prm.H;
     const size_t P = (size_t)W * H;
@@ -1588,6 +1588,7 @@ __global__ __launch_bounds__(256) SLHIP_SHADE_KERNEL void k_shade(slhip_mesh_poo
         float bary[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         unsigned vidx[4] = {0u, 0u, 0u, 0u};
         unsigned cls = 0u, inst = 0u;
+        bool plane_px = false;     // a pixel of the background plane (flat, geometric normal): see k_ssao_mask
         if (key != kVisEmpty) {
             const unsigned prim = (unsigned)(key & 0xFFFFFFFFull);
             unsigned d = sc->draw_begin;
@@ -1759,6 +1760,7 @@ __global__ __launch_bounds__(256) SLHIP_SHADE_KERNEL void k_shade(slhip_mesh_poo
                 shade_fragment(sc, dr, base, world, nrm, front, sm, prm.S, prm.shadow_lights, lm, roughness, metallic, occlusion, emissive, color, nout);
                 cls = dr->class_index & 0xFFFFu;
                 inst = dr->instance_index & 0xFFFFu;
+                plane_px = (dr->flags & (SLHIP_DRAW_NO_VERTEX_ID | SLHIP_DRAW_HAS_NORMAL_TEX)) == SLHIP_DRAW_NO_VERTEX_ID && inst == 0u;
                 if (!(dr->flags & SLHIP_DRAW_NO_VERTEX_ID)) { vidx[0] = vi[0] + 1; vidx[1] = vi[1] + 1; vidx[2] = vi[2] + 1; }
                 bary[0] = b[0]; bary[1] = b[1]; bary[2] = b[2];
             }
@@ -1812,6 +1814,21 @@ __global__ __launch_bounds__(256) SLHIP_SHADE_KERNEL void k_shade(slhip_mesh_poo
             if (r && t) zp[o - Wp + 1] = z;
             if (l && b) zp[o + Wp - 1] = z;
             if (r && b) zp[o + Wp + 1] = z;
+        }
+        if (ssao_tiles) {
+            // what k_ssao_mask needs of the wave's 8 x 8 tile: the nearest camera z of its geometry, and whether any of it is
+            // something else than the background plane (tiled placement only: the wave IS the tile, every lane is active)
+            const bool geo = key != kVisEmpty;
+            const unsigned long long other = __ballot(geo && !plane_px), any = __ballot(geo);
+            float zm = geo ? camc[2] : 3.0e38f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) zm = fminf(zm, __shfl_xor(zm, o, 64));
+            if ((threadIdx.x & 63u) == 0u) {
+                const unsigned tw = (unsigned)W >> 3;
+                const unsigned tx = (pix % (unsigned)W) >> 3, ty = (pix / (unsigned)W) >> 3;
+                ssao_tiles[(size_t)scene * (tw * ((unsigned)H >> 3)) + ty * tw + tx] =
+                    make_float2(zm, __uint_as_float((other ? 1u : 0u) | (any ? 2u : 0u)));
+            }
         }
         if (prm.inline_tonemap) {
             if (out.d_rgb) reinterpret_cast<uchar4*>(out.d_rgb)[gp] = tone_map_px(color, sc->manual_exposure, 0.0f);
@@ -1884,29 +1901,12 @@ __device__ __forceinline__ float ssao_rcp(float x)
     return __uint_as_float((__float_as_uint(r) & 0x7fffffffu) | (__float_as_uint(x) & 0x80000000u));
 }
 
-__global__ __launch_bounds__(256) SLHIP_SSAO_KERNEL void k_ssao(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
-                                              const float* __restrict__ cam, const float* __restrict__ nrm,
-                                              const float* __restrict__ zplane, float* __restrict__ ao,
-                                              const float* __restrict__ kern)
+// occlusion of one pixel with geometry (normal n4, camera position f4): ssao_shader.frag:20-56 as the oracle's ssao_pass spells it
+__device__ __forceinline__ float ssao_pixel(const float* __restrict__ proj, const float* __restrict__ camS, int W, int H, int i, int j,
+                                            float4 n4, float4 f4, const float* __restrict__ kern)
 {
-    const size_t P = (size_t)W * H;
-    const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
-    unsigned scene, blk;
-    if (!scene_block(blocks_per_scene, n_scenes, scene, blk)) return;
-    // A wave takes the pixels of ONE column class (x & 3) of the block's 256-pixel strip: the 4x4 noise tile rotates the
-    // sample kernel per class, so the 64 taps of a sample then move together and land in one strip of the z plane per row
-    // (8-9 cache lines per load instead of the ~12 of four interleaved, differently shifted classes).  Placement only.
-    const unsigned pix = blk * 256 + (threadIdx.x >> 6) + 4u * (threadIdx.x & 63u);
-    if (pix >= P) return;
-    const float* proj = scenes[scene].proj;
-    const float* camS = zplane + (size_t)scene * ((size_t)(W + 2) * (H + 2));
-    const size_t gp = (size_t)scene * P + pix;
-    const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
-    const float4 n4 = reinterpret_cast<const float4*>(nrm)[gp];
     float n[3] = {n4.x, n4.y, n4.z};
-    if (n[0] == 0.0f && n[1] == 0.0f && n[2] == 0.0f) { ao[gp] = 1.0f; return; }
     normalize3(n);
-    const float4 f4 = reinterpret_cast<const float4*>(cam)[gp];
     const float frag[3] = {f4.x, f4.y, f4.z};
     const float* rv0 = &c_ssao_noise[3 * ((j & 3) * 4 + (i & 3))];
     float rv[3] = {rv0[0], rv0[1], rv0[2]};
@@ -1958,7 +1958,164 @@ __global__ __launch_bounds__(256) SLHIP_SSAO_KERNEL void k_ssao(const slhip_scen
     };
     if (w_is_z) taps(std::true_type{});   // scene-uniform: the whole wave takes one side
     else taps(std::false_type{});
-    ao[gp] = 1.0f - occlusion / 64.0f;
+    return 1.0f - occlusion / 64.0f;
+}
+
+__global__ __launch_bounds__(256) SLHIP_SSAO_KERNEL void k_ssao(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
+                                              const float* __restrict__ cam, const float* __restrict__ nrm,
+                                              const float* __restrict__ zplane, float* __restrict__ ao,
+                                              const float* __restrict__ kern)
+{
+    const size_t P = (size_t)W * H;
+    const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
+    unsigned scene, blk;
+    if (!scene_block(blocks_per_scene, n_scenes, scene, blk)) return;
+    // A wave takes the pixels of ONE column class (x & 3) of the block's 256-pixel strip: the 4x4 noise tile rotates the
+    // sample kernel per class, so the 64 taps of a sample then move together and land in one strip of the z plane per row
+    // (8-9 cache lines per load instead of the ~12 of four interleaved, differently shifted classes).  Placement only.
+    const unsigned pix = blk * 256 + (threadIdx.x >> 6) + 4u * (threadIdx.x & 63u);
+    if (pix >= P) return;
+    const float* proj = scenes[scene].proj;
+    const float* camS = zplane + (size_t)scene * ((size_t)(W + 2) * (H + 2));
+    const size_t gp = (size_t)scene * P + pix;
+    const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
+    const float4 n4 = reinterpret_cast<const float4*>(nrm)[gp];
+    if (n4.x == 0.0f && n4.y == 0.0f && n4.z == 0.0f) { ao[gp] = 1.0f; return; }
+    ao[gp] = ssao_pixel(proj, camS, W, H, i, j, n4, reinterpret_cast<const float4*>(cam)[gp], kern);
+}
+
+// ---- SSAO only where something can occlude ----------------------------------------------------------------------------------
+// On the open background plane no tap occludes: the 64 samples lie in the hemisphere over the plane (kernel z >= 0, |sample| <=
+// radius), so along the ray through a sample the plane is never nearer than the sample, and `sd <= spz - bias` fails by the bias
+// (2.5 mm against the micrometres of the bilinear fetch) -- AS LONG AS every texel a tap can reach belongs to that plane or to
+// the cleared background (z = 3000) and no tap leaves the image (a clamped fetch returns the plane's depth somewhere else).  Then
+// occlusion = 0 and ao = 1 - 0 / 64 = 1 exactly, which is what the full loop computes.  k_shade files, per 8 x 8 tile, the nearest
+// camera z and whether the tile holds anything but that plane; k_ssao_mask marks the tiles whose reach -- a sample is at most
+// `radius` from its pixel's position P = (X, Y, Z), so it projects within fx radius sqrt(1 + (X/Z)^2) / (Z - radius) pixels of it
+// (Cauchy-Schwarz on (dx Z - X dz) / (Z (Z + dz))), + 2 for the bilinear footprint and rounding -- stays inside the image and
+// touches plane / background tiles only (a summed-area table of the "other" flags in LDS); k_ssao_tiled writes 1 there and runs
+// the taps for the rest, compacted: a wave walks the pixels of ONE noise class (x & 3, y & 3) of a 16-row band in raster order
+// and queues those that need the loop, 64 at a time (the taps of a wave still move together).
+constexpr int kSsaoTile = 8;
+__global__ __launch_bounds__(256) void k_ssao_mask(const slhip_scene* __restrict__ scenes, int W, int H,
+                                                  const float2* __restrict__ tiles, unsigned char* __restrict__ skip, int dbg)
+{
+    extern __shared__ int s_sat[];              // (TH + 1) x (TW + 1)
+    const int TW = W / kSsaoTile, TH = H / kSsaoTile, SW = TW + 1;
+    const unsigned scene = blockIdx.x;
+    const float2* T = tiles + (size_t)scene * (TW * TH);
+    unsigned char* S = skip + (size_t)scene * (TW * TH);
+    const float* proj = scenes[scene].proj;
+    // the rule is derived for a plain perspective projection (no skew, w = camera z): anything else runs every pixel
+    const bool persp = proj[1] == 0.0f && proj[3] == 0.0f && proj[4] == 0.0f && proj[7] == 0.0f &&
+                       proj[12] == 0.0f && proj[13] == 0.0f && proj[14] == 1.0f && proj[15] == 0.0f && proj[0] > 0.0f && proj[5] > 0.0f;
+    for (int k = threadIdx.x; k < (TH + 1) * SW; k += 256) {
+        const int r = k / SW, c = k % SW;
+        s_sat[k] = (r > 0 && c > 0) ? (int)(__float_as_uint(T[(r - 1) * TW + (c - 1)].y) & 1u) : 0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x + 1; r <= TH; r += 256) { int acc = 0; for (int c = 1; c <= TW; ++c) { acc += s_sat[r * SW + c]; s_sat[r * SW + c] = acc; } }
+    __syncthreads();
+    for (int c = threadIdx.x + 1; c <= TW; c += 256) { int acc = 0; for (int r = 1; r <= TH; ++r) { acc += s_sat[r * SW + c]; s_sat[r * SW + c] = acc; } }
+    __syncthreads();
+    const float fx = proj[0] * 0.5f * (float)W, fy = proj[5] * 0.5f * (float)H;
+    const float tx = (1.0f + fabsf(proj[2])) / proj[0], ty = (1.0f + fabsf(proj[6])) / proj[5];   // largest |X / Z|, |Y / Z| in the image
+    const float tmax = fmaxf(tx, ty);
+    const float reach = fmaxf(fx, fy) * 0.1f * sqrtf(1.0f + tmax * tmax) * 1.001f;
+    for (int k = threadIdx.x; k < TW * TH; k += 256) {
+        const float2 t = T[k];
+        const unsigned fl = __float_as_uint(t.y);
+        unsigned char sk = 0;
+        if (!(fl & 2u)) sk = 1;                                   // no geometry at all: every pixel is 1 anyway
+        else if (persp && !(fl & 1u) && t.x > 0.2f) {
+            const int R = (int)ceilf(reach / (t.x - 0.1f)) + 2;
+            const int x0 = (k % TW) * kSsaoTile - R, x1 = (k % TW) * kSsaoTile + kSsaoTile - 1 + R;
+            const int y0 = (k / TW) * kSsaoTile - R, y1 = (k / TW) * kSsaoTile + kSsaoTile - 1 + R;
+            if (x0 >= 0 && y0 >= 0 && x1 < W && y1 < H) {
+                const int ca = x0 / kSsaoTile, cb = x1 / kSsaoTile + 1, ra = y0 / kSsaoTile, rb = y1 / kSsaoTile + 1;
+                const int others = s_sat[rb * SW + cb] - s_sat[ra * SW + cb] - s_sat[rb * SW + ca] + s_sat[ra * SW + ca];
+                sk = others == 0 ? 1 : 0;
+            }
+        }
+        S[k] = dbg == 1 ? 1 : dbg == 2 ? 0 : sk;
+    }
+}
+
+// grid: scenes x (H / 16) bands x 4 row classes; block = 4 waves = the 4 column classes of the same rows (their normal / position
+// fetches share cache lines)
+__global__ __launch_bounds__(256) SLHIP_SSAO_KERNEL void k_ssao_tiled(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
+                                                    const float* __restrict__ cam, const float* __restrict__ nrm,
+                                                    const float* __restrict__ zplane, float* __restrict__ ao,
+                                                    const float* __restrict__ kern, const unsigned char* __restrict__ skip)
+{
+    __shared__ unsigned s_q[4][128];
+    __shared__ float4 s_n[4][128];              // the queued pixels' normals (read once, in the scan)
+    const unsigned bands = (unsigned)H >> 4;
+    unsigned scene, rest;
+    if (!scene_block(bands * 4u, n_scenes, scene, rest)) return;       // (all blocks of a scene on one XCD: its z plane in ONE L2)
+    const unsigned band = rest >> 2, yc = rest & 3u, xc = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const size_t P = (size_t)W * H;
+    const float* proj = scenes[scene].proj;
+    const float* camS = zplane + (size_t)scene * ((size_t)(W + 2) * (H + 2));
+    const int TW = W / kSsaoTile;
+    const unsigned char* S = skip + (size_t)scene * ((size_t)TW * (H / kSsaoTile));
+    const float4* N4 = reinterpret_cast<const float4*>(nrm) + (size_t)scene * P;
+    const float4* C4 = reinterpret_cast<const float4*>(cam) + (size_t)scene * P;
+    float* A = ao + (size_t)scene * P;
+    unsigned* q = s_q[xc];
+    float4* qn = s_n[xc];
+    const unsigned per_row = (unsigned)W >> 2, total = 4u * per_row;       // the class's pixels in the band: 4 rows x W / 4
+    unsigned count = 0;
+    auto run = [&](unsigned n_run) {
+        // the first n_run (<= 64) queued pixels
+        if (lane < n_run) {
+            const unsigned pix = q[lane];
+            const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
+            A[pix] = ssao_pixel(proj, camS, W, H, i, j, qn[lane], C4[pix], kern);
+        }
+    };
+    // one chunk of candidates ahead: the loads of the next scan are in flight while the taps of the queue run
+    auto pixel_of = [&](unsigned ci) -> unsigned { return (band * 16u + yc + 4u * (ci / per_row)) * (unsigned)W + xc + 4u * (ci % per_row); };
+    auto fetch = [&](unsigned ci, unsigned& pix, bool& sk, float4& n4) {
+        pix = 0; sk = true; n4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (ci < total) {
+            pix = pixel_of(ci);
+            const unsigned y = pix / (unsigned)W, x = pix % (unsigned)W;
+            sk = S[(y >> 3) * (unsigned)TW + (x >> 3)] != 0;
+            if (!sk) n4 = N4[pix];
+        }
+    };
+    unsigned pix_n; bool sk_n; float4 n4_n;
+    fetch(lane, pix_n, sk_n, n4_n);
+    for (unsigned c0 = 0; c0 < total; c0 += 64u) {
+        const unsigned pix = pix_n;
+        const bool sk = sk_n;
+        const float4 n4 = n4_n;
+        const bool valid = c0 + lane < total;
+        fetch(c0 + 64u + lane, pix_n, sk_n, n4_n);
+        const bool need = valid && !sk && !(n4.x == 0.0f && n4.y == 0.0f && n4.z == 0.0f);
+        if (valid && !need) A[pix] = 1.0f;
+        const unsigned long long m = __ballot(need);
+        if (need) {
+            const unsigned at = count + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            q[at] = pix; qn[at] = n4;
+        }
+        count += (unsigned)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (count >= 64u) {
+            run(64u);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned left = count - 64u;
+            unsigned mv = 0;
+            float4 mn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (lane < left) { mv = q[64u + lane]; mn = qn[64u + lane]; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < left) { q[lane] = mv; qn[lane] = mn; }
+            count = left;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (count > 0u) run(count);
 }
 
 // ... and the tone map of the result in the same pass (tone_map_shader.frag after ssao_apply_shader.frag): the blurred-AO colour
@@ -1967,7 +2124,8 @@ __global__ __launch_bounds__(256) SLHIP_SSAO_KERNEL void k_ssao(const slhip_scen
 __global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_ssao_apply(const slhip_scene* __restrict__ scenes, unsigned n_scenes, int W, int H,
                                                     const float* __restrict__ hdr_in, const float* __restrict__ ao,
                                                     const float* __restrict__ zplane, float* __restrict__ hdr_out,
-                                                    const float* __restrict__ lum_scene, uint8_t* __restrict__ rgb)
+                                                    const float* __restrict__ lum_scene, uint8_t* __restrict__ rgb,
+                                                    const unsigned char* __restrict__ skip)
 {
     const size_t P = (size_t)W * H;
     const unsigned blocks_per_scene = (unsigned)((P + 255) / 256);
@@ -1979,6 +2137,25 @@ __global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_ssao_apply(const slh
     const float* aoS = ao + (size_t)scene * P;
     const size_t gp = (size_t)scene * P + pix;
     const int i = (int)(pix % (unsigned)W), j = (int)(pix / (unsigned)W);
+    if (skip) {
+        // every occlusion value the blur of this pixel reads (i-2..i+1, j-2..j+1, clamped) is 1 when the tiles of the footprint's
+        // corners were skipped by the SSAO pass (k_ssao_mask): the weighted mean of ones is 1 -- the colour goes through as it is
+        const int TW = W / kSsaoTile;
+        const unsigned char* S = skip + (size_t)scene * ((size_t)TW * (H / kSsaoTile));
+        const int xa = max(i - 2, 0) >> 3, xb = min(i + 1, W - 1) >> 3, ya = max(j - 2, 0) >> 3, yb = min(j + 1, H - 1) >> 3;
+        const bool ones = (S[ya * TW + xa] & S[ya * TW + xb] & S[yb * TW + xa] & S[yb * TW + xb]) != 0;
+        if (__all(ones)) {
+            const float4 h = reinterpret_cast<const float4*>(hdr_in)[gp];
+            const float c4[4] = {h.x, h.y, h.z, h.w};
+            if (hdr_out) reinterpret_cast<float4*>(hdr_out)[gp] = h;
+            if (rgb) {
+                const float manual = scenes[scene].manual_exposure;
+                const float lum = (manual >= 0.0f) ? 0.0f : lum_scene[(size_t)scene * blocks_per_scene * 4];
+                reinterpret_cast<uchar4*>(rgb)[gp] = tone_map_px(c4, manual, lum);
+            }
+            return;
+        }
+    }
     const float sigma = 3.0f * 0.5f;
     const float falloff = 1.0f / (2.0f * sigma * sigma);
     // The 16 taps (and the centre) sample the z plane at integer coordinates of a LINEAR rect
@@ -2158,6 +2335,14 @@ extern "C" int slhip_render_timings(float* ms_out)
 // ssao_shader.cpp:72-112)
 #include "ssao_tables.inc"
 
+// layout of d_ao: [B][H][W] occlusion, [B][H + 2][W + 2] camera z, then (8-byte aligned) the SSAO tile records and skip bytes
+static inline uint64_t ssao_tiles_per_scene(uint32_t w, uint32_t h) { return (uint64_t)((w + 7) / 8) * ((h + 7) / 8); }
+static inline uint64_t ssao_tiles_offset(uint64_t B, uint32_t w, uint32_t h)
+{
+    const uint64_t b = B * (uint64_t)w * h * 4 + B * (uint64_t)(w + 2) * (h + 2) * 4;
+    return (b + 7u) & ~(uint64_t)7u;
+}
+
 extern "C" int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uint32_t height,
                                           uint32_t shadow_res, uint32_t queue_capacity, uint64_t bytes_out[7])
 {
@@ -2165,11 +2350,34 @@ extern "C" int slhip_render_scratch_bytes(uint32_t n_scenes, uint32_t width, uin
     const uint64_t blocks = (P + 255) / 256;
     bytes_out[0] = B * P * 8;                                              // d_vis
     bytes_out[1] = 2 * B * P * 16;                                         // d_hdr (two planes)
-    bytes_out[2] = B * P * 4 + B * (uint64_t)(width + 2) * (height + 2) * 4;  // d_ao + padded camera-z plane
+    // d_ao + padded camera-z plane + (k_ssao_mask) per 8 x 8 tile: float2 record, skip byte
+    bytes_out[2] = ssao_tiles_offset(B, width, height) + B * ssao_tiles_per_scene(width, height) * 9 + 16;
     bytes_out[3] = B * SLHIP_NUM_LIGHTS * (uint64_t)shadow_res * shadow_res * 4;  // d_shadow
     bytes_out[4] = 16 + (uint64_t)queue_capacity * 16;                     // d_queue
     bytes_out[5] = B * blocks * 16;                                        // d_lum
     bytes_out[6] = B * SLHIP_NUM_LIGHTS * (uint64_t)shadow_tile_words((int)shadow_res) * 4;   // d_shadow_tiles
+    return 0;
+}
+
+// How much of the last SSAO pass on this scratch was skipped (k_ssao_mask): 8 x 8 tiles in all, tiles whose occlusion is 1 without
+// running the taps.  Synchronises `stream`.  counts = {0, 0} when the pass did not run tiled (viewport not a multiple of 32 x 16).
+extern "C" int slhip_render_ssao_skipped(const slhip_render_scratch* scratch, uint32_t n_scenes, uint32_t width, uint32_t height,
+                                         uint64_t counts[2], void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!scratch || !scratch->d_ao || !counts) {
+        slhip::set_error("slhip_render_ssao_skipped: null argument");
+        return -1;
+    }
+    counts[0] = counts[1] = 0;
+    if (width % 32 != 0 || height % 16 != 0 || n_scenes == 0) return 0;
+    const uint64_t nt = (uint64_t)n_scenes * ssao_tiles_per_scene(width, height);
+    std::vector<unsigned char> h(nt);
+    const char* base = reinterpret_cast<const char*>(scratch->d_ao) + ssao_tiles_offset(n_scenes, width, height) + nt * 8;
+    SLHIP_CHECK(hipMemcpyAsync(h.data(), base, nt, hipMemcpyDeviceToHost, stream));
+    SLHIP_CHECK(hipStreamSynchronize(stream));
+    counts[0] = nt;
+    for (unsigned char b : h) counts[1] += b ? 1 : 0;
     return 0;
 }
 
@@ -2314,10 +2522,15 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     float* hdr0 = want_rgb ? scratch->d_hdr : nullptr;
     float* hdr1 = want_rgb ? scratch->d_hdr + 4 * (size_t)n_scenes * P : nullptr;
     mark(4, stream);
+    // SSAO only where something can occlude (k_ssao_mask): needs k_shade's tiles to be the 8 x 8 tiles of the mask and 16-row bands
+    static const int ssao_tiled_on = getenv("SLHIP_SSAO_TILED") ? atoi(getenv("SLHIP_SSAO_TILED")) : 1;   // developer knob
+    const bool ssao_tiled = ssao && want_rgb && ssao_tiled_on && prm.tiled && H % 16 == 0 && W % 32 == 0 && (W / 8 + 1) * (H / 8 + 1) * 4 <= 60000;
+    float2* ssao_tiles = ssao_tiled ? reinterpret_cast<float2*>(reinterpret_cast<char*>(scratch->d_ao) + ssao_tiles_offset(n_scenes, W, H)) : nullptr;
+    unsigned char* ssao_skip = ssao_tiled ? reinterpret_cast<unsigned char*>(ssao_tiles + (size_t)n_scenes * ssao_tiles_per_scene(W, H)) : nullptr;
     k_shade<<<pix_blocks, 256, 0, stream>>>(*pool, d_scenes, d_draws, prm,
                                             reinterpret_cast<const unsigned long long*>(scratch->d_vis), *out, hdr0,
                                             shadows ? scratch->d_shadow : nullptr, scratch->d_lum, clipbuf,
-                                            ssao ? scratch->d_ao + (size_t)n_scenes * P : nullptr, vattr);
+                                            ssao ? scratch->d_ao + (size_t)n_scenes * P : nullptr, vattr, ssao_tiles);
     SLHIP_LAUNCH_CHECK();
     if (shadows && n_chunks > 0) {   // the maps were read for the last time: marked tiles back to 1.0
         k_shadow_restore<<<n_tile_words, 256, 0, stream>>>(reinterpret_cast<unsigned*>(scratch->d_shadow), scratch->d_shadow_tiles,
@@ -2332,11 +2545,16 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
             const float* zpl = scratch->d_ao + (size_t)n_scenes * P;   // second half of d_ao
             const float* d_kernel_table = nullptr;   // the table's device address as a plain kernel argument
             SLHIP_CHECK(hipGetSymbolAddress((void**)&d_kernel_table, HIP_SYMBOL(c_ssao_kernel)));
-            k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, out->d_cam_coord, out->d_normals, zpl, scratch->d_ao,
-                                                   d_kernel_table);
+            if (ssao_tiled) {
+                k_ssao_mask<<<n_scenes, 256, (size_t)(W / 8 + 1) * (H / 8 + 1) * 4, stream>>>(d_scenes, W, H, ssao_tiles, ssao_skip, getenv("SLHIP_SSAO_DEBUG") ? atoi(getenv("SLHIP_SSAO_DEBUG")) : 0);
+                k_ssao_tiled<<<8u * ((n_scenes + 7u) / 8u) * (unsigned)(H / 16) * 4u, 256, 0, stream>>>(d_scenes, n_scenes, W, H, out->d_cam_coord, out->d_normals,
+                                                                                   zpl, scratch->d_ao, d_kernel_table, ssao_skip);
+            } else
+                k_ssao<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, out->d_cam_coord, out->d_normals, zpl, scratch->d_ao,
+                                                       d_kernel_table);
             mark(6, stream);
             k_ssao_apply<<<pix_blocks, 256, 0, stream>>>(d_scenes, n_scenes, W, H, hdr0, scratch->d_ao, zpl,
-                                                         (flags & SLHIP_RENDER_KEEP_HDR) ? hdr1 : nullptr, scratch->d_lum, out->d_rgb);
+                                                         (flags & SLHIP_RENDER_KEEP_HDR) ? hdr1 : nullptr, scratch->d_lum, out->d_rgb, ssao_skip);
             mark(7, stream);
         } else {
             mark(7, stream);

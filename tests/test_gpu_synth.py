@@ -165,6 +165,9 @@ def test_c3_shard_end_to_end_with_gather(sl, oracle, ycb_table):
         assert np.array_equal(buf.normals[k].cpu().numpy().view(np.uint32), ref.normals[0].view(np.uint32)), s
         d = np.abs(buf.rgb[k].cpu().numpy().astype(np.int32) - ref.rgb[0].astype(np.int32))
         assert d.max() <= 2 and (d > 1).mean() < 1e-4 and (d > 0).mean() < 0.02, (s, d.max())
+    # ... with the SSAO taps run only where something can occlude (k_ssao_mask): a third of the tiles and more are open plane
+    tiles, skipped = batch.eng.ssao_skipped(outs[0], W, H)
+    assert tiles == outs[0].B * (W // 8) * (H // 8) and skipped > 0.3 * tiles, (tiles, skipped)
 
 
 def test_batch_scene_hand_over_renders_the_same_picture(sl, ycb_table):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Collects, ON THE GPU BOX, everything bench.py's roofline objects quote, at the bench shape
-(4096 scenes per step, 512-scene render sequences), and writes it under gpurun_out/<round>/:
+(16384 scenes per step, 1024-scene render sequences), and writes it under gpurun_out/<round>/:
 
   kernel_stats.csv          rocprofv3 --kernel-trace --stats of the default `python bench.py`
   bench_under_rocprof.json  the JSON line printed by that very run (its HIP-event durations must agree with the CSV)
@@ -138,7 +138,11 @@ def main():
         }
     notes = {"active_lanes": "64 x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of the kernel) / (the same ratio of an elementwise kernel with all "
                              "64 lanes on, measured in the same session: %.1f)" % full}
+    sys.path.insert(0, ROOT)
+    import bench
+
     res = {
+        "kernel_source_sha": bench.kernel_source_sha(),     # bench.py quotes per-instruction figures only for THESE sources
         "commands": {
             "stats": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline",
             "pmc": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_...> --kernel-trace --output-format csv -- python bench.py --no-cpu-baseline " + " ".join(PMC_SHAPE),
