@@ -102,8 +102,10 @@ class Pipeline:
                               shadows=not os.environ.get("SLHIP_BENCH_NO_SHADOWS"))
             b.set_camera_intrinsics(*INTRINSICS)
             self.sets.append(b)
-        # SLHIP_BENCH_PRIO = "<settle>,<render>" stream priorities (developer knob; -1 = high, 0 = default)
-        ps, pr = (int(x) for x in os.environ.get("SLHIP_BENCH_PRIO", "0,0").split(","))
+        # stream priorities "<settle>,<render>" (-1 = high, 0 = default): the settle is a chain of 2400 short dependent launches, the
+        # render a few long ones -- a settle workgroup that waits behind a render kernel's queue delays everything after it
+        # (round 5, 10 steps: 9 635 -> 9 700 scenes/s).  SLHIP_BENCH_PRIO overrides (developer knob).
+        ps, pr = (int(x) for x in os.environ.get("SLHIP_BENCH_PRIO", "-1,0").split(","))
         self.s_settle = [torch.cuda.Stream(device=dev, priority=ps) for _ in range(settle_streams)]
         self.s_render = torch.cuda.Stream(device=dev, priority=pr)
         n_rs = max(1, int(render_streams))

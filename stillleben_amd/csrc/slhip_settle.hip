@@ -1604,7 +1604,8 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         // the compacted narrowphase passes walk their work lists with a grid stride: enough waves for a step's typical list
         // (a scene has ~40 candidate pairs), never more than the worst case needs
         const unsigned list_stride = n_scenes * (unsigned)D.p_cap;
-        const unsigned work_grid = n_scenes < 16u ? n_scenes * 8u : n_scenes;
+        unsigned work_grid = n_scenes < 16u ? n_scenes * 8u : n_scenes;
+        if (const char* e = getenv("SLHIP_WORK_GRID_DIV")) { const unsigned d = (unsigned)atoi(e); if (d > 1u && work_grid / d >= 64u) work_grid /= d; }
         uint32_t step = params->resume;
         for (uint32_t f = 0; f < params->frames; ++f)
             for (uint32_t sub = 0; sub < params->substeps; ++sub, ++step) {
