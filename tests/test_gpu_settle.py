@@ -249,6 +249,12 @@ def test_c2_soak_distinct_scenes(sl, oracle):
     assert_bodies_equal(gpu, ref)
 
 
+def _yawed(pose, angle):
+    c, s_ = math.cos(angle), math.sin(angle)
+    pose[:2, :2] = [[c, -s_], [s_, c]]
+    return pose
+
+
 def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
     """The scenarios of tests/test_oracle_physics_kat.py (tilted gravity, impacts above / below the bounce threshold,
     free spin, clamped spin, cube columns, head-on collision) through slhip_settle: bit-exact with the oracle, so the
@@ -268,6 +274,10 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
         (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(6)]), dict(frames=400)),   # the column of six: warm start + persistent manifolds
         (K.build(sl, [K.at(-h - 0.02, 0, 1.0), K.at(h + 0.02, 0, 1.0)], plane=False, vel=[(1.5, 0, 0), (-1.5, 0, 0)]), dict(frames=30, dt=0.002, gravity=(0.0, 0.0, 0.0))),
         (K.build(sl, [K.at((c - 1) * (2 * h + 0.001), 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(4) for c in range(3)]), dict(frames=400)),   # the wall
+        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015)], vel=[(0.8, 0, 0)]), dict(frames=120, gravity=(K.G * math.sin(math.atan(0.15)), 0.0, -K.G * math.cos(math.atan(0.15))))),   # the sliding box
+        (K.build(sl, [K.at(-h - 0.0005, 0, K.TABLE + h + 0.0015), K.at(h + 0.0005, 0, K.TABLE + h + 0.0015), K.at(0, 0, K.TABLE + 3 * h + 0.0045)]), dict(frames=150)),   # the pile of three
+        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015), _yawed(K.at(0, 0, K.TABLE + 3 * h + 0.0045), math.pi / 4)]), dict(frames=60)),   # face manifold = corners of an octagon
+        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(8)]), dict(frames=120)),   # the column of eight while it stands
     ]
     for (srec, bodies, hulls, verts), kw in cases:
         prm = SB.default_params(tabletop=False, dt=kw.get("dt", 0.01), frames=kw["frames"], substeps=1)
