@@ -53,6 +53,12 @@ def parse():
     ap.add_argument("--gather-scenes", type=int, default=64,
                     help="N > 1: scenes per rank and step whose ground truth is all-gathered to every rank (BASELINE config C3: "
                          "512 scenes = 64 per GPU x 8); 0 = no exchange")
+    ap.add_argument("--gather", default="c3", choices=["c3", "compact", "full"],
+                    help="N > 1, what a rank exchanges per step: c3 = --gather-scenes scenes of the first chunk (BASELINE config C3's shape); "
+                         "compact = rgb + depth + class + instance (12 B/px) of EVERY scene it renders; full = the whole 6-channel ground "
+                         "truth (40 B/px) of every scene -- both streamed in pieces of --gather-piece scenes (double-buffered staging) "
+                         "while the next chunks render")
+    ap.add_argument("--gather-piece", type=int, default=128, help="scenes per all-gather of the streamed modes")
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5"],
                     help="BASELINE.json configuration: C2 (default) is the headline metric; C1 4 cubes 320x240 (4096 scenes per step), "
                          "C3 512 C2 scenes through the per-object API, C4 bunny x 50 raster stress, C5 sl.diff 64 objects x 32 "
@@ -115,6 +121,7 @@ class Pipeline:
                                               # further chunks have been rendered (50 GB of the last 4096 scenes at the defaults)
         self.gatherer = None
         self.gather_scenes = 0
+        self.gather_mode, self.streamer, self.depth_stage = "c3", None, {}
         self.pending = []
         self.rank = rank
         self.steps_launched = 0
@@ -158,7 +165,18 @@ class Pipeline:
                 if slot >= len(self.buffers):
                     self.buffers.append(buf)
                 revs.append((e0, e1))
-                if ci == 0 and self.gatherer is not None and self.gather_scenes > 0:
+                if self.streamer is not None:
+                    # the rank's whole chunk goes through the exchange, piece by piece, while the next chunk renders
+                    if self.gather_mode == "compact":
+                        d = self.depth_stage.get(slot)
+                        if d is None or d.shape[0] != buf.B:
+                            d = self.depth_stage[slot] = torch.empty(buf.coord.shape[:3], dtype=torch.float32, device=buf.coord.device)
+                        d.copy_(buf.coord[..., 3])            # depth = the 4th channel of coordDepth, made dense (4 B/px)
+                        parts = (buf.rgb, d, buf.cls, buf.instance)
+                    else:
+                        parts = (buf.rgb, buf.coord, buf.cls, buf.instance, buf.normals)
+                    self.pending = self.pending + self.streamer(list(parts))
+                elif ci == 0 and self.gatherer is not None and self.gather_scenes > 0:
                     g = min(self.gather_scenes, buf.B)
                     _, works = self.gatherer([t[:g] for t in (buf.rgb, buf.coord, buf.cls, buf.instance, buf.normals)],
                                              async_op=True)
@@ -414,6 +432,11 @@ def main():
                     comm.close()
                     comm = None
                 pipe.gatherer = BatchGatherer(dist, world, depth=2, comm=comm) if comm is not None else BatchGatherer(dist, world, depth=2)
+            if args.gather != "c3":
+                from stillleben_amd.parallel import ChunkedGatherer
+
+                pipe.gather_mode = args.gather
+                pipe.streamer = ChunkedGatherer(pipe.gatherer, min(args.gather_piece, args.render_chunk))
 
     def scene_base(k):      # disjoint random streams per rank and step
         return (rank * 4096 + k) * args.batch
@@ -430,17 +453,24 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    streamed0 = pipe.streamer.bytes_sent if pipe.streamer is not None else 0
     t0 = time.perf_counter()
     recs = run(args.warmup, args.steps)
     torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0             # this rank's own time (before the closing barrier)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_s = [t_rank]
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        tr = [torch.zeros(1, device="cuda", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tr, torch.tensor([t_rank], device="cuda", dtype=torch.float64))
+        per_rank_s = [float(x.item()) for x in tr]
+    streamed = (pipe.streamer.bytes_sent - streamed0) if pipe.streamer is not None else 0
     for r in recs:
         r["batch"].check_settled()     # a scene the kernel refused (sizing hints) must fail the run, not pass silently
 
@@ -520,7 +550,7 @@ def main():
     exchange = None
     if pipe.gatherer is not None and pipe.gather_scenes > 0 and pipe.buffers:
         buf = pipe.buffers[0]
-        g = min(pipe.gather_scenes, buf.B)
+        g = min(pipe.gather_scenes, buf.B) if pipe.streamer is None else min(pipe.streamer.piece, buf.B)
         shard = [t[:g] for t in (buf.rgb, buf.coord, buf.cls, buf.instance, buf.normals)]
         nbytes = sum(t.numel() * t.element_size() for t in shard)
         pipe.gatherer(shard)
@@ -533,11 +563,28 @@ def main():
             pipe.gatherer(shard)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - tx) / reps * 1e3
-        exchange = {"scenes": g, "bytes_per_rank": nbytes, "ms": ms, "GBps": (world - 1) * nbytes / (ms * 1e-3) / 1e9,
-                    "of_scenes_per_step": args.batch,
+        ranks_seen = None
+        if comm is not None:      # what the communicator behind the C-ABI says about itself
+            nr, rk = C.c_int(0), C.c_int(0)
+            pipe.eng.L.slhip_comm_info(comm.handle, C.byref(nr), C.byref(rk))
+            ranks_seen = int(nr.value)
+        per_step = streamed / args.steps if pipe.streamer is not None else nbytes
+        step_s = elapsed / args.steps
+        exchange = {"mode": args.gather, "scenes": g, "bytes_per_rank": nbytes, "ms": ms, "GBps": (world - 1) * nbytes / (ms * 1e-3) / 1e9,
+                    "of_scenes_per_step": args.batch, "ranks_seen": ranks_seen,
+                    "scenes_exchanged_per_rank_and_step": args.batch if pipe.streamer is not None else g,
+                    "bytes_sent_per_rank_and_step": per_step,
+                    # xGMI is point to point: a rank's shard travels to each of its world - 1 peers over the link to that peer
+                    "per_link_GBps_in_the_timed_region": per_step / step_s / 1e9,
+                    "per_link_budget_GBps": 153.0, "link_share": per_step / step_s / 1e9 / 153.0,
+                    "per_rank_scenes_per_s": [args.batch * args.steps / t for t in per_rank_s],
                     "backend": "slhip_allgather_group (RCCL behind the C-ABI)" if comm is not None else "torch.distributed",
-                    "note": "all-gather of one rank's exchange shard (6-channel GT of `scenes` scenes) to every rank, synchronous, %d "
-                            "repetitions after the timed region; GBps = bytes received per rank / time" % reps}
+                    "note": "ms / GBps: all-gather of one piece (6-channel GT of `scenes` scenes) to every rank, synchronous, %d repetitions "
+                            "after the timed region, GBps = bytes received per rank / time.  Inside the timed region the exchange runs on its "
+                            "own stream beside the render: c3 = one --gather-scenes piece per step; compact (rgb + depth + class + instance, "
+                            "12 B/px) and full (40 B/px) stream EVERY rendered scene in --gather-piece pieces through a double-buffered "
+                            "staging set; per_link_GBps = what each of a rank's peer links carries at the measured step rate (budget "
+                            "~153 GB/s per xGMI link, MI355X_MICROARCH.md)" % reps}
     out = None
     if rank == 0:
         out = report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso,

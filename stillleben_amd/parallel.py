@@ -171,3 +171,30 @@ class BatchGatherer:
                 works.append(w)
         views = [g.view((self.world, -1) + tuple(g.shape[1:])) for g in bufs]
         return (views, works) if async_op else views
+
+
+class ChunkedGatherer:
+    """Streams a rank's WHOLE output through the exchange step, `piece` scenes at a time: every piece is one fused all-gather
+    (BatchGatherer: slhip_allgather_group over RCCL, or torch.distributed) into a double-buffered staging set, issued right after
+    the kernels that produced the chunk -- the pieces of chunk k travel while chunk k + 1 renders.  Staging costs
+    2 x world x piece scenes whatever the step's size (the full ground truth of 16384 scenes per rank would be 1.6 TB gathered).
+    `on_piece(first_scene, views, works)` consumes a gathered piece (the views are valid until two further pieces of the same
+    shape have been issued); without it the pieces are only moved (bench.py measures the exchange, the trainer reads them)."""
+
+    def __init__(self, gatherer, piece):
+        self.g, self.piece = gatherer, max(1, int(piece))
+        self.bytes_sent = 0          # bytes this rank handed to the exchange since construction
+        self.pieces = 0
+
+    def __call__(self, tensors, on_piece=None):
+        n = int(tensors[0].shape[0])
+        works = []
+        for p0 in range(0, n, self.piece):
+            part = [t[p0:p0 + self.piece] for t in tensors]
+            views, w = self.g(part, async_op=True)
+            works.extend(w)
+            self.bytes_sent += sum(t.numel() * t.element_size() for t in part)
+            self.pieces += 1
+            if on_piece is not None:
+                on_piece(p0, views, w)
+        return works

@@ -48,6 +48,25 @@ def _worker(rank, world, port, q):
             exp = _fake_batch(parallel.shard_seeds(r, world, n_items, batch)[k])
             for a, b in zip(keep[k], exp):
                 ok = ok and torch.equal(a[r], b)
+    # streamed form (bench.py --gather compact | full): a rank's whole chunk goes through the exchange in pieces of 3 scenes (the last
+    # one ragged), double-buffered staging; every piece arrives complete and in rank order, the byte count is what was handed over
+    chunk = _fake_batch([1000 * rank + i for i in range(8)])
+    stream = parallel.ChunkedGatherer(parallel.BatchGatherer(dist, world, depth=2), piece=3)
+    got = {}
+
+    def on_piece(first, views, works):
+        for w in works:
+            w.wait()
+        got[first] = [v.clone() for v in views]        # (valid until two further pieces of this shape have been issued)
+
+    works = stream(chunk, on_piece=on_piece)
+    ok = ok and sorted(got) == [0, 3, 6] and stream.pieces == 3 and len(works) == 3 * len(chunk)
+    ok = ok and stream.bytes_sent == sum(t.numel() * t.element_size() for t in chunk)
+    for first, views in got.items():
+        for r in range(world):
+            exp = _fake_batch([1000 * r + i for i in range(first, min(first + 3, 8))])
+            for a, b in zip(views, exp):
+                ok = ok and torch.equal(a[r], b)
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -316,3 +316,42 @@ def test_fronto_parallel_lambert_known_answer(sl, oracle):
     cov = r.instance[0, :, :, 0] == 1
     face = r.hdr[0][cov][:, 0]
     assert face.max() <= want * (1 + 1e-3) and face.min() > 0.97 * want
+
+
+def test_ssao_is_exactly_one_on_the_open_plane(sl, oracle):
+    """What the HIP path's SSAO pass relies on to skip its 64 taps (slhip_render.hip k_ssao_mask), held against the full loop of the
+    restatement: on the background plane, where every texel a tap can reach -- within fx radius sqrt(1 + (X/Z)^2) / (Z - radius) + 2
+    pixels -- belongs to the plane or to the cleared background and no tap leaves the image, no sample is occluded, the occlusion
+    is 1 - 0 / 64 = 1 and the blurred factor leaves the colour bit for bit what it is without SSAO.  The rule below is the
+    kernel's, tile by tile (8 x 8), in numpy."""
+    from scipy import ndimage
+
+    scene = S.clutter_scene(sl, 5, n_objects=6, size=(640, 480))
+    scene.set_camera_look_at(torch.tensor([2.2, -1.4, 1.9]), torch.tensor([0.0, 0.0, 0.1]))
+    W, H = scene.viewport
+    f0 = _abi.OUT_ALL | _abi.RENDER_SHADOWS
+    r1 = oracle_render(oracle, [scene], flags=f0 | _abi.RENDER_SSAO, want_hdr=True)
+    r0 = oracle_render(oracle, [scene], flags=f0, want_hdr=True)
+    P = scene.projection_matrix().numpy()
+    fx, fy = P[0, 0] * W / 2, P[1, 1] * H / 2
+    tmax = max((1 + abs(P[0, 2])) / P[0, 0], (1 + abs(P[1, 2])) / P[1, 1])
+    reach = max(fx, fy) * 0.1 * math.sqrt(1 + tmax * tmax) * 1.001
+    inst, z = r1.instance[0, :, :, 0], r1.cam_coord[0, :, :, 2]
+    geo = z < 2999.0
+    other = (geo & (inst != 0)).reshape(H // 8, 8, W // 8, 8).any(axis=(1, 3))
+    zmin = np.where(geo, z, np.inf).reshape(H // 8, 8, W // 8, 8).min(axis=(1, 3))
+    skip = np.zeros((H // 8, W // 8), bool)
+    for ty in range(H // 8):
+        for tx in range(W // 8):
+            if other[ty, tx] or not np.isfinite(zmin[ty, tx]) or zmin[ty, tx] <= 0.2:
+                continue
+            R = int(math.ceil(reach / (zmin[ty, tx] - 0.1))) + 2
+            x0, x1, y0, y1 = tx * 8 - R, tx * 8 + 7 + R, ty * 8 - R, ty * 8 + 7 + R
+            if x0 < 0 or y0 < 0 or x1 >= W or y1 >= H:
+                continue
+            skip[ty, tx] = not other[y0 // 8:y1 // 8 + 1, x0 // 8:x1 // 8 + 1].any()
+    assert skip.mean() > 0.15                                         # the case is exercised
+    px = np.kron(skip, np.ones((8, 8), bool))
+    safe = ndimage.binary_erosion(px, structure=np.ones((5, 5), bool), border_value=0)   # the 4 x 4 blur reads skipped tiles only
+    differs = (r1.hdr[0].view(np.uint32) != r0.hdr[0].view(np.uint32)).any(axis=2)
+    assert differs.sum() > 1000 and not (differs & safe).any()
