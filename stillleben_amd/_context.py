@@ -57,3 +57,20 @@ def engine():
 def _reset_for_tests():
     global _CTX
     _CTX = None
+
+
+def check_free_memory(device, need_bytes, what):
+    """Raises a RuntimeError that says what is being sized, how much it needs and how much the device has left (free memory of
+    the device + what torch's caching allocator holds unused) BEFORE a large allocation runs into torch's out-of-memory error --
+    scratch sizes follow from the batch shape (scenes per settle launch, scenes per render chunk, list capacities), so the
+    message names the knobs.  Small requests are not checked."""
+    import torch
+
+    if need_bytes < (256 << 20) or not torch.cuda.is_available():
+        return
+    free, total = torch.cuda.mem_get_info(device)
+    cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    if need_bytes > free + cached:
+        raise RuntimeError("%s needs %.1f GB of device memory, %.1f GB are free (of %.1f GB; another process may hold the rest): "
+                           "use fewer scenes per batch / per render chunk or smaller list capacities"
+                           % (what, need_bytes / 1e9, (free + cached) / 1e9, total / 1e9))

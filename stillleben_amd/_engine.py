@@ -95,6 +95,12 @@ class Engine:
             qcap = max(1 << 20, B * QUEUE_ITEMS_PER_SCENE)
             self.L.slhip_render_scratch_bytes(B, W, H, SHADOW_RES if shadows else 0, qcap, C.byref(sizes))
 
+            from ._context import check_free_memory
+
+            want = (int(sizes[0]) + (int(sizes[1] if keep_hdr else sizes[1] // 2) if want_rgb else 0) + (int(sizes[2]) if ssao else 0)
+                    + (int(sizes[3]) // _abi.NUM_LIGHTS * shadow_lights + int(sizes[6]) if shadows else 0) + int(sizes[4]) + int(sizes[5]))
+            check_free_memory(self.device, want, "the render scratch of %d scenes at %d x %d (visibility keys, HDR, SSAO planes, shadow maps)" % (B, W, H))
+
             def buf(n, need=True):
                 return torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device) if need else None
 

@@ -1273,7 +1273,8 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ sm, int S,
 // shadow_tap() touch a 5x5 texel window; when the per-axis tap coordinates are consecutive (always,
 // except where rounding makes two taps share a texel) the window is fetched once and every tap is
 // evaluated from registers with exactly the arithmetic and summation order of the tap-by-tap form.
-__device__ __forceinline__ float shadow_pcf16(const float* __restrict__ sm, int S, float px, float py, float ref)
+__device__ __forceinline__ float shadow_pcf16(const float* __restrict__ sm, int S, float px, float py, float ref,
+                                              const unsigned* __restrict__ tile_bits)
 {
     const float scale = 1.0f / (float)S;
     int ix[4], iy[4];
@@ -1297,6 +1298,18 @@ __device__ __forceinline__ float shadow_pcf16(const float* __restrict__ sm, int 
         for (int k = 0; k < 5; ++k) {
             cx[k] = min(max(ix[0] + k, 0), S - 1);
             off_y[k] = (unsigned)min(max(iy[0] + k, 0), S - 1) * (unsigned)S;
+        }
+        if (tile_bits) {
+            // The shadow raster files which 64 x 64-texel tiles of the map its casters touched (the bits k_shadow_restore clears the
+            // map by): a window that lies in untouched tiles holds the cleared depth 1.0 in all 25 texels, every compare passes
+            // (r <= 1), every tap is exactly 1 -- the same 1.0 as below, without fetching the window.  Most of the background plane.
+            const int tn = shadow_tiles_x(S);
+            const int ta = cx[0] / kShadowTile, tb = cx[4] / kShadowTile;
+            const int ra = (int)(off_y[0] / (unsigned)S) / kShadowTile, rb = (int)(off_y[4] / (unsigned)S) / kShadowTile;
+            const int t00 = ra * tn + ta, t01 = ra * tn + tb, t10 = rb * tn + ta, t11 = rb * tn + tb;
+            const unsigned touched = ((tile_bits[t00 >> 5] >> (t00 & 31)) | (tile_bits[t01 >> 5] >> (t01 & 31)) |
+                                      (tile_bits[t10 >> 5] >> (t10 & 31)) | (tile_bits[t11 >> 5] >> (t11 & 31))) & 1u;
+            if (__ballot(touched == 0u) == __ballot(true)) return 1.0f;
         }
         bool lit[5][5];
         unsigned long long all_lit = ~0ull, any_lit = 0ull;
@@ -1344,7 +1357,7 @@ __device__ __forceinline__ float pow22(float x) { return __builtin_amdgcn_exp2f(
 __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ sc, const slhip_draw* __restrict__ dr,
                                                const float* base, const float* world, const float* nrm_in,
                                                bool front_facing, const float* __restrict__ shadow, int S, int shadow_lights,
-                                               const slhip_light_map* __restrict__ lm, float roughness_in, float metallic_in,
+                                               const unsigned* __restrict__ shadow_tiles, const slhip_light_map* __restrict__ lm, float roughness_in, float metallic_in,
                                                float occlusion, const float* emissive, float* color, float* normal_out)
 {
     float normal[3] = {nrm_in[0], nrm_in[1], nrm_in[2]};
@@ -1383,7 +1396,7 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
             const float py = fmaf(pc[1] * rpw, 0.5f, 0.5f);
             const float pz = fmaf(pc[2] * rpw, 0.5f, 0.5f);
             const float* sm = shadow + (size_t)i * S * S;
-            inverse_shadow = shadow_pcf16(sm, S, px, py, pz - 0.00003f);
+            inverse_shadow = shadow_pcf16(sm, S, px, py, pz - 0.00003f, shadow_tiles ? shadow_tiles + (size_t)i * shadow_tile_words(S) : nullptr);
         }
         float L[3] = {-ld[0], -ld[1], -ld[2]};
         normalize3_fast(L);
@@ -1546,7 +1559,8 @@ __global__ __launch_bounds__(256) SLHIP_SHADE_KERNEL void k_shade(slhip_mesh_poo
                                                slhip_render_out out, float* __restrict__ hdr,
                                                const float* __restrict__ shadow, float* __restrict__ lum_part,
                                                const float4* __restrict__ clipbuf, float* __restrict__ zplane,
-                                               const float4* __restrict__ vattr, float2* __restrict__ ssao_tiles)
+                                               const float4* __restrict__ vattr, float2* __restrict__ ssao_tiles,
+                                               const unsigned* __restrict__ shadow_tiles)
 {
     const int W = prm.W, H = prm.H;
     const size_t P = (size_t)W * H;
@@ -1757,7 +1771,8 @@ __global__ __launch_bounds__(256) SLHIP_SHADE_KERNEL void k_shade(slhip_mesh_poo
                 const float* sm = (prm.flags & SLHIP_RENDER_SHADOWS) && shadow
                                       ? shadow + (size_t)scene * prm.shadow_lights * prm.S * prm.S
                                       : nullptr;
-                shade_fragment(sc, dr, base, world, nrm, front, sm, prm.S, prm.shadow_lights, lm, roughness, metallic, occlusion, emissive, color, nout);
+                shade_fragment(sc, dr, base, world, nrm, front, sm, prm.S, prm.shadow_lights,
+                               sm && shadow_tiles ? shadow_tiles + (size_t)scene * SLHIP_NUM_LIGHTS * shadow_tile_words(prm.S) : nullptr, lm, roughness, metallic, occlusion, emissive, color, nout);
                 cls = dr->class_index & 0xFFFFu;
                 inst = dr->instance_index & 0xFFFFu;
                 plane_px = (dr->flags & (SLHIP_DRAW_NO_VERTEX_ID | SLHIP_DRAW_HAS_NORMAL_TEX)) == SLHIP_DRAW_NO_VERTEX_ID && inst == 0u;
@@ -2530,7 +2545,8 @@ extern "C" int slhip_render(const slhip_mesh_pool* pool, const slhip_scene* d_sc
     k_shade<<<pix_blocks, 256, 0, stream>>>(*pool, d_scenes, d_draws, prm,
                                             reinterpret_cast<const unsigned long long*>(scratch->d_vis), *out, hdr0,
                                             shadows ? scratch->d_shadow : nullptr, scratch->d_lum, clipbuf,
-                                            ssao ? scratch->d_ao + (size_t)n_scenes * P : nullptr, vattr, ssao_tiles);
+                                            ssao ? scratch->d_ao + (size_t)n_scenes * P : nullptr, vattr, ssao_tiles,
+                                            shadows && !getenv("SLHIP_NO_PCF_TILES") ? scratch->d_shadow_tiles : nullptr);
     SLHIP_LAUNCH_CHECK();
     if (shadows && n_chunks > 0) {   // the maps were read for the last time: marked tiles back to 1.0
         k_shadow_restore<<<n_tile_words, 256, 0, stream>>>(reinterpret_cast<unsigned*>(scratch->d_shadow), scratch->d_shadow_tiles,

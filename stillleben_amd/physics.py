@@ -43,6 +43,11 @@ class SettleEngine:
         self.eng.L.slhip_settle_scratch_bytes(n_scenes, C.c_void_p(prm.ctypes.data) if prm is not None else None, C.byref(need))
         cur = self._scratch.get(stream)
         if cur is None or cur.numel() < need.value:
+            from ._context import check_free_memory
+
+            self._scratch.pop(stream, None)
+            del cur
+            check_free_memory(self.eng.device, int(need.value), "the settle scratch of %d scenes (pair cache, contact lists, manifolds)" % n_scenes)
             cur = torch.empty(int(need.value), dtype=torch.uint8, device=self.eng.device)
             self._scratch[stream] = cur
         return cur

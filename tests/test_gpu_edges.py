@@ -275,3 +275,17 @@ def test_long_lived_scene_edge_cases(sl):
     free.linear_velocity = torch.tensor([0.0, 0.0, 1.0])     # kicked from outside: wakes, keeps the state
     st.simulate(0.01)
     assert st._phys_state.steps == 62 and float(free.linear_velocity[2]) > 0.5
+
+
+def test_oversized_scratch_is_refused_with_a_clear_message(sl):
+    """A batch whose scratch cannot fit the device says so before allocating (which knobs to turn), instead of failing inside
+    torch's allocator: 2^22 scenes of 20 objects would need terabytes of settle scratch."""
+    from stillleben_amd import _settle_batch as SB
+    from stillleben_amd import physics
+
+    se = physics.settle_engine()
+    prm = SB.default_params()
+    prm["max_bodies_per_scene"], prm["max_hulls_per_scene"], prm["max_hull_verts_per_scene"] = 20, 160, 4000
+    prm["max_hull_pairs_per_scene"], prm["max_contacts_per_scene"] = 4096, 1024
+    with pytest.raises(RuntimeError, match="settle scratch of 4194304 scenes.*GB are free"):
+        se.scratch(1 << 22, stream=12345, params=prm)
