@@ -116,6 +116,14 @@ class Pipeline:
         self.s_render = torch.cuda.Stream(device=dev, priority=pr)
         n_rs = max(1, int(render_streams))
         self.s_render_all = [self.s_render] + [torch.cuda.Stream(device=dev, priority=pr) for _ in range(n_rs - 1)]
+        if os.environ.get("SLHIP_BENCH_SETTLE_CUS"):
+            # developer knob: the settle streams confined to the first N compute units, the render streams to the rest
+            # (slhip_stream_create_cu_range): no settle workgroup ever waits behind a render kernel's waves
+            from stillleben_amd.parallel import cu_partition_streams
+
+            n_cu = int(os.environ["SLHIP_BENCH_SETTLE_CUS"])
+            self.s_settle, self.s_render = cu_partition_streams(n_cu, settle_streams, device=dev)
+            self.s_render_all = [self.s_render] + [cu_partition_streams(n_cu, 1, device=dev)[1] for _ in range(n_rs - 1)]
         self.free = [None] * self.ring        # event: the set's previous render finished (its records may be rewritten)
         self.buffers = []                     # ring of render-target sets: a chunk's ground truth stays in HBM until TARGET_RING
                                               # further chunks have been rendered (50 GB of the last 4096 scenes at the defaults)
