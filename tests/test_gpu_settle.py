@@ -312,8 +312,9 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
 
 
 def test_solver_wave_packing_and_odd_batches(sl, oracle, monkeypatch):
-    """The lockstep pipeline on a batch of mixed scenes (tabletop settle): two cost-sorted scenes per solver wave (default), one
-    and four give the oracle's bits, also when the last multi-scene solver wave holds a single scene."""
+    """The lockstep pipeline on a batch of mixed scenes (tabletop settle): solver waves of one, two or four cost-sorted scenes by
+    need (default), at most one and at most four per wave give the oracle's bits, also when the last multi-scene solver wave holds
+    a single scene."""
     cube = scaled(sl, S.CUBE, 0.15)
     bunny = scaled(sl, S.BUNNY, 0.2)
     scs = [heap(sl, 300 + i, 4 + 3 * i, cube, bunny) for i in range(6)]
