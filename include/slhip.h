@@ -378,7 +378,8 @@ typedef struct {
 } slhip_settle_params;
 
 /* per-scene scratch (device), sized by slhip_settle_scratch_bytes */
-#define SLHIP_MAX_BODIES     256  /* bodies per scene (the kernels keep a scene's working bodies in LDS: 152 B each)       */
+#define SLHIP_MAX_BODIES     400  /* bodies per scene (the kernels keep a scene's working bodies in LDS: 152 B each -- and its body-
+                                     pair groups: above ~300 bodies set max_body_pairs_per_scene so that both fit the 160 KB)       */
 #define SLHIP_DEFAULT_HULL_PAIRS 2048 /* slhip_settle_params.max_hull_pairs_per_scene = 0 (at most 65535)                  */
 #define SLHIP_DEFAULT_CONTACTS   1024 /* slhip_settle_params.max_contacts_per_scene = 0 (at most 65535)                    */
 #define SLHIP_PAIR_CACHE_DENSE_HULLS 256 /* up to this many convex hulls per scene the pair cache (cached simplex + the way to the

@@ -47,7 +47,7 @@ PAIR_CONTACT_BUDGET = 32
 
 BODY_STATIC = 1
 BODY_ASLEEP = 2
-MAX_BODIES = 256
+MAX_BODIES = 400
 
 
 def default_params(tabletop=True, dt=None, frames=None, substeps=None, pair_contact_budget=0):
@@ -233,6 +233,10 @@ def sizing_hints(params, srec, bodies, hulls):
         mh = int((bh[b1] - bh[b0]).max())
     params = params.copy()
     params["max_bodies_per_scene"], params["max_hull_verts_per_scene"], params["max_hulls_per_scene"] = mb, mv, mh
+    if mb > 256 and int(params["max_body_pairs_per_scene"]) == 0:
+        # hundreds of bodies: the default list of touching body pairs (12 per body) would not fit the kernels' LDS beside the
+        # bodies themselves -- six per body do (a heap: ~3); SettleEngine.run grows the list if a scene needs more
+        params["max_body_pairs_per_scene"] = 6 * mb
     return params
 
 

@@ -1396,7 +1396,7 @@ __device__ __forceinline__ void shade_fragment(const slhip_scene* __restrict__ s
             const float py = fmaf(pc[1] * rpw, 0.5f, 0.5f);
             const float pz = fmaf(pc[2] * rpw, 0.5f, 0.5f);
             const float* sm = shadow + (size_t)i * S * S;
-            inverse_shadow = shadow_pcf16(sm, S, px, py, pz - 0.00003f, shadow_tiles ? shadow_tiles + (size_t)i * shadow_tile_words(S) : nullptr);
+            inverse_shadow = shadow_pcf16(sm, S, px, py, (pz - 0.00003f), shadow_tiles ? shadow_tiles + (size_t)i * shadow_tile_words(S) : nullptr);
         }
         float L[3] = {-ld[0], -ld[1], -ld[2]};
         normalize3_fast(L);

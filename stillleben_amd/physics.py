@@ -57,7 +57,7 @@ class SettleEngine:
         contacts or hull pairs (PhysX allocates as it goes, scene.cpp:738-739): when a step of some scene offered more than the
         scratch's list capacities held (slhip_settle_caps counts what was dropped), the batch is settled again from the same
         start with capacities that hold what was seen -- the result never depends on a capacity."""
-        prm = np.ascontiguousarray(params).copy()
+        prm = SB.sizing_hints(np.ascontiguousarray(params).copy(), srec, bodies, self.pool.arrays()[0])
         for _ in range(8):
             d_bodies = self.run_device(srec, bodies, prm)
             self.check_status(len(srec))

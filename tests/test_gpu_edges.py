@@ -85,6 +85,12 @@ def test_large_heaps(sl, oracle):
     assert_bodies_equal(gpu, ref)
     caps = physics.settle_engine().caps(2)
     assert caps["contact_drop_steps"] == 0 and caps["pair_drop_steps"] == 0
+    # SLHIP_MAX_BODIES = 400: the working bodies (60 KB) and the groups of six body pairs per body share a workgroup's LDS
+    four_hundred = heap(sl, 14, 400, cube)
+    gpu, ref = run_both(oracle, [four_hundred, small], frames=10)
+    assert_bodies_equal(gpu, ref)
+    caps = physics.settle_engine().caps(2)
+    assert caps["scenes_dropped"] == 0 and caps["max_contacts"] > 0 and caps["group_drop_steps"] == 0
 
 
 def test_hundred_bodies_settle(sl):

@@ -1,6 +1,8 @@
 """GPU parity tests of the settle half: slhip_settle / slhip_overlap_any (through the C-ABI)
 vs the CPU oracle.  Bar: BIT-EXACT body state (pose, velocities, separation, flags) after the
 full 400-step settle -- the algorithm uses only exactly rounded operations in a fixed order."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -41,6 +43,7 @@ def run_both(oracle, scenes_, plane=True, **kw):
     ref = bodies.copy()
     prm["max_hull_pairs_per_scene"] = se.last_params["max_hull_pairs_per_scene"]      # (the host path grows the lists when a heap
     prm["max_contacts_per_scene"] = se.last_params["max_contacts_per_scene"]          #  needs it: the oracle gets the same)
+    prm["max_body_pairs_per_scene"] = se.last_params["max_body_pairs_per_scene"]
     oracle.settle(srec, ref, hulls, verts, prm)
     return gpu, ref
 
