@@ -571,7 +571,7 @@ def main():
             pipe.gatherer(shard)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - tx) / reps * 1e3
-        ranks_seen = None
+        ranks_seen = dist.get_world_size() if dist is not None else None
         if comm is not None:      # what the communicator behind the C-ABI says about itself
             nr, rk = C.c_int(0), C.c_int(0)
             pipe.eng.L.slhip_comm_info(comm.handle, C.byref(nr), C.byref(rk))
