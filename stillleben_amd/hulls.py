@@ -181,6 +181,30 @@ def write_cache(cache_file, data, flags, hulls):
         pass                              # read-only asset directory: the cache is an optimisation
 
 
+def _solid_volume(data):
+    """Volume of the solid a mesh bounds.  A closed, consistently oriented surface: the divergence theorem's signed volume.
+    Anything else (open at the bottom, duplicated vertices along seams): the voxel grid of the decomposition -- interior cells
+    whole, the cells the surface passes through half (counted whole they overestimate a thin or small solid by the shell's
+    thickness, and a mesh near the reference's 75 % rule would be classed convex where the reference decomposes it)."""
+    from . import acd
+
+    p = np.asarray(data.positions, dtype=np.float64)
+    t = np.asarray(data.indices, dtype=np.int64).reshape(-1, 3)
+    # closed and oriented: every directed edge has its opposite exactly once
+    e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]])
+    n = int(p.shape[0])
+    fwd = e[:, 0] * n + e[:, 1]
+    bwd = e[:, 1] * n + e[:, 0]
+    uf, cf = np.unique(fwd, return_counts=True)
+    if cf.max(initial=0) == 1 and np.array_equal(uf, np.unique(bwd)):
+        a, b, c = p[t[:, 0]], p[t[:, 1]], p[t[:, 2]]
+        return abs(float(np.einsum("ij,ij->i", a, np.cross(b, c)).sum()) / 6.0)
+    occ, _, h = acd.voxelize(data.positions, data.indices, resolution=100000)
+    idx = np.argwhere(occ)
+    shell = len(acd._boundary(idx, occ.shape))
+    return (float(len(idx)) - 0.5 * float(shell)) * h ** 3
+
+
 def _compute_hulls(data, force):
     """Mesh::loadPhysics' procedure (mesh.cpp:335-470) on the in-tree decomposition: the single hull when it is forced
     (PHYSICS_FORCE_CONVEX_HULL), when the mesh has no volume (mesh.cpp:373-378: the raw vertices' hull), or when the
@@ -194,9 +218,8 @@ def _compute_hulls(data, force):
     if hv < 1e-9:
         return [single]
     # the parts of a decomposition cover the solid: when the solid itself fills 75 % of its hull, the rule's answer is known
-    # before any cut is made (volume from the voxel grid: robust for meshes that are not closed)
-    occ, _, h = acd.voxelize(data.positions, data.indices, resolution=100000)
-    if float(occ.sum()) * h ** 3 >= 0.80 * hv:
+    # before any cut is made
+    if _solid_volume(data) >= 0.80 * hv:
         return [single]
     parts = [Hull(v, t) for v, t in acd.decompose(data.positions, data.indices)]
     if len(parts) <= 1 or sum(p.volume() for p in parts) / hv >= 0.75:

@@ -104,3 +104,36 @@ def test_decomposed_mesh_settles(sl, oracle):
     hulls, verts = pool.arrays()
     oracle.settle(srec, bodies, hulls, verts, SB.default_params(tabletop=True))
     assert bodies["pose"][0][11] > 0.04 and np.abs(bodies["lin_vel"]).max() < 0.05
+
+
+def test_solid_volume_of_closed_and_open_meshes():
+    """The 75 % pre-check of `_compute_hulls` (mesh.cpp:426-429) compares the SOLID's volume with its hull's: exact (divergence
+    theorem) for a closed oriented surface; for an open one the voxel estimate counts the surface cells half -- counted whole, a
+    slab two cells thick would come out twice its volume and pass for convex."""
+    from types import SimpleNamespace
+
+    from stillleben_amd import hulls
+
+    def box(hx, hy, hz):
+        p = np.array([[sx * hx, sy * hy, sz * hz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], np.float32)
+        # outward-facing triangles of the box with corners indexed x-major
+        q = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+        t = np.array([[a, b, c] for a, b, c, d in q] + [[a, c, d] for a, b, c, d in q], np.uint32)
+        return p, t
+
+    p, t = box(0.05, 0.04, 0.03)
+    closed = SimpleNamespace(positions=p, indices=t.reshape(-1))
+    assert hulls._solid_volume(closed) == pytest.approx(8 * 0.05 * 0.04 * 0.03, rel=1e-5)
+    # the same box without its top: not closed, the voxel path (the shell still encloses the interior from five sides; the
+    # flood fill leaks through the open face, so what is left is the five walls -- far less than the box)
+    keep = ~np.all(p[t][:, :, 2] > 0, axis=1)
+    opened = SimpleNamespace(positions=p, indices=t[keep].reshape(-1))
+    v_open = hulls._solid_volume(opened)
+    assert 0.0 < v_open < 0.5 * 8 * 0.05 * 0.04 * 0.03
+    # a thin closed slab whose surface the orientation test rejects (one triangle flipped): the voxel estimate must stay near
+    # the true volume instead of doubling it
+    p2, t2 = box(0.1, 0.1, 0.004)
+    t2 = t2.copy(); t2[0] = t2[0][::-1]
+    slab = SimpleNamespace(positions=p2, indices=t2.reshape(-1))
+    true = 8 * 0.1 * 0.1 * 0.004
+    assert hulls._solid_volume(slab) == pytest.approx(true, rel=0.35)
