@@ -98,6 +98,20 @@ def ssao_tables():
     return noise, kern
 
 
+def ssao_pass(proj, cam_coord, normals):
+    """The SSAO pass alone (before the blur): proj float32[4, 4] row-major, cam_coord / normals float32[H, W, 4] -> ao float32[H, W]."""
+    L = lib()
+    H, W = cam_coord.shape[:2]
+    proj = np.ascontiguousarray(proj, np.float32).reshape(16)
+    cam = np.ascontiguousarray(cam_coord, np.float32)
+    nrm = np.ascontiguousarray(normals, np.float32)
+    ao = np.zeros((H, W), np.float32)
+    L.slref_ssao_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.slref_ssao_pass.restype = None
+    L.slref_ssao_pass(_p(proj), _p(cam), _p(nrm), W, H, _p(ao))
+    return ao
+
+
 class SettleState:
     """Contact state of a settle that outlives a call (slref_settle_ex): created by a call with params['resume'] == 0,
     continued by calls with params['resume'] == the steps run so far."""

@@ -844,6 +844,10 @@ static void ssao_pass(const float* proj, const float* cam, const float* nrm, int
         }
 }
 
+/* The unblurred occlusion of one picture (tests: the analytic inner-corner known answer looks at the pass itself, not at the
+   colour it ends up in).  proj: row-major 4 x 4, cam / nrm: [H, W, 4] as slref_render writes them, ao: [H, W]. */
+void slref_ssao_pass(const float* proj, const float* cam, const float* nrm, int W, int H, float* ao) { ssao_pass(proj, cam, nrm, W, H, ao); }
+
 /* ssao_apply_shader.frag:29-75: 4x4 bilateral blur (offsets -2..1), multiplies rgb.
    texelFetch outside the image is undefined in GL; we clamp to the edge. */
 static void ssao_apply(const float* hdr_in, const float* ao, const float* cam, int W, int H,

@@ -355,3 +355,80 @@ def test_ssao_is_exactly_one_on_the_open_plane(sl, oracle):
     safe = ndimage.binary_erosion(px, structure=np.ones((5, 5), bool), border_value=0)   # the 4 x 4 blur reads skipped tiles only
     differs = (r1.hdr[0].view(np.uint32) != r0.hdr[0].view(np.uint32)).any(axis=2)
     assert differs.sum() > 1000 and not (differs & safe).any()
+
+
+def test_ssao_inner_corner_known_answer(sl, oracle):
+    """The SSAO pass (ssao_shader.frag:20-56) against a computation that shares nothing with it but the pinned sample tables:
+    a right-angle inner corner -- floor z = 0 and wall x = 0, two faces of big cubes -- where the depth "texture" is known in closed
+    form (the nearer of two ray-plane intersections).  For pixels on both sides of the crease the occlusion is recomputed in
+    float64 numpy from the geometry: hemisphere basis from the 4 x 4 noise tile (Gram-Schmidt against the plane's normal), the 64
+    kernel samples at radius 0.1, their projection, the analytic depth along the ray through the sample's window position, the
+    2.5 mm bias and the smoothstep range check.  The restatement samples a rasterised depth plane bilinearly instead: a sample
+    within 0.4 mm of the threshold may fall on either side (`near`), everything else must agree to the sample."""
+    a = 2.0
+    scene = sl.Scene((640, 480))
+    m = sl.Mesh(S.CUBE, physics=False)
+    m.center_bbox()
+    m.scale_to_bbox_diagonal(2 * a * math.sqrt(3.0))
+    for c in ((0.0, 0.0, -a), (-a, 0.0, a)):
+        o = sl.Object(m)
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, 3] = c
+        o.set_pose(torch.from_numpy(pose))
+        scene.add_object(o)
+    scene.set_camera_look_at(torch.tensor([0.9, 0.35, 0.8]), torch.tensor([0.0, 0.0, 0.02]))
+    W, H = scene.viewport
+    r = oracle_render(oracle, [scene], flags=_abi.OUT_ALL)
+    P = scene.projection_matrix().numpy().astype(np.float64)
+    T = scene.camera_pose().numpy().astype(np.float64)                    # camera -> world
+    Rcw, tcw = T[:3, :3], T[:3, 3]
+    ao = oracle.ssao_pass(P.astype(np.float32), r.cam_coord[0], r.normals[0])
+    noise, kern = oracle.ssao_tables()                                    # pinned: test_oracle_constants.py::test_ssao_random_stream_is_libstdcxx
+    noise, kern = noise.reshape(16, 3).astype(np.float64), kern.reshape(64, 3).astype(np.float64)
+    # the two planes in camera space, n . X = c, each valid on its side of the crease (floor: world x >= 0, wall: world z >= 0)
+    planes = [(Rcw.T @ np.array(nw), -float(np.array(nw) @ tcw), ax) for nw, ax in (((0.0, 0.0, 1.0), 0), ((1.0, 0.0, 0.0), 2))]
+
+    def first_hit(u, v):
+        d = np.array([(u - P[0, 2]) / P[0, 0], (v - P[1, 2]) / P[1, 1], 1.0])      # w = camera z: the ray X = z d
+        best, which = np.inf, -1
+        for k, (nc, c, ax) in enumerate(planes):
+            t = c / (nc @ d)
+            if t > 0 and (Rcw @ (t * d) + tcw)[ax] >= -1e-9 and t < best:
+                best, which = t, k
+        return best, which, d
+
+    def analytic(i, j):
+        z, which, d = first_hit((i + 0.5) / W * 2 - 1, (j + 0.5) / H * 2 - 1)
+        frag, n = z * d, planes[which][0]
+        rv = noise[(j & 3) * 4 + (i & 3)]
+        rv = rv / np.linalg.norm(rv)
+        tg = rv - n * (rv @ n)
+        tg /= np.linalg.norm(tg)
+        bt = np.cross(n, tg)
+        occ, near = 0.0, 0
+        for s in kern:
+            sp = frag + 0.1 * (tg * s[0] + bt * s[1] + n * s[2])
+            clip = P @ np.array([sp[0], sp[1], sp[2], 1.0])
+            sd = first_hit(clip[0] / clip[3], clip[1] / clip[3])[0]
+            near += abs(sd - (sp[2] - 0.0025)) < 4e-4
+            if sd <= sp[2] - 0.0025:
+                t = min(max(0.1 / abs(frag[2] - sd), 0.0), 1.0)
+                occ += t * t * (3.0 - 2.0 * t)
+        return 1.0 - occ / 64.0, frag, near
+
+    inst = r.instance[0, :, :, 0]
+    pix = []
+    for j in range(192, 300, 4):                                          # the crease: where a row changes from floor to wall
+        row = inst[j]
+        x = int(np.argmax(row != row[0]))
+        assert 60 < x < W - 60
+        pix += [(x + dx, j) for dx in (-41, -17, -6, -2, 1, 5, 14, 37)]
+    got, want, slack = [], [], []
+    for i, j in pix:
+        A, frag, near = analytic(i, j)
+        assert np.abs(frag - r.cam_coord[0, j, i, :3]).max() < 2e-5       # the geometry the pass starts from is the analytic one
+        got.append(float(ao[j, i])); want.append(A); slack.append(near)
+    got, want, slack = np.array(got), np.array(want), np.array(slack)
+    assert (want < 0.9).mean() > 0.3 and want.min() < 0.7 and want.max() == 1.0      # the corner darkens, the open faces do not
+    assert np.all(np.abs(got - want) <= slack / 64.0 + 1e-6), np.abs(got - want).max()
+    assert np.abs(got - want).mean() < 2e-3
