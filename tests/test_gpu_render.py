@@ -116,6 +116,39 @@ def test_fronto_parallel_lambert_known_answer(sl, eng):
     assert hdr[H // 2, W // 2, 3] == 1.0
 
 
+def test_cast_shadow_known_answer(sl, eng):
+    """The geometric shadow of tests/test_oracle_render.py (a slab test in numpy: no oracle involved) on the kernels' float image:
+    inside the analytic shadow the ambient-only picture, outside it the picture without shadows, bit for bit; the outline within
+    a few pixels."""
+    from test_oracle_render import cast_shadow_kat_check, cast_shadow_kat_scene
+
+    def hdr_of(scene, shadows):
+        W, H = scene.viewport
+        bufs = eng.render([scene], _abi.OUT_ALL, ssao=False, shadows=shadows, keep_hdr=True)
+        torch.cuda.synchronize()
+        hdr = bufs._keepalive[0]["hdr"].view(torch.float32)[: H * W * 4].reshape(H, W, 4).cpu().numpy().copy()
+        return hdr[:, :, :3], bufs.cam_coord.cpu().numpy()[0].copy(), bufs.instance.cpu().numpy()[0, :, :, 0].copy()
+
+    lit_scene, ld = cast_shadow_kat_scene(sl, 3.0)
+    hs, cam, inst = hdr_of(lit_scene, True)
+    hn, _, _ = hdr_of(lit_scene, False)
+    ha, _, _ = hdr_of(cast_shadow_kat_scene(sl, 0.0)[0], False)
+    cast_shadow_kat_check(lit_scene, ld, cam, inst, hs, hn, ha)
+
+
+def test_ssao_inner_corner_known_answer(sl, eng):
+    """The analytic occlusion of an inner right-angle corner (tests/test_oracle_render.py: closed-form depth, float64 numpy, the
+    generator's sample tables -- no oracle involved) on the occlusion plane k_ssao_tiled writes."""
+    from test_oracle_render import inner_corner_kat_check, inner_corner_kat_scene
+
+    scene = inner_corner_kat_scene(sl)
+    W, H = scene.viewport
+    bufs = eng.render([scene], _abi.OUT_ALL, ssao=True, shadows=False)
+    torch.cuda.synchronize()
+    ao = bufs._keepalive[0]["ao"].view(torch.float32)[: H * W].reshape(H, W).cpu().numpy()
+    inner_corner_kat_check(scene, ao, bufs.cam_coord.cpu().numpy()[0], bufs.instance.cpu().numpy()[0, :, :, 0])
+
+
 def test_cube_lookat(sl, oracle, eng):
     scene = S.cube_lookat_scene(sl)
     bufs, ref = both(eng, oracle, [scene])

@@ -357,14 +357,21 @@ def test_ssao_is_exactly_one_on_the_open_plane(sl, oracle):
     assert differs.sum() > 1000 and not (differs & safe).any()
 
 
-def test_ssao_inner_corner_known_answer(sl, oracle):
-    """The SSAO pass (ssao_shader.frag:20-56) against a computation that shares nothing with it but the pinned sample tables:
-    a right-angle inner corner -- floor z = 0 and wall x = 0, two faces of big cubes -- where the depth "texture" is known in closed
-    form (the nearer of two ray-plane intersections).  For pixels on both sides of the crease the occlusion is recomputed in
-    float64 numpy from the geometry: hemisphere basis from the 4 x 4 noise tile (Gram-Schmidt against the plane's normal), the 64
-    kernel samples at radius 0.1, their projection, the analytic depth along the ray through the sample's window position, the
-    2.5 mm bias and the smoothstep range check.  The restatement samples a rasterised depth plane bilinearly instead: a sample
-    within 0.4 mm of the threshold may fall on either side (`near`), everything else must agree to the sample."""
+def ssao_tables_from_the_generator():
+    """The 4 x 4 noise tile and the 64 kernel samples from tools/gen_ssao_tables.py (std::mt19937 restated, pinned bit for bit to
+    libstdc++'s stream: test_oracle_constants.py::test_ssao_random_stream_is_libstdcxx) -- not from the oracle, not from the kernels."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("gen", os.path.join(os.path.dirname(__file__), "..", "tools", "gen_ssao_tables.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    noise, kern = gen.tables()
+    return np.asarray(noise, np.float64).reshape(16, 3), np.asarray(kern, np.float64).reshape(64, 3)
+
+
+def inner_corner_kat_scene(sl):
+    """A right-angle inner corner: floor z = 0 and wall x = 0, two faces of 4 m cubes, seen from (0.9, 0.35, 0.8)."""
     a = 2.0
     scene = sl.Scene((640, 480))
     m = sl.Mesh(S.CUBE, physics=False)
@@ -377,14 +384,21 @@ def test_ssao_inner_corner_known_answer(sl, oracle):
         o.set_pose(torch.from_numpy(pose))
         scene.add_object(o)
     scene.set_camera_look_at(torch.tensor([0.9, 0.35, 0.8]), torch.tensor([0.0, 0.0, 0.02]))
+    return scene
+
+
+def inner_corner_kat_check(scene, ao, cam_coord, instance):
+    """ao [H, W]: the unblurred occlusion of the SSAO pass; cam_coord [H, W, >= 3], instance [H, W] of the same picture.  The
+    occlusion is recomputed in float64 numpy from the geometry: the depth "texture" is known in closed form (the nearer of two
+    ray-plane intersections), the hemisphere basis comes from the 4 x 4 noise tile (Gram-Schmidt against the plane's normal), then
+    the 64 kernel samples at radius 0.1, their projection, the analytic depth along the ray through the sample's window position,
+    the 2.5 mm bias and the smoothstep range check (ssao_shader.frag:20-56).  The pass samples a rasterised depth plane bilinearly
+    instead: a sample within 0.4 mm of the threshold may fall on either side (`near`), everything else must agree to the sample."""
     W, H = scene.viewport
-    r = oracle_render(oracle, [scene], flags=_abi.OUT_ALL)
     P = scene.projection_matrix().numpy().astype(np.float64)
     T = scene.camera_pose().numpy().astype(np.float64)                    # camera -> world
     Rcw, tcw = T[:3, :3], T[:3, 3]
-    ao = oracle.ssao_pass(P.astype(np.float32), r.cam_coord[0], r.normals[0])
-    noise, kern = oracle.ssao_tables()                                    # pinned: test_oracle_constants.py::test_ssao_random_stream_is_libstdcxx
-    noise, kern = noise.reshape(16, 3).astype(np.float64), kern.reshape(64, 3).astype(np.float64)
+    noise, kern = ssao_tables_from_the_generator()
     # the two planes in camera space, n . X = c, each valid on its side of the crease (floor: world x >= 0, wall: world z >= 0)
     planes = [(Rcw.T @ np.array(nw), -float(np.array(nw) @ tcw), ax) for nw, ax in (((0.0, 0.0, 1.0), 0), ((1.0, 0.0, 0.0), 2))]
 
@@ -416,19 +430,94 @@ def test_ssao_inner_corner_known_answer(sl, oracle):
                 occ += t * t * (3.0 - 2.0 * t)
         return 1.0 - occ / 64.0, frag, near
 
-    inst = r.instance[0, :, :, 0]
     pix = []
     for j in range(192, 300, 4):                                          # the crease: where a row changes from floor to wall
-        row = inst[j]
+        row = instance[j]
         x = int(np.argmax(row != row[0]))
         assert 60 < x < W - 60
         pix += [(x + dx, j) for dx in (-41, -17, -6, -2, 1, 5, 14, 37)]
     got, want, slack = [], [], []
     for i, j in pix:
         A, frag, near = analytic(i, j)
-        assert np.abs(frag - r.cam_coord[0, j, i, :3]).max() < 2e-5       # the geometry the pass starts from is the analytic one
+        assert np.abs(frag - cam_coord[j, i, :3]).max() < 2e-5            # the geometry the pass starts from is the analytic one
         got.append(float(ao[j, i])); want.append(A); slack.append(near)
     got, want, slack = np.array(got), np.array(want), np.array(slack)
     assert (want < 0.9).mean() > 0.3 and want.min() < 0.7 and want.max() == 1.0      # the corner darkens, the open faces do not
     assert np.all(np.abs(got - want) <= slack / 64.0 + 1e-6), np.abs(got - want).max()
     assert np.abs(got - want).mean() < 2e-3
+
+
+def test_ssao_inner_corner_known_answer(sl, oracle):
+    """The SSAO pass against a computation that shares nothing with it but the pinned sample tables (inner_corner_kat_check)."""
+    scene = inner_corner_kat_scene(sl)
+    r = oracle_render(oracle, [scene], flags=_abi.OUT_ALL)
+    ao = oracle.ssao_pass(scene.projection_matrix().numpy().astype(np.float32), r.cam_coord[0], r.normals[0])
+    inner_corner_kat_check(scene, ao, r.cam_coord[0], r.instance[0, :, :, 0])
+
+
+def cast_shadow_kat_scene(sl, light_colour):
+    """A cube (half edge 0.08) floating at z = 0.3 over a matte floor (the top face z = 0 of a 1 m cube) under ONE directional light."""
+    scene = sl.Scene((640, 480))
+    big = sl.Mesh(S.CUBE, physics=False)
+    big.center_bbox()
+    big.scale_to_bbox_diagonal(2 * 0.5 * math.sqrt(3.0))
+    small = sl.Mesh(S.CUBE, physics=False)
+    small.center_bbox()
+    small.scale_to_bbox_diagonal(2 * 0.08 * math.sqrt(3.0))
+    for m, c in ((big, (0.0, 0.0, -0.5)), (small, (0.0, 0.0, 0.3))):
+        o = sl.Object(m)
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, 3] = c
+        o.set_pose(torch.from_numpy(pose))
+        o.metallic, o.roughness = 0.0, 1.0
+        scene.add_object(o)
+    scene.set_camera_look_at(torch.tensor([1.0, 0.8, 0.9]), torch.tensor([0.0, 0.0, 0.05]))
+    ld = np.array([-0.3, 0.2, -1.0], np.float32)
+    ld /= np.linalg.norm(ld)
+    scene.light_directions = torch.tensor([ld.tolist(), [0.0] * 3, [0.0] * 3])
+    scene.light_colors = torch.tensor([[light_colour] * 3, [0.0] * 3, [0.0] * 3])
+    scene.ambient_light = torch.tensor([0.1, 0.1, 0.1])
+    scene.manual_exposure = 1.0
+    return scene, ld
+
+
+def cast_shadow_kat_check(scene, ld, cam_coord, instance, hs, hn, ha):
+    """hs / hn / ha: the float pictures [H, W, 3] with shadows, without, and with the light switched off; cam_coord [H, W, >=3],
+    instance [H, W] of any of them.  A floor point is in shadow iff the ray from it against the light's direction meets the cube
+    (slab test) -- nothing of the shadow matrices, the map or the bias enters that."""
+    from scipy import ndimage
+
+    T = scene.camera_pose().numpy().astype(np.float64)
+    Xw = cam_coord[:, :, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    top = (instance == 1) & (np.abs(Xw[:, :, 2]) < 1e-4)                                      # the floor's upper face
+    d = -ld.astype(np.float64)
+    lo, hi = np.array([-0.08, -0.08, 0.22]), np.array([0.08, 0.08, 0.38])
+    t1, t2 = (lo - Xw) / d, (hi - Xw) / d
+    tn, tf = np.minimum(t1, t2).max(axis=2), np.maximum(t1, t2).min(axis=2)
+    shadow = top & (tn <= tf) & (tf > 0)
+    k = np.ones((13, 13), bool)
+    core_shadow, core_lit = ndimage.binary_erosion(shadow, structure=k), ndimage.binary_erosion(top & ~shadow, structure=k)
+    assert core_shadow.sum() > 1000 and core_lit.sum() > 50000
+    assert np.array_equal(hs[core_lit], hn[core_lit])
+    assert np.array_equal(hs[core_shadow], ha[core_shadow])
+    assert np.allclose(ha[core_shadow], 0.1 * 0.8, rtol=1e-6) and hn[core_lit].min() > 5 * 0.08     # ambient * albedo against the lit floor
+    # the outline, away from the floor's own rim (its side faces are in the map too -- front faces are culled in the shadow pass --
+    # and a handful of rim pixels compare against them)
+    inner = ndimage.binary_erosion(top, structure=np.ones((5, 5), bool))
+    rendered = inner & (np.abs(hs - hn).max(axis=2) > 1e-6)
+    band = ndimage.binary_dilation(shadow, structure=np.ones((7, 7), bool)) & ~ndimage.binary_erosion(shadow, structure=np.ones((7, 7), bool))
+    assert not ((rendered ^ (shadow & inner)) & ~band).any()
+    assert abs(int(rendered.sum()) - int((shadow & inner).sum())) < 0.1 * shadow.sum()
+
+
+def test_cast_shadow_known_answer(sl, oracle):
+    """The shadow pass (shadow_shader.vert, render_pass.cpp:131-211, the PCF of render_shader.frag) against plain geometry: a cube
+    floating over a matte floor under ONE directional light.  Well inside the analytic shadow the picture must be the ambient-only
+    picture, well outside it the picture without shadows, bit for bit (every PCF tap agrees there); the rendered outline may differ
+    from the analytic one by the map's texel and the 4 x 4 taps only: a band of a few pixels."""
+    lit_scene, ld = cast_shadow_kat_scene(sl, 3.0)
+    with_shadow = oracle_render(oracle, [lit_scene], flags=_abi.OUT_ALL | _abi.RENDER_SHADOWS, want_hdr=True)
+    without = oracle_render(oracle, [lit_scene], flags=_abi.OUT_ALL, want_hdr=True)
+    ambient = oracle_render(oracle, [cast_shadow_kat_scene(sl, 0.0)[0]], flags=_abi.OUT_ALL, want_hdr=True)
+    cast_shadow_kat_check(lit_scene, ld, with_shadow.cam_coord[0], with_shadow.instance[0, :, :, 0],
+                          with_shadow.hdr[0][:, :, :3], without.hdr[0][:, :, :3], ambient.hdr[0][:, :, :3])
