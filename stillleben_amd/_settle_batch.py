@@ -233,7 +233,7 @@ def sizing_hints(params, srec, bodies, hulls):
         mh = int((bh[b1] - bh[b0]).max())
     params = params.copy()
     params["max_bodies_per_scene"], params["max_hull_verts_per_scene"], params["max_hulls_per_scene"] = mb, mv, mh
-    if mb > 256 and int(params["max_body_pairs_per_scene"]) == 0:
+    if mb > 256 and int(np.asarray(params["max_body_pairs_per_scene"]).reshape(-1)[0]) == 0:
         # hundreds of bodies: the default list of touching body pairs (12 per body) would not fit the kernels' LDS beside the
         # bodies themselves -- six per body do (a heap: ~3); SettleEngine.run grows the list if a scene needs more
         params["max_body_pairs_per_scene"] = 6 * mb

@@ -27,6 +27,9 @@ class SettleEngine:
         self._dev = None
         self._scratch = {}
         self._keep = {}
+        # list capacities earlier batches on this engine turned out to need (run): later batches start from them instead of
+        # paying the settle-again of the first one (a result never depends on a capacity)
+        self._learned = {"max_hull_pairs_per_scene": 0, "max_contacts_per_scene": 0}   # (global-memory lists; the body-pair list sizes LDS)
 
     def hulls_dev(self):
         if self.pool.dirty or self._dev is None:
@@ -58,6 +61,10 @@ class SettleEngine:
         scratch's list capacities held (slhip_settle_caps counts what was dropped), the batch is settled again from the same
         start with capacities that hold what was seen -- the result never depends on a capacity."""
         prm = SB.sizing_hints(np.ascontiguousarray(params).copy(), srec, bodies, self.pool.arrays()[0])
+        if int(prm["resume"].reshape(-1)[0]) == 0:
+            for k, v in self._learned.items():
+                if int(prm[k].reshape(-1)[0]) == 0 and v > 0:      # (a capacity the caller names is the caller's)
+                    prm[k] = v
         for _ in range(8):
             d_bodies = self.run_device(srec, bodies, prm)
             self.check_status(len(srec))
@@ -84,6 +91,8 @@ class SettleEngine:
                                                       int(prm["max_body_pairs_per_scene"].reshape(-1)[0]))
             if cur_p >= 65535 and cur_c >= 65535 and not caps["group_drop_steps"]:
                 raise RuntimeError("slhip_settle: a scene offers more hull pairs / contacts per step than the 16-bit lists hold (%r)" % (caps,))
+            for k in self._learned:      # (bounded: a giant heap's lists are not what every later batch should allocate)
+                self._learned[k] = max(self._learned[k], min(8192, int(prm[k].reshape(-1)[0])))
         else:
             raise RuntimeError("slhip_settle: list capacities still too small after eight attempts (%r)" % (caps,))
         out = np.frombuffer(d_bodies.cpu().numpy().tobytes(), dtype=SB.BODY_DTYPE).copy()
