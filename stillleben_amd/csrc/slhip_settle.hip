@@ -368,6 +368,7 @@ __device__ int reduce_simplex(Simplex& S, v3* v)
 }
 
 constexpr int kGjkMaxIter = 32;
+constexpr unsigned kPersistentMaxScenes = 2048u;   // slhip_settle: batches up to this many scenes take k_w_persistent (measured: DESIGN.md section 4)
 
 __device__ __forceinline__ bool same_w(const SV& a, const SV& b)
 {
@@ -1606,6 +1607,19 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         const unsigned list_stride = n_scenes * (unsigned)D.p_cap;
         unsigned work_grid = n_scenes < 16u ? n_scenes * 8u : n_scenes;
         if (const char* e = getenv("SLHIP_WORK_GRID_DIV")) { const unsigned d = (unsigned)atoi(e); if (d > 1u && work_grid / d >= 64u) work_grid /= d; }
+        // small batches: one launch, a wave per scene through every step (k_w_persistent); large ones: six launches per step over
+        // the whole batch.  The results are the same bits; the choice is about time only.
+        bool persistent = n_scenes <= kPersistentMaxScenes;
+        if (const char* e = getenv("SLHIP_SETTLE_PERSISTENT")) persistent = atoi(e) != 0;
+        if (persistent) {
+            const int lds = max(max(BL.total, FL.total), solve_lds);
+            SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_persistent), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            unsigned grid = n_scenes < 4096u ? n_scenes : 4096u;
+            if (const char* e = getenv("SLHIP_SETTLE_PERSISTENT_GRID")) { const unsigned g = (unsigned)atoi(e); if (g > 0u && g < grid) grid = g; }
+            k_w_persistent<<<grid, 64, lds, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, W, BL, FL, pc, drive_w, list_stride, n_scenes);
+            SLHIP_LAUNCH_CHECK();
+            return 0;
+        }
         uint32_t step = params->resume;
         for (uint32_t f = 0; f < params->frames; ++f)
             for (uint32_t sub = 0; sub < params->substeps; ++sub, ++step) {

@@ -93,6 +93,21 @@ def test_batch_of_scenes(sl, oracle):
     assert_bodies_equal(gpu, ref)
 
 
+@pytest.mark.parametrize("form", ["lockstep", "persistent"])
+def test_both_forms_of_the_step_give_the_same_bits(sl, oracle, monkeypatch, form):
+    """slhip_settle has two launch forms -- six launches per step over the whole batch (large batches), one launch in which a
+    wave takes a scene through every step (k_w_persistent: small batches; the default of every other test of this file) -- built
+    from the same per-scene and per-pair functions.  Both against the oracle on a batch of heaps with ragged sizes, a resumed
+    second call included."""
+    monkeypatch.setenv("SLHIP_SETTLE_PERSISTENT", "1" if form == "persistent" else "0")
+    cube = scaled(sl, S.CUBE, 0.15)
+    bunny = scaled(sl, S.BUNNY, 0.2)
+    scs = [heap(sl, 300 + i, 2 + 3 * i, cube, bunny) for i in range(7)]
+    gpu, ref = run_both(oracle, scs, frames=60)
+    assert_bodies_equal(gpu, ref)
+    assert np.abs(gpu["lin_vel"]).max() > 0.0
+
+
 def test_static_object_and_no_plane(sl, oracle):
     cube = scaled(sl, S.CUBE, 0.2)
     big = scaled(sl, S.CUBE, 1.0)
