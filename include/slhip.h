@@ -389,7 +389,9 @@ typedef struct {
 /* Steps every scene of the batch `frames * substeps` times without a host round trip -- a short sequence of kernel launches per
  * step over the whole batch (broadphase; GJK / portal refinement per hull pair; the face manifold of NEW contact pairs and of those that lost a point; persistent
  * manifolds, contact list and colouring; the warm-started 4 + 4 Gauss-Seidel sweeps, integration, sleeping), including the redrop
- * heuristic when params->tabletop.  State that PhysX keeps from step to step lives in the scratch: the cached simplex, the
+ * heuristic when params->tabletop.  Batches of up to 2048 scenes take ONE launch instead, in which a wave carries a scene through
+ * all its steps (the same per-scene and per-pair functions: the results are the same bits; environment SLHIP_SETTLE_PERSISTENT=0/1
+ * forces a form; the per-kernel timings below exist for the lockstep form only).  State that PhysX keeps from step to step lives in the scratch: the cached simplex, the
  * persistent contact manifold and its impulses per hull pair, the table contacts per body -- and stays valid after the call:
  * a later call with params->resume = (steps run so far) continues from it (Scene::simulate, ManipulationSim::step and the
  * frames of simulateTableTopScene with a visualisation callback step ONE long-lived PxScene in the reference).
