@@ -1620,8 +1620,11 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
             SLHIP_LAUNCH_CHECK();
             return 0;
         }
+        // (probe: the frames from SLHIP_SETTLE_SWITCH_FRAME on in the persistent form -- both forms work on the same state)
+        uint32_t lockstep_frames = params->frames;
+        if (const char* e = getenv("SLHIP_SETTLE_SWITCH_FRAME")) { const int v = atoi(e); if (v >= 0 && (uint32_t)v < params->frames) lockstep_frames = (uint32_t)v; }
         uint32_t step = params->resume;
-        for (uint32_t f = 0; f < params->frames; ++f)
+        for (uint32_t f = 0; f < lockstep_frames; ++f)
             for (uint32_t sub = 0; sub < params->substeps; ++sub, ++step) {
                 // (a caller that never reads the timings must not grow the lists for ever: sampling stops at kMaxTimedEvents)
                 constexpr size_t kMaxTimedEvents = 1u << 16;
@@ -1652,6 +1655,16 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                     for (int k = 0; k < 6; ++k) g_settle_timing.events.push_back(ev[k]);
                 }
             }
+        if (lockstep_frames < params->frames) {
+            slhip_settle_params rest = *params;
+            rest.resume = step;
+            rest.frames = params->frames - lockstep_frames;
+            const int lds = max(max(BL.total, FL.total), solve_lds);
+            SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_persistent), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            unsigned grid = n_scenes < 4096u ? n_scenes : 4096u;
+            if (const char* e = getenv("SLHIP_SETTLE_PERSISTENT_GRID")) { const unsigned g = (unsigned)atoi(e); if (g > 0u && g < grid) grid = g; }
+            k_w_persistent<<<grid, 64, lds, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, rest, W, BL, FL, pc, drive_w, list_stride, n_scenes);
+        }
         SLHIP_LAUNCH_CHECK();
         return 0;
     }
