@@ -93,13 +93,15 @@ def test_batch_of_scenes(sl, oracle):
     assert_bodies_equal(gpu, ref)
 
 
-@pytest.mark.parametrize("form", ["lockstep", "persistent"])
+@pytest.mark.parametrize("form", ["lockstep", "persistent", "lockstep, then persistent from frame 25"])
 def test_both_forms_of_the_step_give_the_same_bits(sl, oracle, monkeypatch, form):
     """slhip_settle has two launch forms -- six launches per step over the whole batch (large batches), one launch in which a
     wave takes a scene through every step (k_w_persistent: small batches; the default of every other test of this file) -- built
     from the same per-scene and per-pair functions.  Both against the oracle on a batch of heaps with ragged sizes, a resumed
     second call included."""
     monkeypatch.setenv("SLHIP_SETTLE_PERSISTENT", "1" if form == "persistent" else "0")
+    if "then" in form:
+        monkeypatch.setenv("SLHIP_SETTLE_SWITCH_FRAME", "25")      # (both forms work on the same state: a call may change between them)
     cube = scaled(sl, S.CUBE, 0.15)
     bunny = scaled(sl, S.BUNNY, 0.2)
     scs = [heap(sl, 300 + i, 2 + 3 * i, cube, bunny) for i in range(7)]
