@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 RESOLUTION = (640, 480)
 INTRINSICS = (1066.778, 1067.487, 312.9869, 241.3109)  # reference examples/ycb.py:32
 N_OBJECTS = 20
-TARGET_RING = 8     # render-target sets kept alive (chunks of --render-chunk scenes)
+TARGET_RING = int(os.environ.get("SLHIP_BENCH_TARGET_RING", 4))     # render-target sets kept alive (chunks of --render-chunk scenes): 4 x 1024 scenes = 50 GB
 
 
 def parse():
@@ -35,11 +35,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16384,
-                    help="scenes per GPU per step = one settle launch.  Scenes settle in very different times (60 .. 410 ms against a "
-                         "145 ms mean) and 2048 are resident at once, so a launch ends with a tail of idle CUs; the more rounds of "
-                         "workgroups a launch has, the smaller the share of that tail: 4096 -> 4 490, 8192 -> 5 110, 16384 -> 5 550, "
-                         "24576 -> 5 660 scenes/s (profiles/r02)")
+    ap.add_argument("--batch", type=int, default=32768,
+                    help="scenes per GPU per step = one settle call.  Every one of a settle's 2 400 launches ends with a tail of idle "
+                         "SIMDs, and the more rounds of workgroups a launch has, the smaller the share of that tail: round 2 measured "
+                         "4096 -> 4 490, 8192 -> 5 110, 16384 -> 5 550, 24576 -> 5 660 scenes/s; round 5, same box, default lengths: "
+                         "16384 -> 9 866, 32768 -> 10 240; 3-step runs: 32768 -> 9 700, 49152 -> 9 790, 65535 -> 9 830 (the settle scratch "
+                         "is 2 MB per scene: 65 GB at 32768)")
     ap.add_argument("--render-chunk", type=int, default=None,
                     help="scenes per render launch sequence (fewer, larger sequences: every kernel boundary is a chance for "
                          "queued settle workgroups to take the freed SIMDs); default 1024")

@@ -1,10 +1,10 @@
-"""BASELINE config C2 at the benchmark's full step size -- 16384 scenes of 20 YCB-like objects in one batch -- checked
-through properties that do not need the CPU oracle to run 16384 settles (it would take minutes):
+"""BASELINE config C2 at the benchmark's full step size -- 32768 scenes of 20 YCB-like objects in one batch -- checked
+through properties that do not need the CPU oracle to run 32768 settles (it would take minutes):
 
   * placement independence: a scene's random stream is keyed by its scene id, so scenes 7000..7063 of the big batch must
     come out bit for bit like a separate 64-scene batch staged at scene_id_base = 7000 -- other launch sizes, other
-    neighbours (cross-scene work lists of other lengths, another cost order of the solver launch, other partners in the solver
-    waves);
+    neighbours AND the other launch form: the big batch runs the lockstep kernels (cross-scene work lists, cost-ordered solver
+    launch, partners in the solver waves), the small one the persistent kernel;
   * sanity of every body of every scene: finite, above the table, rotation orthonormal;
   * the oracle on a few of the scenes, bit for bit;
   * the rendered ground truth of a scene is the same bits whether it is rendered as slot 7000 - 6144 of a 1024-scene chunk
@@ -18,7 +18,7 @@ from stillleben_amd import _settle_batch as SB
 
 pytestmark = pytest.mark.gpu
 
-N_BIG, N_OBJ, BASE_SMALL, N_SMALL = 16384, 20, 7000, 64
+N_BIG, N_OBJ, BASE_SMALL, N_SMALL = 32768, 20, 7000, 64
 
 
 @pytest.fixture(scope="module")
