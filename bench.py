@@ -785,6 +785,9 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
         },
         "breakdown_isolated_ms": {n: float(v) for n, v in zip(names, iso)},
         "dominant_render_phase": names[k_dom],
+        # what the rank holds in HBM at its peak (torch's allocator: records, settle scratch, render scratch, the ring of ground truth)
+        "hbm_footprint_GB": {"peak_allocated": torch.cuda.max_memory_allocated() / 1e9,
+                             "device_total": torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory / 1e9},
     }
 
 
