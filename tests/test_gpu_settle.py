@@ -15,6 +15,14 @@ pytestmark = pytest.mark.gpu
 TABLE = 0.04
 
 
+@pytest.fixture(autouse=True, params=["lockstep", "persistent"])
+def launch_form(request, monkeypatch):
+    """Every test of this file runs in both launch forms of slhip_settle: six launches per step over the whole batch (what large
+    batches -- the benchmark's -- take) and the one-launch persistent kernel (what batches of this size take by default)."""
+    monkeypatch.setenv("SLHIP_SETTLE_PERSISTENT", "1" if request.param == "persistent" else "0")
+    return request.param
+
+
 def scaled(sl, path, diag):
     m = sl.Mesh(path)
     m.center_bbox()
@@ -94,7 +102,9 @@ def test_batch_of_scenes(sl, oracle):
 
 
 @pytest.mark.parametrize("form", ["lockstep", "persistent", "lockstep, then persistent from frame 25"])
-def test_both_forms_of_the_step_give_the_same_bits(sl, oracle, monkeypatch, form):
+def test_both_forms_of_the_step_give_the_same_bits(sl, oracle, monkeypatch, form, launch_form):
+    if launch_form != "lockstep":
+        pytest.skip("sets the form itself")
     """slhip_settle has two launch forms -- six launches per step over the whole batch (large batches), one launch in which a
     wave takes a scene through every step (k_w_persistent: small batches; the default of every other test of this file) -- built
     from the same per-scene and per-pair functions.  Both against the oracle on a batch of heaps with ragged sizes, a resumed
