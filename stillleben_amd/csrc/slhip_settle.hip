@@ -1585,9 +1585,13 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         }
         const BeginLds BL = begin_layout(nb_cap, D.lh_cap);
         const FinishLds FL = finish_layout(nb_cap, W.g_cap);
-        // LDS of a solver wave: 32 KB (five waves per CU), more when a scene of the batch's largest shape needs it.  Its quarters and
-        // halves are the wave classes of k_w_finish (SLHIP_SOLVE_SPW = 1 / 2: at most one / two scenes per wave)
-        int solve_lds = 32 * 1024;
+        // LDS of a solver wave: 20 KB (eight waves per CU), more when a scene of the batch's largest shape needs it.  Its quarters and
+        // halves are the wave classes of k_w_finish (SLHIP_SOLVE_SPW = 1 / 2: at most one / two scenes per wave).  The sweeps are
+        // latency chains: what counts is how many solver waves a CU holds.  Per launch over 32768 C2 scenes alone, LDS per wave
+        // 48 / 40 / 32 / 24 / 20 / 16 KB (3 / 4 / 5 / 6 / 8 / 10 waves per CU): 2.41 / 1.91 / 2.10 / 1.59 / 1.38 / 1.42 ms -- the settle 1.88 s at
+        // 32 KB (rounds 4 and 5 until now), 1.57 s at 20; beside the render 9 920 - 9 980 against 10 060 scenes/s.  At 20 KB 8 % of the
+        // scenes sweep part of their contacts from global memory in some step (same bits), at 32 KB 0.05 %.
+        int solve_lds = 20 * 1024;
         if (solve_min_lds(nb_cap, W.g_cap) > solve_lds) solve_lds = (solve_min_lds(nb_cap, W.g_cap) + 1023) & ~1023;
         if (const char* e = getenv("SLHIP_SOLVE_LDS_KB")) { const int kb = atoi(e) * 1024; if (kb >= solve_min_lds(nb_cap, W.g_cap) && kb <= 160 * 1024) solve_lds = kb; }
         int max_class = 2;
