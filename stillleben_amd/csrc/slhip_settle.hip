@@ -1616,11 +1616,14 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         bool persistent = n_scenes <= kPersistentMaxScenes;
         if (const char* e = getenv("SLHIP_SETTLE_PERSISTENT")) persistent = atoi(e) != 0;
         if (persistent) {
-            const int lds = max(max(BL.total, FL.total), solve_lds);
+            // (one wave per SIMD by its registers: a wave may as well have a quarter of the CU's LDS for its scene's contacts)
+            WideBufs Wp = W;
+            Wp.solve_lds = max(solve_lds, 32 * 1024);      // (+ 6 KB of static LDS: four waves per CU still fit)
+            const int lds = max(max(BL.total, FL.total), Wp.solve_lds);
             SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_persistent), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             unsigned grid = n_scenes < 4096u ? n_scenes : 4096u;
             if (const char* e = getenv("SLHIP_SETTLE_PERSISTENT_GRID")) { const unsigned g = (unsigned)atoi(e); if (g > 0u && g < grid) grid = g; }
-            k_w_persistent<<<grid, 64, lds, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, W, BL, FL, pc, drive_w, list_stride, n_scenes);
+            k_w_persistent<<<grid, 64, lds, stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, Wp, BL, FL, pc, drive_w, list_stride, n_scenes);
             SLHIP_LAUNCH_CHECK();
             return 0;
         }
