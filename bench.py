@@ -64,6 +64,10 @@ def parse():
                     help="BASELINE.json configuration: C2 (default) is the headline metric; C1 4 cubes 320x240 (4096 scenes per step), "
                          "C3 512 C2 scenes through the per-object API, C4 bunny x 50 raster stress, C5 sl.diff 64 objects x 32 "
                          "hypotheses -- one JSON line in the same schema each (single GPU)")
+    ap.add_argument("--pair-budget", type=int, default=0,
+                    help="slhip_settle_params.pair_contact_budget: 0 (default) = every contact point goes to the solver, as in PhysX; "
+                         "N > 0 = the compound manifold reduction (NOT in the reference): a body pair touching through more hull pairs "
+                         "keeps the N deepest -- 32 is what rounds 3 and 4 ran (+2 %% scenes/s: 10 090 against 9 880 on one box)")
     ap.add_argument("--no-ssao", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes per host thread of the bounded CPU-baseline sample")
@@ -92,7 +96,7 @@ class Pipeline:
     the slhip_render launch sequences of the step's chunks on the render stream; `ring` SceneBatch record sets are
     recycled.  The host only enqueues: nothing is read back, no host thread sits between settle and render."""
 
-    def __init__(self, sl, table, batch, render_chunk, ssao, settle_streams, seed, rank, render_streams=1):
+    def __init__(self, sl, table, batch, render_chunk, ssao, settle_streams, seed, rank, render_streams=1, pair_contact_budget=0):
         from stillleben_amd import _abi
         from stillleben_amd._context import engine
 
@@ -106,7 +110,7 @@ class Pipeline:
         self.sets = []
         for _ in range(self.ring):
             b = sl.SceneBatch(table, batch, N_OBJECTS, resolution=RESOLUTION, seed=seed, render_chunk=render_chunk,
-                              shadows=not os.environ.get("SLHIP_BENCH_NO_SHADOWS"))
+                              shadows=not os.environ.get("SLHIP_BENCH_NO_SHADOWS"), pair_contact_budget=pair_contact_budget)
             b.set_camera_intrinsics(*INTRINSICS)
             self.sets.append(b)
         # stream priorities "<settle>,<render>" (-1 = high, 0 = default): the settle is a chain of 2400 short dependent launches, the
@@ -216,7 +220,7 @@ def _header_define(name):
     return int(m.group(1)) if m else None
 
 
-def cpu_baseline(table_meshes, scenes_per_thread, ssao):
+def cpu_baseline(table_meshes, scenes_per_thread, ssao, pair_contact_budget=0):
     """The oracle (scalar C restatement) timed on the host cores on a bounded sample of the same workload: every
     thread takes `scenes_per_thread` scenes through {tabletop set-up + 400-step settle + camera / light placement +
     640x480 render}.  Scenes are independent, so the threads mirror the reference's JobQueue workers: the stated figure runs
@@ -239,7 +243,7 @@ def cpu_baseline(table_meshes, scenes_per_thread, ssao):
     W, H = RESOLUTION
     proto = sl.Scene(RESOLUTION)
     proto.set_camera_intrinsics(*INTRINSICS)
-    sp = SB.default_params(tabletop=True, pair_contact_budget=SB.PAIR_CONTACT_BUDGET)   # what sl.SceneBatch asks for
+    sp = SB.default_params(tabletop=True, pair_contact_budget=pair_contact_budget)   # what the timed GPU path runs with
 
     def params(t):
         p = np.zeros((), dtype=_abi.SYNTH_PARAMS_DTYPE)
@@ -411,7 +415,7 @@ def main():
         args.render_chunk = 1024
     args.render_chunk = min(args.render_chunk, args.batch)
     pipe = Pipeline(sl, table, args.batch, args.render_chunk, not args.no_ssao, max(1, args.settle_streams), seed=20260929, rank=rank,
-                    render_streams=min(max(1, args.render_streams), 2))
+                    render_streams=min(max(1, args.render_streams), 2), pair_contact_budget=args.pair_budget)
     pipe.eng.L.slhip_timing_enable(1)
     pipe.eng.L.slhip_settle_timing_enable(1)
     table.device()
@@ -602,7 +606,7 @@ def main():
         out["caps"] = caps
         out["exchange"] = exchange
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(meshes, args.cpu_scenes, not args.no_ssao)
+            out["cpu_baseline"] = cpu_baseline(meshes, args.cpu_scenes, not args.no_ssao, args.pair_budget)
     if comm is not None:
         comm.close()
     if dist is not None:

@@ -362,7 +362,7 @@ typedef struct {
        several hundred one-point manifolds, one Gauss-Seidel chain of that length -- keeps the B hull pairs with the deepest points
        (ties: list order); the others stay filed as manifolds (no impulse) and return when they are among the deepest.  Counted per
        (scene, step) by slhip_settle_caps.  On the 20-object workload a budget of 32 or 64 leaves the share of bodies at rest, the redrops
-       and the deepest penetrations where they are without it.                                            */
+       and the deepest penetrations where they are without it.  Every host path of this repository passes 0.   */
     uint32_t pair_contact_budget;
     /* 0: the call starts from a cold contact state (it initialises the scratch).  N > 0: the call CONTINUES the N steps that earlier
        calls ran on the same d_scratch with the same scenes, bodies (same order, same hulls) and sizing hints -- the state PhysX

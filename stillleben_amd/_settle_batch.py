@@ -40,10 +40,12 @@ PARAMS_DTYPE = np.dtype([
 ])
 assert PARAMS_DTYPE.itemsize == 120
 
-# slhip_settle_params.pair_contact_budget (0: every point goes to the solver, as in PhysX -- the default of every per-scene entry point):
-# a body pair touching through more hull pairs keeps the deepest ones -- nested concave shapes otherwise put several hundred one-point
-# manifolds into ONE Gauss-Seidel chain.  This value is what sl.SceneBatch (the throughput path) asks for, and says so (settle_caps).
-PAIR_CONTACT_BUDGET = 32
+# slhip_settle_params.pair_contact_budget.  0: every point goes to the solver, as in PhysX -- the default of every entry point, sl.SceneBatch
+# and the benchmark included (round 5; rounds 3 and 4 ran the batch path at 32).  > 0: a body pair touching through more hull pairs keeps the
+# deepest ones -- nested concave shapes otherwise put several hundred one-point manifolds into ONE Gauss-Seidel chain.  NOT in the
+# reference; an option (sl.SceneBatch(..., pair_contact_budget=32), bench.py --pair-budget 32: +2 % scenes/s), stated by settle_caps.
+PAIR_CONTACT_BUDGET = 0
+PAIR_CONTACT_BUDGET_FAST = 32
 
 BODY_STATIC = 1
 BODY_ASLEEP = 2

@@ -122,7 +122,7 @@ class SceneBatch:
 
     def __init__(self, table, n_scenes, n_objects, resolution=(640, 480), seed=0, asset_ids=None, random_pbr=True,
                  shadows=True, render_chunk=None, plane_size=(3.0, 3.0), light_color=(300.0, 300.0, 300.0),
-                 ambient=(0.05, 0.05, 0.05), manual_exposure=-1.0, scene_id_base=0):
+                 ambient=(0.05, 0.05, 0.05), manual_exposure=-1.0, scene_id_base=0, pair_contact_budget=SB.PAIR_CONTACT_BUDGET):
         from .scene import Scene
 
         if not 1 <= n_objects <= 64:      # SLHIP_SYNTH_MAX_OBJECTS: the synthesis kernels map an object to a lane of one wave
@@ -160,7 +160,7 @@ class SceneBatch:
         self.shadows = bool(shadows)
         self._set_projection()
         # settle parameters with the sizing hints of the WORST scene the table can produce (no read-back)
-        sp = SB.default_params(tabletop=True, pair_contact_budget=SB.PAIR_CONTACT_BUDGET)   # (the compound manifold reduction: slhip.h)
+        sp = SB.default_params(tabletop=True, pair_contact_budget=int(pair_contact_budget))   # (0: every point, as in PhysX; > 0: the compound manifold reduction of slhip.h)
         sp["max_bodies_per_scene"] = self.n_objects
         sp["max_hulls_per_scene"] = table.bound(table.n_hulls, n_objects, distinct)
         sp["max_hull_verts_per_scene"] = table.bound(table.n_hull_verts, n_objects, distinct)
@@ -169,7 +169,8 @@ class SceneBatch:
         # ever seen: 3 168 candidate pairs in a step -- mug in bowl on banana; 664 contacts with the default pair_contact_budget)
         h = int(sp["max_hulls_per_scene"])
         sp["max_hull_pairs_per_scene"] = max(64, min(4096, h * h // 2))
-        sp["max_contacts_per_scene"] = 1024
+        # (32768 C2 scenes: at most 2 191 contacts in a step with every point in the solver, 543 with a pair budget of 32)
+        sp["max_contacts_per_scene"] = 3072 if int(pair_contact_budget) == 0 else 1024
         for key, env in (("max_hull_pairs_per_scene", "SLHIP_PAIR_CAP"), ("max_contacts_per_scene", "SLHIP_CONTACT_CAP"),
                          ("pair_contact_budget", "SLHIP_PAIR_BUDGET")):      # developer knobs (tools/probes)
             if os.environ.get(env):

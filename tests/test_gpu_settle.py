@@ -434,9 +434,9 @@ def test_no_contact_is_dropped(sl, oracle):
     assert caps["max_contacts"] > 255                      # beyond round 3's cap ...
     assert caps["spill_steps"] > 0 and caps["scenes_spilled"] > 0      # ... and beyond the LDS-resident part: the case is exercised
     assert caps["reduced_steps"] == 0
-    # the same pile with the default compound manifold reduction (pair_contact_budget): bunny on bunny offers hundreds of one-point
+    # the same pile with the optional compound manifold reduction (pair_contact_budget = 32): bunny on bunny offers hundreds of one-point
     # manifolds per body pair, the deepest 64 go to the solver -- counted, and identical on both sides
-    prm["pair_contact_budget"] = SB.PAIR_CONTACT_BUDGET
+    prm["pair_contact_budget"] = SB.PAIR_CONTACT_BUDGET_FAST
     gpu, caps = se.run_with_caps(srec, bodies.copy(), prm)
     ref = bodies.copy()
     oc = _oracle_caps(oracle, srec, ref, hulls, verts, SB.sizing_hints(prm, srec, bodies, hulls))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (CPU, oracle): how well the settle comes to rest on the C2 workload -- share of bodies
 with |v| < 0.05 m/s after the 400 steps, share asleep, redrops per scene, deepest penetration, bodies below the table.
-    python tools/physics_quality.py [n_scenes] [first_seed] [n_objects] [threads] [pair_contact_budget = 32, sl.SceneBatch's]
+    python tools/physics_quality.py [n_scenes] [first_seed] [n_objects] [threads] [pair_contact_budget = 0: every point, as in PhysX and as sl.SceneBatch runs; 32: the optional reduction]
 Scenes are independent: they are settled on `threads` processes (fork)."""
 import os
 import sys
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def stage(n, seed0, n_objects, budget=32):
+def stage(n, seed0, n_objects, budget=0):
     import bench
     import oracle
     import stillleben_amd as sl
@@ -60,7 +60,7 @@ def settle_range(args):
     return lo, hi, bodies[b0:b1].copy(), trace, caps
 
 
-def measure(n=64, seed0=900000, n_objects=20, threads=8, budget=32, quiet=False):
+def measure(n=64, seed0=900000, n_objects=20, threads=8, budget=0, quiet=False):
     import multiprocessing as mp
 
     bodies, ss, hull_recs, hull_verts, prm = stage(n, seed0, n_objects, budget)
@@ -113,4 +113,4 @@ def measure(n=64, seed0=900000, n_objects=20, threads=8, budget=32, quiet=False)
 
 if __name__ == "__main__":
     a = [int(x) for x in sys.argv[1:]]
-    measure(*(a + [64, 900000, 20, 8, 32][len(a):]))
+    measure(*(a + [64, 900000, 20, 8, 0][len(a):]))
