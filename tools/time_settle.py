@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): one settle of B C2 scenes with the GPU to itself, per-kernel launch averages from the
 library's own HIP events (slhip_settle_timings) -- the quick loop for work on the k_w_* kernels.
-    python tools/time_settle.py [B=16384] [repeats=2] [budget]
+    python tools/time_settle.py [B=16384] [repeats=2] [pair_contact_budget = sl.SceneBatch's default, 0]
 SLHIP_BY_STEP=file.csv: the last repeat times EVERY step and writes step, ms of the five kernels (profiles/rNN/solve_by_step.csv)."""
 import ctypes as C
 import os
