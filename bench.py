@@ -485,8 +485,12 @@ def main():
         dist.all_gather(tr, torch.tensor([t_rank], device="cuda", dtype=torch.float64))
         per_rank_s = [float(x.item()) for x in tr]
     streamed = (pipe.streamer.bytes_sent - streamed0) if pipe.streamer is not None else 0
+    settle_errors = []
     for r in recs:
-        r["batch"].check_settled()     # a scene the kernel refused (sizing hints) must fail the run, not pass silently
+        try:
+            r["batch"].check_settled()     # a scene the kernel refused (sizing hints) or a list that overflowed must not pass silently ...
+        except RuntimeError as e:          # ... nor take the measurement with it: the line reports it (caps, settle_errors)
+            settle_errors.append(str(e)[:400])
 
     # phase timings: the render events of all timed steps accumulate in the library
     ms_all = (C.c_float * 8)()
@@ -604,6 +608,7 @@ def main():
         out = report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage, t_place, t_render, t_render_iso,
                      phases, iso, settle_kernels, caps)
         out["caps"] = caps
+        out["settle_errors"] = settle_errors      # must be empty: refused scenes / overflowed lists of the timed steps' record sets
         out["exchange"] = exchange
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(meshes, args.cpu_scenes, not args.no_ssao, args.pair_budget)

@@ -170,7 +170,7 @@ class SceneBatch:
         h = int(sp["max_hulls_per_scene"])
         sp["max_hull_pairs_per_scene"] = max(64, min(4096, h * h // 2))
         # (32768 C2 scenes: at most 2 191 contacts in a step with every point in the solver, 543 with a pair budget of 32)
-        sp["max_contacts_per_scene"] = 3072 if int(pair_contact_budget) == 0 else 1024
+        sp["max_contacts_per_scene"] = 4096 if int(pair_contact_budget) == 0 else 1024
         for key, env in (("max_hull_pairs_per_scene", "SLHIP_PAIR_CAP"), ("max_contacts_per_scene", "SLHIP_CONTACT_CAP"),
                          ("pair_contact_budget", "SLHIP_PAIR_BUDGET")):      # developer knobs (tools/probes)
             if os.environ.get(env):
