@@ -19,7 +19,7 @@ repository needs --
 (the decomposition is used only when it has less than 75 % of the single hull's volume, mesh.cpp:426-429).
 
 tests/test_host_acd.py compares the result with the fixtures the reference's own V-HACD produced (cube, bunny, the 21 YCB-like
-classes): same single-hull decisions, total hull volume within 10 %, hull counts within a factor of two."""
+classes): same single-hull decisions, total hull volume within 6 % (bunny 12 %), hull counts within a factor of 1.8 (bunny: 123 against 121)."""
 import numpy as np
 
 MAX_DEPTH = 20            # VHACD.h:222 m_depth

@@ -70,8 +70,10 @@ def test_ycb_like_classes_match_the_vhacd_fixtures(results):
         vref = sum(h.volume() for h in ref)
         assert mv <= 64
         assert (n == 1) == (len(ref) == 1), "%s: single-hull decision differs (%d vs %d hulls)" % (name, n, len(ref))
-        assert vol == pytest.approx(vref, rel=0.10), "%s: total hull volume %.4g vs %.4g" % (name, vol, vref)
-        assert len(ref) / 2.0 <= n <= 2.0 * len(ref), "%s: %d hulls vs %d" % (name, n, len(ref))
+        # (measured: the 17 convex classes within 0.6 %, large marker +5.0 %; bowl +4.8 %, scissors +1.7 %, mug / drill -0.7 %, banana +0.5 %)
+        assert vol == pytest.approx(vref, rel=0.06), "%s: total hull volume %.4g vs %.4g" % (name, vol, vref)
+        # (measured: banana 27 vs 44, scissors 15 vs 26, bowl 36 vs 28, mug 34 vs 28, drill 10 vs 6: axis-aligned cuts against V-HACD's)
+        assert len(ref) / 1.8 <= n <= 1.8 * len(ref), "%s: %d hulls vs %d" % (name, n, len(ref))
     assert all(results[c][0] > 1 for c in CONCAVE)
 
 
@@ -82,8 +84,8 @@ def test_bunny_matches_the_vhacd_fixture(results):
     ref = [H.Hull(z["v%d" % i], z["t%d" % i]) for i in range(int(z["n_hulls"]))]
     n, vol, mv = results["bunny"]
     assert mv <= 64 and len(ref) == 121
-    assert len(ref) / 2.0 <= n <= 2.0 * len(ref)
-    assert vol == pytest.approx(sum(h.volume() for h in ref), rel=0.12)
+    assert len(ref) / 1.25 <= n <= 1.25 * len(ref)                 # (measured: 123 hulls against V-HACD's 121)
+    assert vol == pytest.approx(sum(h.volume() for h in ref), rel=0.12)      # (+10.4 %: the bunny is open at the bottom)
 
 
 def test_decomposed_mesh_settles(sl, oracle):
