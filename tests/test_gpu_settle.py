@@ -120,6 +120,32 @@ def test_both_forms_of_the_step_give_the_same_bits(sl, oracle, monkeypatch, form
     assert np.abs(gpu["lin_vel"]).max() > 0.0
 
 
+_NATIVE = {}
+
+
+def test_natively_decomposed_meshes_settle_bit_exact(sl, oracle):
+    """Row S1 feeding the settle: collision hulls made by the IN-TREE decomposition (hulls._compute_hulls: no V-HACD fixture, no
+    cache) -- a power drill (10 hulls) and a mug (34) -- dropped with cubes; the kernels against the oracle on those hulls."""
+    from stillleben_amd import hulls as H
+    from stillleben_amd import physics, synthetic
+    from stillleben_amd.mesh import Mesh
+
+    if not _NATIVE:      # (the decomposition takes seconds: once for both launch forms)
+        for name in ("035_power_drill", "025_mug"):
+            cm, _ = synthetic.make_class_mesh(name, 0, 8192, 64)
+            hs = H._compute_hulls(cm, False)
+            assert len(hs) > 1
+            _NATIVE[name] = Mesh.from_data(cm, hs, "memory://%s_native" % name)
+    cube = scaled(sl, S.CUBE, 0.12)
+    scene = sl.Scene((320, 240), seed=11)
+    for m in (_NATIVE["035_power_drill"], cube, _NATIVE["025_mug"], cube, _NATIVE["035_power_drill"]):
+        scene.add_object(sl.Object(m))
+    physics.prepare_tabletop(scene)
+    gpu, ref = run_both(oracle, [scene], frames=50)
+    assert_bodies_equal(gpu, ref)
+    assert (gpu["pose"][:, 11] > TABLE).all()
+
+
 def test_static_object_and_no_plane(sl, oracle):
     cube = scaled(sl, S.CUBE, 0.2)
     big = scaled(sl, S.CUBE, 1.0)
