@@ -622,16 +622,24 @@ def main():
 
 
 def kernel_source_sha():
-    """Fingerprint of the kernel sources (stillleben_amd/csrc/*.hip|*.inc|*.h, include/slhip.h): tools/collect_counters.py files it
-    with the counters it takes, and the roofline below only multiplies a live time by a counter taken from THESE sources."""
+    """Fingerprint of the kernel sources (stillleben_amd/csrc/*.hip|*.inc|*.h, include/slhip.h) -- of their CODE: comments and
+    white space do not count (a reworded comment does not make a counter stale).  tools/collect_counters.py files it with the
+    counters it takes, and the roofline below only multiplies a live time by a counter taken from THESE sources."""
     import hashlib
+    import re
+
+    def code_of(text):
+        # string literals first (a "//" inside one is not a comment), then block and line comments, then all white space
+        pat = re.compile(r'"(?:\\.|[^"\\])*"|/\*.*?\*/|//[^\n]*', re.S)
+        text = pat.sub(lambda m: m.group(0) if m.group(0).startswith('"') else " ", text)
+        return re.sub(r"\s+", " ", text).strip()
 
     h = hashlib.sha256()
     d = os.path.join(ROOT, "stillleben_amd", "csrc")
     for f in sorted(os.listdir(d)) + ["../../include/slhip.h"]:
         if f.endswith((".hip", ".inc", ".h")):
-            with open(os.path.join(d, f), "rb") as fh:
-                h.update(f.encode() + b"\0" + fh.read())
+            with open(os.path.join(d, f), "r", encoding="utf-8", errors="replace") as fh:
+                h.update(f.encode() + b"\0" + code_of(fh.read()).encode("utf-8", "replace"))
     return h.hexdigest()[:16]
 
 
