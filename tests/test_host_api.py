@@ -422,3 +422,30 @@ def test_pybind11_diff_module_is_the_reference_boundary():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no HIP device"):
             m.generate_sobel_valid_mask(torch.zeros(4, 4, dtype=torch.int16), torch.zeros(4, 4))
+
+
+def test_kernel_source_fingerprint_counts_code_only(tmp_path, monkeypatch):
+    """bench.py quotes per-instruction roofline figures only when profiles/rNN/counters.json was taken from the kernel sources of
+    the tree (kernel_source_sha): the fingerprint must move with the code and stay put when a comment is reworded."""
+    import os
+    import shutil
+    import sys
+
+    root = os.path.join(os.path.dirname(__file__), "..")
+    sys.path.insert(0, root)
+    import bench
+
+    a = bench.kernel_source_sha()
+    assert len(a) == 16 and a == bench.kernel_source_sha()
+    # a copy of the tree's sources with (1) a reworded comment, (2) a changed constant
+    for sub in ("stillleben_amd/csrc", "include"):
+        shutil.copytree(os.path.join(root, sub), tmp_path / sub)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.kernel_source_sha() == a
+    f = tmp_path / "include" / "slhip.h"
+    text = f.read_text()
+    f.write_text(text.replace("/*", "/* reworded:", 1) + "\n// a trailing remark\n")
+    assert bench.kernel_source_sha() == a
+    assert "#define SLHIP_ABI_VERSION 4" in text
+    f.write_text(text.replace("#define SLHIP_ABI_VERSION 4", "#define SLHIP_ABI_VERSION 5", 1))
+    assert bench.kernel_source_sha() != a
