@@ -5,3 +5,7 @@ import sys as _sys
 
 libstillleben_diff_python = _il.import_module("stillleben_amd.lib.libstillleben_diff_python")
 _sys.modules[__name__ + ".libstillleben_diff_python"] = libstillleben_diff_python
+
+# the main module (python/src/bridge.cpp:23-42) under the name the reference imports it by
+libstillleben_python = _il.import_module("stillleben_amd.lib.libstillleben_python")
+_sys.modules[__name__ + ".libstillleben_python"] = libstillleben_python

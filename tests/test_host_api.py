@@ -424,6 +424,40 @@ def test_pybind11_diff_module_is_the_reference_boundary():
             m.generate_sobel_valid_mask(torch.zeros(4, 4, dtype=torch.int16), torch.zeros(4, 4))
 
 
+def test_main_module_answers_to_the_reference_name():
+    """python/src/bridge.cpp:23-42: the main extension module is `libstillleben_python`; the reference's package imports it as
+    `from .lib.libstillleben_python import *` + `import _set_install_prefix` (python/stillleben/__init__.py:12-13) and its diff
+    module as `from .lib.libstillleben_python import Scene, RenderPassResult` (diff.py:22).  The module exports exactly the names
+    bridge.cpp's thirteen init(m) calls register (py_*.cpp: py::class_ / m.def), and they are the package's objects."""
+    import importlib
+
+    ns = {}
+    exec("from stillleben.lib.libstillleben_python import *\n"
+         "from stillleben.lib.libstillleben_python import _set_install_prefix\n"
+         "from stillleben.lib.libstillleben_python import Scene, RenderPassResult\n", ns)
+    m = importlib.import_module("stillleben.lib.libstillleben_python")
+    registered = {
+        "init", "init_cuda", "_set_install_prefix",                                   # py_context.cpp:82-102
+        "Range3D", "quat_to_matrix", "matrix_to_quat", "Texture", "Texture2D",        # py_magnum.cpp:51-157
+        "Mesh", "MeshCache", "Object", "LightMap", "Scene",                           # py_mesh / py_object / py_light_map / py_scene
+        "RenderPassResult", "RenderPass", "render_debug_image",                       # py_render_pass.cpp:81-282
+        "ImageLoader", "ImageSaver", "Animator", "Viewer", "view", "JobQueue", "ManipulationSim",
+    }
+    public = {n for n in vars(m) if not n.startswith("_")} | {"_set_install_prefix"}
+    assert public == registered
+    assert set(m.__all__) == registered - {"_set_install_prefix"}
+    import stillleben as sl
+    import stillleben_amd
+    for n in registered:
+        assert getattr(m, n) is getattr(stillleben_amd, n) is getattr(sl, n), n
+        assert n.startswith("_") or ns[n] is getattr(m, n)
+    # the reference's own __all__ (python/stillleben/__init__.py:15-42) resolves on the alias package
+    for n in ("init", "init_cuda", "render_debug_image", "Animator", "ImageLoader", "ImageSaver", "LightMap", "Mesh", "MeshCache",
+              "Object", "Range3D", "RenderPass", "RenderPassResult", "Scene", "Texture", "Texture2D", "Viewer", "view",
+              "camera_model", "diff", "extension", "losses", "quat_to_matrix", "matrix_to_quat"):
+        assert hasattr(sl, n), n
+
+
 def test_kernel_source_fingerprint_counts_code_only(tmp_path, monkeypatch):
     """bench.py quotes per-instruction roofline figures only when profiles/rNN/counters.json was taken from the kernel sources of
     the tree (kernel_source_sha): the fingerprint must move with the code and stay put when a comment is reworded."""
