@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32768,
+    ap.add_argument("--batch", type=int, default=None,
                     help="scenes per GPU per step = one settle call.  Every one of a settle's 2 400 launches ends with a tail of idle "
                          "SIMDs, and the more rounds of workgroups a launch has, the smaller the share of that tail: round 2 measured "
                          "4096 -> 4 490, 8192 -> 5 110, 16384 -> 5 550, 24576 -> 5 660 scenes/s; round 5, same box, default lengths: "
@@ -356,10 +356,12 @@ def run_other_config(args):
                                        "in 128-scene launch sequences (shadows + SSAO); the 8-rank form shards them 64 per GPU"},
                 "roofline": r["roofline"]}
     elif cfg == "C4":
-        r = bc.c4()
-        line = {"metric": "renders/sec, stanford bunny x 50 (%d triangles), 640x480, all 8 outputs" % r["triangles"],
-                "value": 1e3 / r["render_ms"], "unit": "scenes/s", "steps": 10, "warmup": 1, "ms_per_step": r["render_ms"],
-                "config": {"workload": "C4: bunny x 50 raster stress, render only", "mtris_per_s": r["mtris_per_s"]},
+        B4 = args.batch or 1
+        r = bc.c4(B4)
+        line = {"metric": "renders/sec, stanford bunny x 50 (%d triangles per scene), 640x480, all 8 outputs" % (r["triangles"] // B4),
+                "value": B4 * 1e3 / r["render_ms"], "unit": "scenes/s", "steps": 10 if B4 == 1 else 5, "warmup": 1, "ms_per_step": r["render_ms"],
+                "config": {"workload": "C4: bunny x 50 raster stress, render only, %d scene(s) per launch sequence (--batch)" % B4,
+                           "mtris_per_s": r["mtris_per_s"], "raster_share": r["raster_share"], "raster": r["raster"]},
                 "roofline": r["roofline"]}
     else:
         r = bc.c5()
@@ -381,6 +383,8 @@ def main():
         if args.gpus != 1:
             sys.exit("bench.py: --config %s is a single-GPU configuration" % args.config)
         return run_other_config(args)
+    if args.batch is None:
+        args.batch = 32768
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(respawn_ranks(args))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
@@ -720,8 +724,8 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
         # mean contacts the solver took per scene and step: counted by the kernels themselves (slhip_settle_caps counts[9])
         contacts = caps["contacts_per_scene_step"] if caps else sq.get("contacts_per_scene_step", 45.0)
         # per launch (= one step of every scene): the scene's working bodies (152 B) and prepared contacts (72 B) in, group /
-        # colour lists in, the body records (288 B) out -- DESIGN.md section 4
-        per_scene = N_OBJECTS * 152 + contacts * 72 + 1500 + N_OBJECTS * 288
+        # colour lists in, the body records (304 B) out -- DESIGN.md section 4
+        per_scene = N_OBJECTS * 152 + contacts * 72 + 1500 + N_OBJECTS * 304
         ms_launch = settle_kernels[kname]["avg_ms_per_launch"]
         launches_per_settle = 400
         measured = ("HIP events on the settle streams around every k_w_solve launch of every 8th step of the timed region "
@@ -729,7 +733,7 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
     else:
         kname = "k_settle"
         sq = ck.get(kname, {})
-        per_scene = N_OBJECTS * 288 * 2 + hulls_per_scene * 64 + hverts_per_scene * 16
+        per_scene = N_OBJECTS * 304 * 2 + hulls_per_scene * 64 + hverts_per_scene * 16
         ms_launch = t_settle
         launches_per_settle = 1
         measured = "HIP events on the launch's stream around every slhip_settle of the timed region"

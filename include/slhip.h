@@ -33,12 +33,14 @@
 extern "C" {
 #endif
 
-#define SLHIP_ABI_VERSION 4   /* 2: slhip_render_scratch.d_shadow_tiles, slhip_render_scratch_bytes fills 7 sizes
+#define SLHIP_ABI_VERSION 5   /* 2: slhip_render_scratch.d_shadow_tiles, slhip_render_scratch_bytes fills 7 sizes
                                  3: slhip_render_scratch.d_vattr is REQUIRED (the post-transform vertex cache) and `_pad` became
                                     shadow_lights; d_clip holds 9 float4 planes per vertex; slhip_settle_params grew to 116 bytes
                                  4: slhip_settle_params.max_body_pairs_per_scene (120 bytes); slhip_settle_caps fills ten counts
                                     (list capacities instead of caps, pair_contact_budget, resume: the contact state of a settle
-                                    outlives the call); slhip_settle_caps fills counts[8]                                        */
+                                    outlives the call); slhip_settle_caps fills counts[8]
+                                 5: slhip_settle_params.stabilization_threshold (128 bytes); slhip_body.stab (304 bytes) carries the
+                                    stabilisation state of a body, SLHIP_BODY_FROZEN                                             */
 #define SLHIP_NUM_LIGHTS 3 /* reference include/stillleben/common.h:17 */
 
 /* ---------------------------------------------------------------------------------------------
@@ -292,6 +294,7 @@ typedef struct {
 
 #define SLHIP_BODY_STATIC   1u   /* Object::isStatic -> eKINEMATIC (object.cpp:515-520)       */
 #define SLHIP_BODY_ASLEEP   2u
+#define SLHIP_BODY_FROZEN   4u   /* out: held in place by the stabilisation this step (PxSceneFlag::eENABLE_STABILIZATION) */
 
 /* Rigid body state.  `pose` is the object pose exactly as sl.Object.pose() returns it.       */
 typedef struct {
@@ -315,7 +318,10 @@ typedef struct {
     float drive_target[4];   /* world position the object origin is driven to                 */
     float drive_frame[4];    /* joint frame orientation (quaternion x y z w) = initial pose   */
     float drive_params[4];   /* stiffness, damping, force limit (manipulation_sim.cpp:52-55), unused */
-} slhip_body;                /* 288 bytes */
+    float stab[4];           /* state of the stabilisation (slhip_settle_params.stabilization_threshold), 0 in a fresh record:
+                                [0] seconds the body has spent below its threshold (PhysX: PXD_FREEZE_INTERVAL - PxsRigidBody::freezeCount [ext]),
+                                [1] 1 - the share of gravity the body feels (PhysX: 1 - accelScale [ext]), [2], [3] unused      */
+} slhip_body;                /* 304 bytes */
 
 /* One scene of the settle batch: bodies [body_begin, body_end).                              */
 typedef struct {
@@ -375,7 +381,20 @@ typedef struct {
        neighbours.  A body pair beyond the capacity is dropped with its hull pairs AND COUNTED (slhip_settle_caps counts[8]):
        the caller settles again with a larger value, like for the other two lists.                                          */
     uint32_t max_body_pairs_per_scene;
-} slhip_settle_params;
+    /* PxSceneFlag::eENABLE_STABILIZATION (scene.cpp:163).  The per-body stabilisation threshold, PhysX default 1e-5 * tolerance speed^2
+       = 1e-3 with context.cpp:236-238's speed of 10 [ext].  A body in an island that rests on something static, whose frame energy
+       (mass-normalised, from the velocities that moved it this step) is below min(10, touching body pairs) x threshold: both velocities
+       are scaled by 1 - SLHIP_STAB_DAMPING dt, the share of gravity it feels goes to SLHIP_STAB_GRAVITY by a quarter of the
+       distance per step (and back up by dt per step); after SLHIP_STAB_FREEZE_INTERVAL s of that, below
+       SLHIP_STAB_FREEZE_TOLERANCE x threshold, it is frozen: the step's pose change is taken back (SLHIP_BODY_FROZEN).  0: off. */
+    float stabilization_threshold;
+    uint32_t _pad_params;
+} slhip_settle_params;           /* 128 bytes */
+#define SLHIP_STAB_DAMPING          0.5f   /* PXD_SLEEP_DAMPING [ext]   */
+#define SLHIP_STAB_GRAVITY          0.9f   /* PXD_FREEZE_SCALE [ext]    */
+#define SLHIP_STAB_FREEZE_INTERVAL  1.5f   /* PXD_FREEZE_INTERVAL [ext] */
+#define SLHIP_STAB_FREEZE_TOLERANCE 0.25f  /* PXD_FREEZE_TOLERANCE [ext] */
+#define SLHIP_STAB_MAX_INTERACTIONS 10
 
 /* per-scene scratch (device), sized by slhip_settle_scratch_bytes */
 #define SLHIP_MAX_BODIES     400  /* bodies per scene (the kernels keep a scene's working bodies in LDS: 152 B each -- and its body-

@@ -190,6 +190,8 @@ typedef struct {
     int* body_lh;                        /* [NB + 1] first hull ordinal of every body */
     int *order, *size;                   /* [P + NB] colouring scratch */
     uint64_t* used;                      /* [NB] */
+    v3 *mv, *mw;                         /* [NB] the velocities that moved the bodies this step (after the position iterations) */
+    int *st_n, *st_touch;                /* [NB] stabilisation: touching body pairs of a body, its island rests on something static */
 } scene_ws;
 
 static void ws_free(scene_ws* ws)
@@ -198,6 +200,7 @@ static void ws_free(scene_ws* ws)
     free(ws->hp_ba); free(ws->hp_bb); free(ws->hp_ha); free(ws->hp_hb);
     free(ws->g_begin); free(ws->g_end); free(ws->g_a); free(ws->g_b); free(ws->g_color);
     free(ws->c); free(ws->wb); free(ws->hp_pm); free(ws->pp); free(ws->body_lh); free(ws->order); free(ws->size); free(ws->used);
+    free(ws->mv); free(ws->mw); free(ws->st_n); free(ws->st_touch);
     free(ws);
 }
 
@@ -225,8 +228,11 @@ static scene_ws* ws_alloc(int P, int C, int NB, int BP)
     ws->body_lh = (int*)malloc(sizeof(int) * (NB + 1));
     ws->order = (int*)malloc(sizeof(int) * G); ws->size = (int*)malloc(sizeof(int) * G);
     ws->used = (uint64_t*)malloc(sizeof(uint64_t) * (NB ? NB : 1));
+    ws->mv = (v3*)malloc(sizeof(v3) * (NB ? NB : 1)); ws->mw = (v3*)malloc(sizeof(v3) * (NB ? NB : 1));
+    ws->st_n = (int*)malloc(sizeof(int) * (NB ? NB : 1)); ws->st_touch = (int*)malloc(sizeof(int) * (NB ? NB : 1));
     if (!ws->hp_ba || !ws->hp_bb || !ws->hp_ha || !ws->hp_hb || !ws->g_begin || !ws->g_end || !ws->g_a || !ws->g_b || !ws->g_color ||
-        !ws->c || !ws->wb || !ws->hp_pm || !ws->pp || !ws->body_lh || !ws->order || !ws->size || !ws->used) { ws_free(ws); return NULL; }
+        !ws->c || !ws->wb || !ws->hp_pm || !ws->pp || !ws->body_lh || !ws->order || !ws->size || !ws->used ||
+        !ws->mv || !ws->mw || !ws->st_n || !ws->st_touch) { ws_free(ws); return NULL; }
     return ws;
 }
 
@@ -1397,6 +1403,20 @@ static void update_world_inertia(const slhip_body* b, wbody* w)
             w->Iinv_w.m[3 * r + c] = fmaf(T.m[3 * r + 2], w->R.m[3 * c + 2], fmaf(T.m[3 * r + 1], w->R.m[3 * c + 1], T.m[3 * r] * w->R.m[3 * c]));
 }
 
+/* mass-normalised kinetic energy [ext]: 0.5 (v.v + w.(I w) / m), I = inverse of inv_inertia (object axes, by cofactors) */
+static float kinetic_energy(const slhip_body* b, const wbody* wbd, v3 v, v3 w)
+{
+    const float* L = b->inv_inertia;
+    v3 wl = m3_tmul(&wbd->R, w);
+    float c00 = L[5] * L[10] - L[6] * L[9], c01 = L[6] * L[8] - L[4] * L[10], c02 = L[4] * L[9] - L[5] * L[8];
+    float c11 = L[0] * L[10] - L[2] * L[8], c12 = L[1] * L[8] - L[0] * L[9], c22 = L[0] * L[5] - L[1] * L[4];
+    float det = fmaf(L[2], c02, fmaf(L[1], c01, L[0] * c00));
+    v3 iw = V(fmaf(c02, wl.z, fmaf(c01, wl.y, c00 * wl.x)), fmaf(c12, wl.z, fmaf(c11, wl.y, c01 * wl.x)),
+              fmaf(c22, wl.z, fmaf(c12, wl.y, c02 * wl.x)));
+    float ang = det != 0.0f ? dot(wl, iw) / det * wbd->inv_mass : 0.0f;
+    return 0.5f * (dot(v, v) + ang);
+}
+
 static void store_body(slhip_body* b, const wbody* w)
 {
     for (int r = 0; r < 3; ++r)
@@ -1421,7 +1441,8 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         update_world_inertia(&bodies[i], &wb[i]);
         bodies[i].separation = 3.0e38f; /* +inf (scene.cpp:732) */
         if (wb[i].dynamic) {
-            wb[i].v = madd(wb[i].v, V(prm->gravity[0], prm->gravity[1], prm->gravity[2]), dt);
+            /* stabilisation: a settling body feels a share of gravity (PhysX: accelScale in the unconstrained-velocity integration [ext]) */
+            wb[i].v = madd(wb[i].v, V(prm->gravity[0], prm->gravity[1], prm->gravity[2]), dt * (1.0f - bodies[i].stab[1]));
             float damp = 1.0f - prm->angular_damping * dt;
             if (damp < 0.0f) damp = 0.0f;
             wb[i].w = scale(wb[i].w, damp);
@@ -1624,6 +1645,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         float ww = dot(wb[i].w, wb[i].w);
         float wl = prm->max_angular_velocity;
         if (ww > wl * wl) wb[i].w = scale(wb[i].w, wl / sqrtf(ww));
+        ws->mv[i] = wb[i].v; ws->mw[i] = wb[i].w;
         wb[i].x = madd(wb[i].x, wb[i].v, dt);
         quat wq = {wb[i].w.x, wb[i].w.y, wb[i].w.z, 0.0f};
         quat dq = quat_mul(wq, wb[i].q);
@@ -1655,21 +1677,66 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         }
     ws->step++;
 
+    /* Stabilisation, PxSceneFlag::eENABLE_STABILIZATION (scene.cpp:163); PhysX 4.1 Dy::updateWakeCounter, stabilisation branch, as
+       remembered [ext].  Per body: the body pairs it touches through contacts of this step's solver (PhysX: numCountedInteractions),
+       and whether its island -- the bodies connected through such contacts between dynamic bodies -- rests on something that does not
+       move: the table, a static or a sleeping body (PhysX: hasStaticTouch).  The flag spreads over the groups until nothing changes. */
+    const int stab = prm->stabilization_threshold > 0.0f;
+    if (stab) {
+        for (int i = 0; i < nb; ++i) { ws->st_n[i] = 0; ws->st_touch[i] = 0; }
+        for (int g = 0; g < ws->n_groups; ++g) {
+            int any = 0;
+            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) any |= ws->c[i].valid;
+            if (!any) continue;
+            const int a = ws->g_a[g], b = ws->g_b[g];
+            ws->st_n[a]++;
+            if (b >= 0) ws->st_n[b]++;
+            if (b < 0 || !wb[b].dynamic) ws->st_touch[a] = 1;
+            if (b >= 0 && !wb[a].dynamic) ws->st_touch[b] = 1;
+        }
+        for (int changed = 1; changed;) {
+            changed = 0;
+            for (int g = 0; g < ws->n_groups; ++g) {
+                const int a = ws->g_a[g], b = ws->g_b[g];
+                if (b < 0 || !wb[a].dynamic || !wb[b].dynamic || ws->st_touch[a] == ws->st_touch[b]) continue;
+                int any = 0;
+                for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) any |= ws->c[i].valid;
+                if (!any) continue;
+                ws->st_touch[a] = 1; ws->st_touch[b] = 1; changed = 1;
+            }
+        }
+    }
+
     /* (k) store, sleep bookkeeping */
     for (int i = 0; i < nb; ++i) {
         if (!wb[i].dynamic) continue;
         quat_to_m3(wb[i].q, &wb[i].R);
         wb[i].t = sub(wb[i].x, m3_mul(&wb[i].R, V(bodies[i].com[0], bodies[i].com[1], bodies[i].com[2])));
-        /* mass-normalised kinetic energy [ext]: 0.5 (v.v + w.(I w) / m), I = inverse of inv_inertia (object axes, by cofactors) */
-        const float* L = bodies[i].inv_inertia;
-        v3 wl = m3_tmul(&wb[i].R, wb[i].w);
-        float c00 = L[5] * L[10] - L[6] * L[9], c01 = L[6] * L[8] - L[4] * L[10], c02 = L[4] * L[9] - L[5] * L[8];
-        float c11 = L[0] * L[10] - L[2] * L[8], c12 = L[1] * L[8] - L[0] * L[9], c22 = L[0] * L[5] - L[1] * L[4];
-        float det = fmaf(L[2], c02, fmaf(L[1], c01, L[0] * c00));
-        v3 iw = V(fmaf(c02, wl.z, fmaf(c01, wl.y, c00 * wl.x)), fmaf(c12, wl.z, fmaf(c11, wl.y, c01 * wl.x)),
-                  fmaf(c22, wl.z, fmaf(c12, wl.y, c02 * wl.x)));
-        float ang = det != 0.0f ? dot(wl, iw) / det * wb[i].inv_mass : 0.0f;
-        float en = 0.5f * (dot(wb[i].v, wb[i].v) + ang);
+        int frozen = 0;
+        if (stab) {
+            /* frame energy from the velocities that moved the body (mass-normalised, like the sleep energy) */
+            float fen = kinetic_energy(&bodies[i], &wb[i], ws->mv[i], ws->mw[i]);
+            int ni = ws->st_n[i] > SLHIP_STAB_MAX_INTERACTIONS ? SLHIP_STAB_MAX_INTERACTIONS : ws->st_n[i];
+            float thresh = ws->st_touch[i] ? (float)ni * prm->stabilization_threshold : 0.0f;
+            float fc = bodies[i].stab[0] + dt;   /* seconds the body has been below the threshold (PhysX counts freezeCount down from the interval) */
+            float as = (1.0f - bodies[i].stab[1]) + dt;
+            if (as > 1.0f) as = 1.0f;
+            int settled = 1;
+            if (fen >= thresh) { settled = 0; fc = 0.0f; }
+            if (!ws->st_touch[i]) { as = 1.0f; settled = 0; }
+            if (settled) {
+                float d = 1.0f - SLHIP_STAB_DAMPING * dt;
+                wb[i].v = scale(wb[i].v, d);
+                wb[i].w = scale(wb[i].w, d);
+                as = as * 0.75f + 0.25f * SLHIP_STAB_GRAVITY;
+                if (fc >= SLHIP_STAB_FREEZE_INTERVAL && fen < prm->stabilization_threshold * SLHIP_STAB_FREEZE_TOLERANCE) frozen = 1;
+            }
+            bodies[i].stab[0] = fc;
+            bodies[i].stab[1] = 1.0f - as;
+        }
+        if (frozen) bodies[i].flags |= SLHIP_BODY_FROZEN; else bodies[i].flags &= ~SLHIP_BODY_FROZEN;
+        /* the sleep energy: from the velocities the body keeps (damped above) */
+        float en = kinetic_energy(&bodies[i], &wb[i], wb[i].v, wb[i].w);
         if (en >= prm->sleep_threshold || (bodies[i].drive_flags & 1u)) bodies[i].wake_counter = prm->wake_time;
         else {
             bodies[i].wake_counter -= dt;
@@ -1679,7 +1746,10 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
                 wb[i].w = V(0, 0, 0);
             }
         }
-        store_body(&bodies[i], &wb[i]);
+        if (frozen) {   /* held in place: the step's pose change is taken back (PhysX: body2World = the last transform [ext]), the velocities stay */
+            bodies[i].lin_vel[0] = wb[i].v.x; bodies[i].lin_vel[1] = wb[i].v.y; bodies[i].lin_vel[2] = wb[i].v.z;
+            bodies[i].ang_vel[0] = wb[i].w.x; bodies[i].ang_vel[1] = wb[i].w.y; bodies[i].ang_vel[2] = wb[i].w.z;
+        } else store_body(&bodies[i], &wb[i]);
     }
 }
 
@@ -1701,7 +1771,8 @@ static void redrop(const slhip_settle_scene* sc, slhip_body* bodies, int me, con
     float off_z = fmaf(P[10], c[2], fmaf(P[9], c[1], P[8] * c[0])) - c[3];
     P[3] = 0.0f; P[7] = 0.0f; P[11] = max_z - off_z;
     bodies[me].stuck_counter = 0;
-    for (int k = 0; k < 4; ++k) { bodies[me].lin_vel[k] = 0.0f; bodies[me].ang_vel[k] = 0.0f; }
+    for (int k = 0; k < 4; ++k) { bodies[me].lin_vel[k] = 0.0f; bodies[me].ang_vel[k] = 0.0f; bodies[me].stab[k] = 0.0f; }
+    bodies[me].flags &= ~SLHIP_BODY_FROZEN;
     /* a teleport invalidates every resting state */
     for (int o = 0; o < nb; ++o) {
         bodies[o].flags &= ~SLHIP_BODY_ASLEEP;

@@ -39,7 +39,7 @@ RENDER_SSAO = 0x100
 RENDER_SHADOWS = 0x200
 RENDER_SHADOW_RESET = 0x400
 RENDER_KEEP_HDR = 0x800
-ABI_VERSION = 4
+ABI_VERSION = 5
 DEFAULT_HULL_PAIRS, DEFAULT_CONTACTS = 2048, 1024   # SLHIP_DEFAULT_HULL_PAIRS / SLHIP_DEFAULT_CONTACTS of include/slhip.h
 COMM_ID_BYTES = 128
 

@@ -17,8 +17,9 @@ BODY_DTYPE = np.dtype([
     ("max_lin_vel", np.float32), ("separation", np.float32), ("wake_counter", np.float32), ("flags", np.uint32),
     ("hull_begin", np.uint32), ("hull_end", np.uint32), ("stuck_counter", np.int32), ("drive_flags", np.uint32),
     ("drive_target", np.float32, (4,)), ("drive_frame", np.float32, (4,)), ("drive_params", np.float32, (4,)),
+    ("stab", np.float32, (4,)),
 ])
-assert BODY_DTYPE.itemsize == 288
+assert BODY_DTYPE.itemsize == 304
 
 HULL_DTYPE = np.dtype([("vtx_begin", np.uint32), ("vtx_count", np.uint32), ("_pad", np.uint32, (2,)),
                        ("sphere", np.float32, (4,)), ("aabb_center", np.float32, (4,)), ("aabb_half", np.float32, (4,))])
@@ -37,8 +38,9 @@ PARAMS_DTYPE = np.dtype([
     ("max_bodies_per_scene", np.uint32), ("max_hull_verts_per_scene", np.uint32), ("max_hulls_per_scene", np.uint32),
     ("max_hull_pairs_per_scene", np.uint32), ("max_contacts_per_scene", np.uint32),
     ("pair_contact_budget", np.uint32), ("resume", np.uint32), ("max_body_pairs_per_scene", np.uint32),
+    ("stabilization_threshold", np.float32), ("_pad_params", np.uint32),
 ])
-assert PARAMS_DTYPE.itemsize == 120
+assert PARAMS_DTYPE.itemsize == 128
 
 # slhip_settle_params.pair_contact_budget.  0: every point goes to the solver, as in PhysX -- the default of every entry point, sl.SceneBatch
 # and the benchmark included (round 5; rounds 3 and 4 ran the batch path at 32).  > 0: a body pair touching through more hull pairs keeps the
@@ -49,6 +51,7 @@ PAIR_CONTACT_BUDGET_FAST = 32
 
 BODY_STATIC = 1
 BODY_ASLEEP = 2
+BODY_FROZEN = 4
 MAX_BODIES = 400
 
 
@@ -65,6 +68,7 @@ def default_params(tabletop=True, dt=None, frames=None, substeps=None, pair_cont
     p["bounce_threshold"] = 0.2 * 10.0
     p["sleep_threshold"] = 5e-5 * 10.0 * 10.0
     p["wake_time"] = 0.4
+    p["stabilization_threshold"] = 1e-5 * 10.0 * 10.0   # PxSceneFlag::eENABLE_STABILIZATION (scene.cpp:163) with PhysX's default threshold [ext]
     p["angular_damping"] = 0.05
     p["max_angular_velocity"] = 100.0
     p["plane_mu_s"], p["plane_mu_d"], p["plane_restitution"] = 0.5, 0.5, 0.0  # scene.cpp:645

@@ -20,9 +20,9 @@
 
 namespace {
 
-static_assert(sizeof(slhip_body) == 288, "slhip_body layout");
+static_assert(sizeof(slhip_body) == 304, "slhip_body layout");
 static_assert(sizeof(slhip_hull) == 64, "slhip_hull layout");
-static_assert(sizeof(slhip_settle_params) == 120, "slhip_settle_params layout");
+static_assert(sizeof(slhip_settle_params) == 128, "slhip_settle_params layout");
 
 constexpr int kMaxContactsPerHP = 4;
 constexpr float kInf = 3.0e38f;
@@ -1272,16 +1272,22 @@ __device__ void update_world_inertia(const slhip_body& b, WBody& w)
 // mass-normalised kinetic energy of the sleep test (oracle step_scene (k)): 0.5 (v.v + w.(I w) / m), I = inverse of inv_inertia
 // in object axes by cofactors
 // (L: the 3x3 of the body record's inv_inertia rows, L[3 r + c] = inv_inertia[4 r + c])
-__device__ __forceinline__ float kinetic_energy(const float (&L)[9], const WBody& w)
+__device__ __forceinline__ float kinetic_energy(const float (&L)[9], const m3& R, v3 v, v3 w, float inv_mass)
 {
-    const v3 wl = m3_tmul(w.R, w.w);
+    const v3 wl = m3_tmul(R, w);
     const float c00 = L[4] * L[8] - L[5] * L[7], c01 = L[5] * L[6] - L[3] * L[8], c02 = L[3] * L[7] - L[4] * L[6];
     const float c11 = L[0] * L[8] - L[2] * L[6], c12 = L[1] * L[6] - L[0] * L[7], c22 = L[0] * L[4] - L[1] * L[3];
     const float det = fmaf(L[2], c02, fmaf(L[1], c01, L[0] * c00));
     const v3 iw = V(fmaf(c02, wl.z, fmaf(c01, wl.y, c00 * wl.x)), fmaf(c12, wl.z, fmaf(c11, wl.y, c01 * wl.x)),
                     fmaf(c22, wl.z, fmaf(c12, wl.y, c02 * wl.x)));
-    const float ang = det != 0.0f ? dot(wl, iw) / det * w.inv_mass : 0.0f;
-    return 0.5f * (dot(w.v, w.v) + ang);
+    const float ang = det != 0.0f ? dot(wl, iw) / det * inv_mass : 0.0f;
+    return 0.5f * (dot(v, v) + ang);
+}
+
+__device__ void store_velocities(slhip_body& b, const WBody& w)
+{
+    b.lin_vel[0] = w.v.x; b.lin_vel[1] = w.v.y; b.lin_vel[2] = w.v.z;
+    b.ang_vel[0] = w.w.x; b.ang_vel[1] = w.w.y; b.ang_vel[2] = w.w.z;
 }
 
 __device__ void store_body(slhip_body& b, const WBody& w)
@@ -1310,7 +1316,8 @@ __device__ void redrop(slhip_body* bodies, int nb, int me, const slhip_settle_pa
     const float off_z = fmaf(P[10], c[2], fmaf(P[9], c[1], P[8] * c[0])) - c[3];
     P[3] = 0.0f; P[7] = 0.0f; P[11] = max_z - off_z;
     bodies[me].stuck_counter = 0;
-    for (int k = 0; k < 4; ++k) { bodies[me].lin_vel[k] = 0.0f; bodies[me].ang_vel[k] = 0.0f; }
+    for (int k = 0; k < 4; ++k) { bodies[me].lin_vel[k] = 0.0f; bodies[me].ang_vel[k] = 0.0f; bodies[me].stab[k] = 0.0f; }
+    bodies[me].flags &= ~SLHIP_BODY_FROZEN;
     for (int o = 0; o < nb; ++o) {
         bodies[o].flags &= ~SLHIP_BODY_ASLEEP;
         bodies[o].wake_counter = prm.wake_time;

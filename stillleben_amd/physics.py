@@ -225,7 +225,7 @@ def smoke_check(sl, checker):
     hulls, verts = se.pool.arrays()
     ref = bodies.copy()
     checker.settle(srec, ref, hulls, verts, SB.sizing_hints(prm, srec, bodies, hulls))
-    for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "stuck_counter"):
+    for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "stuck_counter", "stab"):
         a, b = np.ascontiguousarray(gpu[name]), np.ascontiguousarray(ref[name])
         if not np.array_equal(a.view(np.uint8), b.view(np.uint8)):
             raise AssertionError("settle smoke: body field '%s' differs from the oracle" % name)

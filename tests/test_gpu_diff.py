@@ -283,3 +283,56 @@ def test_pose_hypothesis_batch_equals_the_loop(sl):
         ref = sl.diff.backpropagate_gradient_to_poses(scene, rp.render(scene), g)
         scale = max(1e-9, float(ref.abs().max()))
         assert float((got2[k] - ref).abs().max()) <= 1e-4 * scale
+
+
+def test_c5_at_its_real_shape_64_objects_32_hypotheses(sl):
+    """BASELINE config C5 as BASELINE.json states it: 64 objects x 32 pose hypotheses, 640x480, ONE
+    slhip_diff_pose_backward_batch behind sl.diff.backpropagate_gradient_to_poses_batch.  Held against (1) the per-hypothesis
+    path (set_pose + render + backpropagate_gradient_to_poses) on four sampled hypotheses, (2) additivity / linearity in the image
+    gradient on ALL 32 x 64 pose gradients, (3) a repeated hypothesis gives the same row."""
+    cube = sl.Mesh(S.CUBE, physics=False)
+    cube.center_bbox()
+    cube.scale_to_bbox_diagonal(0.12)
+    scene = sl.Scene((640, 480))
+    scene.set_camera_intrinsics(1066.778, 1067.487, 312.9869, 241.3109)
+    rng = np.random.default_rng(55)
+    for i in range(64):
+        o = sl.Object(cube)
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, :3] = S.random_rotation(rng)
+        pose[:3, 3] = [((i % 8) - 3.5) * 0.11, ((i // 8) - 3.5) * 0.085, 1.6 + 0.3 * rng.uniform()]
+        o.set_pose(torch.from_numpy(pose))
+        scene.add_object(o)
+    scene.light_directions = torch.tensor([[0.1, 0.2, 0.9]])
+    scene.manual_exposure = 1.0
+    base = [o.pose() for o in scene.objects]
+    K = 32
+    hyps = torch.stack([torch.stack([sl.diff.apply_pose_delta(b, torch.from_numpy(rng.normal(0, 0.01, 6).astype(np.float32))) for b in base])
+                        for _ in range(K)])
+    hyps[K - 1] = hyps[3]                                               # (3)
+    g1 = torch.from_numpy(pattern_grad(480, 640))
+    g2 = torch.from_numpy(np.random.default_rng(1).standard_normal((3, 480, 640)).astype(np.float32))
+    d1, buf = sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps, g1, return_results=True)
+    assert tuple(d1.shape) == (K, 64, 6) and torch.isfinite(d1).all()
+    assert tuple(buf.instance.shape[:3]) == (K, 480, 640)
+    seen = [len(torch.unique(buf.instance[k])) for k in range(K)]
+    assert min(seen) >= 60                                             # every hypothesis shows (nearly) all 64 objects
+    assert float(d1.abs().amax(dim=(1, 2)).min()) > 0                  # ... and has a gradient
+    assert torch.equal(d1[K - 1], d1[3]) and not torch.equal(d1[0], d1[1])
+    # (1) the per-hypothesis path
+    rp = sl.RenderPass()
+    for k in (0, 11, 22, 31):
+        for o, p in zip(scene.objects, hyps[k]):
+            o.set_pose(p)
+        res = rp.render(scene)
+        assert torch.equal(res.instance_index().squeeze(-1).cpu(), buf.instance[k].squeeze(-1).cpu())
+        ref = sl.diff.backpropagate_gradient_to_poses(scene, res, g1)
+        scale = max(1e-9, float(ref.abs().max()))
+        assert float((d1[k] - ref).abs().max()) <= 1e-4 * scale
+    for o, p in zip(scene.objects, base):
+        o.set_pose(p)
+    # (2) linear and additive on all of them
+    d2 = sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps, g2)
+    d12 = sl.diff.backpropagate_gradient_to_poses_batch(scene, hyps, 2.0 * g1 - 0.5 * g2)
+    scale = max(float(d1.abs().max()), float(d2.abs().max()))
+    assert float((d12 - (2.0 * d1 - 0.5 * d2)).abs().max()) <= 2e-5 * scale

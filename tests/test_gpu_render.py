@@ -316,3 +316,52 @@ def test_watertight_sheet_on_the_gpu(sl, oracle, eng):
     for n_points, seed, tilt in ((600, 1, 0.0), (15000, 2, 0.0), (90000, 3, 0.0), (60000, 5, 50.0)):
         check_watertight(render, sl, n_points, seed, tilt)
 
+
+
+def test_reference_format_scene_file_renders_like_the_oracle(sl, oracle, eng):
+    """SURVEY 8f row f3 through the device (Scene::deserialize src/scene.cpp:802-869, Object::deserialize object.cpp:415-452,
+    Mesh::deserialize mesh.cpp:1104-1115): the hand-written reference-format document tests/golden/reference_format_scene.ini --
+    a scene "settled by the reference" -- is deserialised, rendered through slhip_render and every output compared with the oracle on
+    the records of the same scene; then serialised, read back into a fresh scene and rendered again: the same bits."""
+    import os
+
+    from conftest import GOLDEN
+
+    text = open(os.path.join(GOLDEN, "reference_format_scene.ini")).read().replace("@CUBE@", S.CUBE)
+    scene = sl.Scene((64, 48))
+    scene.deserialize(text)
+    assert scene.viewport == (320, 240) and len(scene.objects) == 2
+    bufs, ref = both(eng, oracle, [scene])
+    assert_geometry_equal(bufs, ref)
+    assert_rgb_close(bufs, ref)
+    inst = bufs.instance.cpu().numpy()[0, :, :, 0]
+    cls = bufs.cls.cpu().numpy()[0, :, :, 0]
+    assert {1, 2} <= set(np.unique(inst).tolist())                       # both objects of the file are in the picture ...
+    assert set(np.unique(cls[inst > 0]).tolist()) == {4}                 # ... with the mesh group's classIndex
+    rgb = bufs.rgb.cpu().numpy()
+    assert rgb[0, :, :, :3].max() > 0                                    # lit by the file's one light
+    # write -> read -> render: the document we write carries everything the picture depends on.  Floats are written with six
+    # significant digits (Corrade's ConfigurationValue<float> [ext]), so the first write rounds the poses the file's decimal
+    # literals gave; from then on write -> read is the identity: the same text, the same bits in every output
+    again = sl.Scene((64, 48))
+    again.deserialize(scene.serialize())
+    third = sl.Scene((64, 48))
+    third.deserialize(again.serialize())
+    assert third.serialize() == again.serialize()                       # (the camera's matrix -> quaternion -> text has settled)
+    fourth = sl.Scene((64, 48))
+    fourth.deserialize(third.serialize())
+    bufs2, ref2 = both(eng, oracle, [again])
+    assert_geometry_equal(bufs2, ref2)
+    assert_rgb_close(bufs2, ref2)
+    bufs3 = eng.render([third], _abi.OUT_ALL, ssao=True, shadows=True)
+    bufs4 = eng.render([fourth], _abi.OUT_ALL, ssao=True, shadows=True)
+    torch.cuda.synchronize()
+    for name in ("instance", "cls", "vertex_idx", "coord", "bary", "cam_coord", "normals", "rgb"):
+        a, b = getattr(bufs3, name).cpu().numpy(), getattr(bufs4, name).cpu().numpy()
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
+    assert (bufs3.instance.cpu().numpy() != bufs2.instance.cpu().numpy()).mean() < 1e-3
+    inst2 = bufs2.instance.cpu().numpy()[0, :, :, 0]
+    assert (inst2 != inst).mean() < 1e-3                                 # the rounding moves a silhouette pixel at most
+    # and through the public API, as a user of the reference would (py_scene.cpp: Scene.deserialize; py_render_pass.cpp: render)
+    res = sl.RenderPass().render(again)
+    assert np.array_equal(res.instance_index().cpu().numpy()[:, :, 0], inst2)

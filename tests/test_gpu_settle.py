@@ -57,7 +57,7 @@ def run_both(oracle, scenes_, plane=True, **kw):
 
 
 def assert_bodies_equal(gpu, ref):
-    for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "stuck_counter", "wake_counter"):
+    for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "stuck_counter", "wake_counter", "stab"):
         a, b = np.ascontiguousarray(gpu[name]), np.ascontiguousarray(ref[name])
         if not np.array_equal(a.view(np.uint8), b.view(np.uint8)):
             bad = np.argwhere(a != b)
@@ -334,10 +334,17 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
         (K.build(sl, [K.at(-h - 0.0005, 0, K.TABLE + h + 0.0015), K.at(h + 0.0005, 0, K.TABLE + h + 0.0015), K.at(0, 0, K.TABLE + 3 * h + 0.0045)]), dict(frames=150)),   # the pile of three
         (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015), _yawed(K.at(0, 0, K.TABLE + 3 * h + 0.0045), math.pi / 4)]), dict(frames=60)),   # face manifold = corners of an octagon
         (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(8)]), dict(frames=120)),   # the column of eight while it stands
+        # the stabilisation (scene.cpp:163): a cube kept awake is lightened, damped and, after 1.5 s, frozen; a pile of two beside a falling cube
+        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015)]), dict(frames=300, sleep_threshold=0.0, frozen=True)),
+        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015), K.at(0, 0, K.TABLE + 3 * h + 0.0045), K.at(1.0, 0, 3.0)]), dict(frames=30, sleep_threshold=0.0)),
+        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(4)]), dict(frames=200, stabilization_threshold=0.0)),   # ... and switched off
     ]
     for (srec, bodies, hulls, verts), kw in cases:
         prm = SB.default_params(tabletop=False, dt=kw.get("dt", 0.01), frames=kw["frames"], substeps=1)
         prm["gravity"] = kw.get("gravity", (0.0, 0.0, -K.G))
+        for key in ("sleep_threshold", "stabilization_threshold"):
+            if key in kw:
+                prm[key] = kw[key]
         # the KAT builder used its own hull pool: rebuild the batch on the engine's pool (same hulls, other indices)
         gb = bodies.copy()
         cube = K.cube_mesh(sl)
@@ -346,9 +353,11 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
         gpu = se.run(srec, gb, prm)
         ref = bodies.copy()
         oracle.settle(srec, ref, hulls, verts, prm)
-        for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "wake_counter"):
+        for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "wake_counter", "stab"):
             a, b = np.ascontiguousarray(gpu[name]), np.ascontiguousarray(ref[name])
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
+        if kw.get("frozen"):
+            assert int(gpu[0]["flags"]) & SB.BODY_FROZEN
     # the 3 : 1 box on an incline, just beyond its toppling threshold (tan = 0.37 > 1/3): it goes over on the device as well
     a_ = 0.02
     th = math.atan(0.37)

@@ -26,7 +26,7 @@ def test_abi_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_abi.lib_path())
     for n in sorted(names):
         assert hasattr(L, n), "libslhip.so does not export %s" % n
-    assert _abi.lib().slhip_abi_version() == _abi.ABI_VERSION == 4
+    assert _abi.lib().slhip_abi_version() == _abi.ABI_VERSION == 5
     assert _abi.lib().slhip_last_error() is not None
 
 
@@ -480,6 +480,6 @@ def test_kernel_source_fingerprint_counts_code_only(tmp_path, monkeypatch):
     text = f.read_text()
     f.write_text(text.replace("/*", "/* reworded:", 1) + "\n// a trailing remark\n")
     assert bench.kernel_source_sha() == a
-    assert "#define SLHIP_ABI_VERSION 4" in text
-    f.write_text(text.replace("#define SLHIP_ABI_VERSION 4", "#define SLHIP_ABI_VERSION 5", 1))
+    assert "#define SLHIP_ABI_VERSION 5" in text
+    f.write_text(text.replace("#define SLHIP_ABI_VERSION 5", "#define SLHIP_ABI_VERSION 6", 1))
     assert bench.kernel_source_sha() != a

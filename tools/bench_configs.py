@@ -96,39 +96,63 @@ def c3():
                    "frac": alg / (ms * 1e-3) / 1e9 / PEAK, "note": "render incl. per-call host batch assembly (engine.render)"})
 
 
-def c4():
+def c4(B=1):
+    """Bunny x 50 (3.47 M triangles per scene), 640x480, all 8 outputs, render only.  B > 1: B such scenes (their own random
+    rotations) in ONE launch sequence -- the form in which the configuration stresses bandwidth and not launch latency."""
+    import ctypes as C
+
     m = sl.Mesh(S.BUNNY, physics=False)
     m.center_bbox()
     m.scale_to_bbox_diagonal(0.5)
-    scene = sl.Scene((640, 480))
     rng = np.random.default_rng(4)
-    for i in range(50):
-        o = sl.Object(m)
-        pose = np.eye(4, dtype=np.float32)
-        pose[:3, :3] = S.random_rotation(rng)
-        z = 1.0 + 2.0 * (i / 49.0)
-        pose[:3, 3] = [((i % 10) - 4.5) * 0.11 * z, ((i // 10) - 2.0) * 0.16 * z, z]
-        o.set_pose(torch.from_numpy(pose))
-        scene.add_object(o)
-    scene.light_directions = torch.tensor([[0.2, 0.5, 0.8]])
+    scs = []
+    for b in range(B):
+        scene = sl.Scene((640, 480))
+        for i in range(50):
+            o = sl.Object(m)
+            pose = np.eye(4, dtype=np.float32)
+            pose[:3, :3] = S.random_rotation(rng)
+            z = 1.0 + 2.0 * (i / 49.0)
+            pose[:3, 3] = [((i % 10) - 4.5) * 0.11 * z, ((i // 10) - 2.0) * 0.16 * z, z]
+            o.set_pose(torch.from_numpy(pose))
+            scene.add_object(o)
+        scene.light_directions = torch.tensor([[0.2, 0.5, 0.8]])
+        scs.append(scene)
     eng = engine()
     from stillleben_amd._batch import build_batch
 
-    srec, drec, crec = build_batch([scene], eng.pool, None, with_shadows=False)
+    srec, drec, crec = build_batch(scs, eng.pool, None, with_shadows=False)
     eng.L.slhip_timing_enable(0)
     buf = [None]
 
     def render():
         buf[0] = eng.render_records(srec, drec, crec, 640, 480, _abi.OUT_ALL, ssao=False, shadows=False, buffers=buf[0])
 
-    ms = timed(render, reps=10)
+    reps = 10 if B == 1 else 5
+    ms = timed(render, reps=reps)
+    # the visibility raster's share: the library's own HIP events around each phase of one more sequence
+    eng.L.slhip_timing_enable(1)
+    render()
+    torch.cuda.synchronize()
+    ph = (C.c_float * 8)()
+    eng.L.slhip_render_timings(C.byref(ph))
+    eng.L.slhip_timing_enable(0)
+    names = ["shadow_raster", "shadow_large", "vis_raster", "vis_large", "shade", "ssao", "ssao_apply", "tonemap"]
+    phases = {n: float(ph[i]) for i, n in enumerate(names)}
     tris = int(drec["n_tris"].sum())
     verts = int(drec["n_verts"].sum())
-    alg = verts * 68 + tris * 12 + 307200 * 88
-    return emit("C4 bunny x50 raster stress", triangles=tris, vertices=verts, render_ms=ms, mtris_per_s=tris / (ms * 1e-3) / 1e6,
+    alg = verts * 68 + tris * 12 + B * 307200 * 88
+    raster_ms = phases["vis_raster"] + phases["vis_large"]
+    alg_raster = verts * 16 + tris * 12 + B * 307200 * 8          # positions + indices in, one 64-bit key per pixel out
+    return emit("C4 bunny x50 raster stress" + (" (batch of %d scenes per launch sequence)" % B if B > 1 else ""), batch=B,
+         triangles=tris, vertices=verts, render_ms=ms, render_ms_per_scene=ms / B, mtris_per_s=tris / (ms * 1e-3) / 1e6,
+         phases_ms=phases, raster_share=raster_ms / max(1e-9, sum(phases.values())),
+         raster={"ms": raster_ms, "mtris_per_s": tris / max(1e-9, raster_ms * 1e-3) / 1e6, "algorithmic_bytes": alg_raster,
+                 "achieved_GBps": alg_raster / max(1e-9, raster_ms * 1e-3) / 1e9, "frac": alg_raster / max(1e-9, raster_ms * 1e-3) / 1e9 / PEAK},
          roofline={"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK, "unit": "GB/s",
                    "frac": alg / (ms * 1e-3) / 1e9 / PEAK,
-                   "note": "one scene per launch sequence: 3.5 M triangles cannot fill 256 CUs for long, fixed launch latencies dominate"})
+                   "note": ("one scene per launch sequence: 3.5 M triangles cannot fill 256 CUs for long, fixed launch latencies dominate"
+                            if B == 1 else "%d scenes per launch sequence; SURVEY 8d byte model: 68 B per vertex + 12 B per triangle + 88 B per pixel" % B)})
 
 
 def c5():
@@ -196,4 +220,4 @@ if __name__ == "__main__":
     sl.init_cuda(0)
     which = sys.argv[1:] or ["c1", "c1big", "c3", "c4", "c5"]
     for w in which:
-        {"c1": c1, "c1big": lambda: c1(4096), "c3": c3, "c4": c4, "c5": c5}[w]()
+        {"c1": c1, "c1big": lambda: c1(4096), "c3": c3, "c4": c4, "c4x64": lambda: c4(64), "c5": c5}[w]()
