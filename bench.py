@@ -212,6 +212,12 @@ class Pipeline:
         torch.cuda.synchronize()
 
 
+def _abi_lib():
+    from stillleben_amd import _abi
+
+    return _abi.lib()
+
+
 def _header_define(name):
     """Value of an integer #define of include/slhip.h (the caps the bench line quotes are the library's, not a copy)."""
     import re
@@ -220,12 +226,37 @@ def _header_define(name):
     return int(m.group(1)) if m else None
 
 
+def host_cpu_facts():
+    """What the host lets this process run on: os.cpu_count() is the machine, the affinity mask and the cgroup CPU quota
+    (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us) are the process -- usable_cpus is the smaller of the two."""
+    import math
+
+    out = {"os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_quota_cpus": None}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            out["cgroup_quota_cpus"] = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                out["cgroup_quota_cpus"] = q / per
+        except (OSError, ValueError):
+            pass
+    usable = out["affinity"]
+    if out["cgroup_quota_cpus"]:
+        usable = min(usable, max(1, int(math.floor(out["cgroup_quota_cpus"] + 1e-9))))
+    out["usable_cpus"] = max(1, usable)
+    return out
+
+
 def cpu_baseline(table_meshes, scenes_per_thread, ssao, pair_contact_budget=0):
     """The oracle (scalar C restatement) timed on the host cores on a bounded sample of the same workload: every
     thread takes `scenes_per_thread` scenes through {tabletop set-up + 400-step settle + camera / light placement +
-    640x480 render}.  Scenes are independent, so the threads mirror the reference's JobQueue workers: the stated figure runs
-    hardware_concurrency() / 2 of them (job_queue.cpp:35-40); one thread and all hardware threads are printed beside it
-    (SURVEY.md 8d).  The C calls release the GIL and share no state."""
+    640x480 render}.  Scenes are independent, so the threads mirror the reference's JobQueue workers; the stated figure runs as
+    many of them as the host lets this process use at once (host_cpu_facts: affinity mask and cgroup quota, not os.cpu_count()),
+    one thread is printed beside it.  The C calls release the GIL and share no state."""
     from concurrent.futures import ThreadPoolExecutor
 
     import oracle
@@ -234,7 +265,8 @@ def cpu_baseline(table_meshes, scenes_per_thread, ssao, pair_contact_budget=0):
     from stillleben_amd import _settle_batch as SB
     from stillleben_amd._batch import HostPool
 
-    ncpu = os.cpu_count() or 1
+    host = host_cpu_facts()
+    ncpu = host["usable_cpus"]
     flags = _abi.OUT_GT6 | _abi.RENDER_SHADOWS | (_abi.RENDER_SSAO if ssao else 0) | _abi.OUT_CAM_COORD
     pool, hulls = HostPool(), SB.HullPool()
     table = sl.AssetTable(table_meshes, mesh_pool=pool, hull_pool=hulls)   # host records only (untimed set-up, as on the GPU)
@@ -287,23 +319,41 @@ def cpu_baseline(table_meshes, scenes_per_thread, ssao, pair_contact_budget=0):
         return {"threads": threads, "scenes": n, "wall_s": wall, "scenes_per_s": n / wall,
                 "settle_s_per_scene": sum(t[0] for t in times) / n, "render_s_per_scene": sum(t[1] for t in times) / n}
 
-    half = max(1, ncpu // 2)
-    one, jq = leg(1), leg(half)
-    full = leg(ncpu) if ncpu > half else jq
+    # The figure beside the GPU line: as many threads as the host lets this process RUN -- the smaller of the affinity mask and the
+    # cgroup's CPU quota (os.cpu_count() reports the machine: on the pool's boxes 256 hardware threads behind a quota of 16 CPUs;
+    # round 5 ran 128 threads on those 16 and called them cores).  Beside it one thread, and the reference JobQueue's own count --
+    # hardware_concurrency() / 2 workers (job_queue.cpp:35-40), which a quota does not lower -- when that is a different number.
+    one, full = leg(1), leg(ncpu)
+    jq_threads = max(1, (host["os_cpu_count"] or 1) // 2)
+    jq = leg(jq_threads) if jq_threads != ncpu and jq_threads <= 8 * ncpu else None
     cpu_model = "?"
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "?")
     except OSError:
         pass
+    notes = []
+    for name, lg in (("usable-CPU", full), ("JobQueue-count", jq)):
+        if lg is None:
+            continue
+        slow = (lg["settle_s_per_scene"] + lg["render_s_per_scene"]) / max(1e-9, one["settle_s_per_scene"] + one["render_s_per_scene"])
+        lg["per_scene_time_vs_one_thread"] = slow
+        if slow > 2.0:
+            notes.append("%s leg: a scene takes %.1f x the single-thread time on %d threads -- %s"
+                         % (name, slow, lg["threads"],
+                            "more threads than usable CPUs (%d): they take turns" % ncpu if lg["threads"] > ncpu else
+                            "the threads share memory bandwidth and last-level cache (the oracle's render walks 2048^2 shadow maps per scene)"))
     return {
-        "value": jq["scenes_per_s"], "unit": "scenes/s", "cores": half, "kind": "port",
-        "sample": "%d scenes on %d threads = hardware threads / 2, the reference JobQueue's worker count (job_queue.cpp:35-40; host: %d x %s), "
-                  "%.1f s wall; beside it: 1 thread %.2f scenes/s (set-up + settle %.3f s, placement + render %.3f s per scene), all %d "
-                  "threads %.1f scenes/s (oracle/, same C2 workload and seeds scheme)"
-                  % (jq["scenes"], half, ncpu, cpu_model, jq["wall_s"], one["scenes_per_s"], one["settle_s_per_scene"],
-                     one["render_s_per_scene"], full["threads"], full["scenes_per_s"]),
-        "single_thread": one, "job_queue_threads": jq, "all_threads": full,
+        "value": full["scenes_per_s"], "unit": "scenes/s", "cores": ncpu, "kind": "port",
+        "sample": "%d scenes on %d threads = the CPUs this process may use (host: %s; os.cpu_count %s, affinity %d, cgroup quota %s), %.1f s "
+                  "wall; beside it: 1 thread %.2f scenes/s (set-up + settle %.3f s, placement + render %.3f s per scene)%s (oracle/, same C2 "
+                  "workload and seeds scheme)"
+                  % (full["scenes"], ncpu, cpu_model, host["os_cpu_count"], host["affinity"],
+                     ("%.1f CPUs" % host["cgroup_quota_cpus"]) if host["cgroup_quota_cpus"] else "none", full["wall_s"], one["scenes_per_s"],
+                     one["settle_s_per_scene"], one["render_s_per_scene"],
+                     (", %d threads (the reference JobQueue's hardware_concurrency / 2) %.1f scenes/s" % (jq["threads"], jq["scenes_per_s"])) if jq else ""),
+        "host": host, "notes": notes,
+        "single_thread": one, "usable_cpu_threads": full, "job_queue_threads": jq,
     }
 
 
@@ -559,7 +609,7 @@ def main():
             "contacts_per_scene_step": cp["contact_sum"] / scene_steps,
             "pair_contact_budget": int(b_last.settle_params["pair_contact_budget"]),
             "reduced_steps": cp["reduced_steps"], "reduced_step_rate": cp["reduced_steps"] / scene_steps,
-            "solver_wave_lds_bytes": 32768,
+            "solver_wave_lds_bytes": int(_abi_lib().slhip_settle_solver_wave_lds()),
             "contact_capacity": int(b_last.settle_params["max_contacts_per_scene"]) or _header_define("SLHIP_DEFAULT_CONTACTS"),
             "hull_pair_capacity": int(b_last.settle_params["max_hull_pairs_per_scene"]) or _header_define("SLHIP_DEFAULT_HULL_PAIRS"),
             "note": "one settle of the step's scenes after the timed region (slhip_settle_caps): the solver takes every contact a step "
@@ -622,7 +672,14 @@ def main():
         dist.destroy_process_group()
     if out is not None:      # rank 0's line is the LAST thing on stdout (library banners come earlier)
         sys.stderr.flush()
+        if out.get("settle_errors"):
+            # a settle that refused scenes or dropped contacts / pairs did less (and other) work than the metric names: the line stays
+            # for diagnosis, marked invalid, and the run fails
+            out["valid"] = False
+            out["invalid_value"], out["value"] = out["value"], None
         print(json.dumps(out), flush=True)
+        if out.get("settle_errors"):
+            sys.exit("bench.py: the timed steps' settles reported errors (settle_errors): the line is INVALID")
 
 
 def kernel_source_sha():
@@ -699,9 +756,11 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
             # a model that exceeds what the counters saw move is not a roofline (positions served by the L2 are not HBM traffic):
             # the kernel is priced on min(model, counter bytes)
             priced = bts * args.render_chunk if traffic is None else min(bts * args.render_chunk, traffic)
-            per_kernel[k] = {"algorithmic_bytes_per_launch": priced, "model_bytes_per_launch": bts * args.render_chunk,
+            # names as in the contract: `algorithmic` = the byte model, `traffic` = what the counters saw; `priced` = the smaller
+            per_kernel[k] = {"algorithmic_bytes_per_launch": bts * args.render_chunk, "traffic": traffic,
+                             "priced_bytes_per_launch": priced, "priced_on": "traffic" if priced != bts * args.render_chunk else "algorithmic",
                              "ms_per_launch": ms, "achieved_GBps": priced / (ms * 1e-3) / 1e9,
-                             "frac": priced / (ms * 1e-3) / 8e12, "traffic": traffic}
+                             "frac": priced / (ms * 1e-3) / 8e12}
     ms_seq = t_render_iso / n_chunks
     roof_render = {
         "bound": "hbm", "kernel": "slhip_render launch sequence (%d scenes: vertex transform, shadow pass, visibility, shade, SSAO, tone map)" % args.render_chunk,
@@ -765,6 +824,14 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
                        "measured 2.3 cycles for streams of independent v_fma_f32 at 16 waves per CU (peak 1068.5: the fraction would read 15 % higher)",
         "counters_stale": stale, "counters_kernel_source_sha": cnt.get("kernel_source_sha"), "kernel_source_sha": kernel_source_sha(),
         "active_lanes": sq.get("active_lanes"),
+        # the issue rate rewards instructions, not work: beside it the share of the chip's fp32 LANE issue (x active lanes / 64) and
+        # SURVEY 8d's FLOP model of the sweeps (contacts x 8 sweeps x ~120 flop) against the dense fp32 vector peak
+        "lane_issue_frac": (issued / issue_peak * sq["active_lanes"] / 64.0) if issued and sq.get("active_lanes") else None,
+        "flop_model": {"flops_per_launch": contacts * 8 * 120 * args.batch if lockstep else None,
+                       "achieved_TFLOPs": (contacts * 8 * 120 * args.batch / (ms_launch * 1e-3) / 1e12) if lockstep and ms_launch > 0 else None,
+                       "peak_TFLOPs": 157.3,
+                       "frac": (contacts * 8 * 120 * args.batch / (ms_launch * 1e-3) / 1e12 / 157.3) if lockstep and ms_launch > 0 else None,
+                       "model": "SURVEY.md 8d: contacts per scene-step (counted by the kernels) x (4 + 4) sweeps x ~120 flop per row set"},
         "ms_per_launch_alone": settle_kernels[kname].get("avg_ms_per_launch_alone") if lockstep else None,
         "counters_source": cnt.get("source"),
         "settle_kernels_ms_per_launch": {k: v["avg_ms_per_launch"] for k, v in settle_kernels.items()} if lockstep else None,

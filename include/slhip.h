@@ -36,11 +36,11 @@ extern "C" {
 #define SLHIP_ABI_VERSION 5   /* 2: slhip_render_scratch.d_shadow_tiles, slhip_render_scratch_bytes fills 7 sizes
                                  3: slhip_render_scratch.d_vattr is REQUIRED (the post-transform vertex cache) and `_pad` became
                                     shadow_lights; d_clip holds 9 float4 planes per vertex; slhip_settle_params grew to 116 bytes
-                                 4: slhip_settle_params.max_body_pairs_per_scene (120 bytes); slhip_settle_caps fills ten counts
                                     (list capacities instead of caps, pair_contact_budget, resume: the contact state of a settle
                                     outlives the call); slhip_settle_caps fills counts[8]
+                                 4: slhip_settle_params.max_body_pairs_per_scene (120 bytes); slhip_settle_caps fills ten counts
                                  5: slhip_settle_params.stabilization_threshold (128 bytes); slhip_body.stab (304 bytes) carries the
-                                    stabilisation state of a body, SLHIP_BODY_FROZEN                                             */
+                                    stabilisation state of a body, SLHIP_BODY_FROZEN; slhip_settle_solver_wave_lds            */
 #define SLHIP_NUM_LIGHTS 3 /* reference include/stillleben/common.h:17 */
 
 /* ---------------------------------------------------------------------------------------------
@@ -452,6 +452,9 @@ int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5]);
  * ms_out[5 * i + kernel] and steps_out[i] (may be NULL) = the step's index within its settle call; *n_out = rows written.          */
 int slhip_settle_timing_every(uint32_t every);
 int slhip_settle_timings_by_step(float* ms_out, uint32_t* steps_out, uint32_t capacity, uint32_t* n_out);
+/* LDS bytes a solver wave (k_w_solve) of the last slhip_settle call was launched with: 20 KB, more when the batch's largest scene
+ * shape needs it, SLHIP_SOLVE_LDS_KB overrides (measurement read-out: bench.py states the configuration it measured).             */
+int slhip_settle_solver_wave_lds(void);
 /* scratch for n_scenes scenes: accumulators + the per-scene pair cache, sized from the hints in
  * `params` (NULL or zero hints: the worst case)                                                      */
 int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_params* params, uint64_t* bytes_out);

@@ -255,6 +255,8 @@ def lib():
     L.slhip_render_scratch_bytes.argtypes = [
         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64 * 7)
     ]
+    L.slhip_settle_solver_wave_lds.restype = C.c_int
+    L.slhip_settle_solver_wave_lds.argtypes = []
     L.slhip_timing_enable.argtypes = [C.c_int]
     L.slhip_render_timings.argtypes = [C.POINTER(C.c_float * 8)]
     L.slhip_diff_sobel_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

@@ -1498,14 +1498,18 @@ static int settle_timings_read(float avg_ms_out[5], uint32_t launches_out[5], fl
     uint32_t n[5] = {0, 0, 0, 0, 0};
     bool failed = false;
     uint32_t rows = 0;
+    bool row_open = false;             // the current step has a row of its own (false once `cap` rows are written: later steps are averaged only)
     for (auto& r : g_settle_timing.pending) {
         float ms = 0.0f;
         if (failed || hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { failed = true; continue; }
         acc[r.kernel] += ms;
         ++n[r.kernel];
         if (by_step_ms) {
-            if (r.kernel == 0 && rows < cap) { if (steps_out) steps_out[rows] = r.step; ++rows; }
-            if (rows > 0 && rows <= cap) by_step_ms[5 * (size_t)(rows - 1) + r.kernel] = ms;
+            if (r.kernel == 0) {
+                row_open = rows < cap;
+                if (row_open) { if (steps_out) steps_out[rows] = r.step; ++rows; }
+            }
+            if (row_open) by_step_ms[5 * (size_t)(rows - 1) + r.kernel] = ms;
         }
     }
     for (hipEvent_t e : g_settle_timing.events) (void)hipEventDestroy(e);   // on the error path as well
@@ -1527,6 +1531,9 @@ extern "C" int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5
 {
     return settle_timings_read(avg_ms_out, launches_out, nullptr, nullptr, 0, nullptr);
 }
+
+static int g_last_solve_lds = 0;   // LDS bytes per solver wave of the last lockstep slhip_settle call (measurement read-out)
+extern "C" int slhip_settle_solver_wave_lds(void) { return g_last_solve_lds; }
 
 extern "C" int slhip_settle_timing_every(uint32_t every)
 {
@@ -1604,6 +1611,7 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         int max_class = 2;
         if (const char* e = getenv("SLHIP_SOLVE_SPW")) { const int v = atoi(e); max_class = v == 1 ? 0 : v == 2 ? 1 : 2; }
         W.solve_lds = solve_lds; W.solve_max_class = max_class;
+        g_last_solve_lds = solve_lds;
         if (BL.total > 160 * 1024 || FL.total > 160 * 1024 || solve_lds > 160 * 1024) {
             slhip::set_error("slhip_settle: scenes of %d bodies / %d hulls do not fit the kernels' LDS", nb_cap, D.lh_cap);
             return -1;

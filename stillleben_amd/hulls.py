@@ -196,13 +196,37 @@ def _solid_volume(data):
     fwd = e[:, 0] * n + e[:, 1]
     bwd = e[:, 1] * n + e[:, 0]
     uf, cf = np.unique(fwd, return_counts=True)
+    signed = None
     if cf.max(initial=0) == 1 and np.array_equal(uf, np.unique(bwd)):
         a, b, c = p[t[:, 0]], p[t[:, 1]], p[t[:, 2]]
-        return abs(float(np.einsum("ij,ij->i", a, np.cross(b, c)).sum()) / 6.0)
+        signed = abs(float(np.einsum("ij,ij->i", a, np.cross(b, c)).sum()) / 6.0)
+        if _connected_components(t, n) == 1:
+            return signed
+        # several closed shells (a mug's body and its handle, an assembly): where they intersect the signed volumes count the
+        # overlap twice -- the voxel estimate below does not; the smaller of the two stands
     occ, _, h = acd.voxelize(data.positions, data.indices, resolution=100000)
     idx = np.argwhere(occ)
     shell = len(acd._boundary(idx, occ.shape))
-    return (float(len(idx)) - 0.5 * float(shell)) * h ** 3
+    vox = (float(len(idx)) - 0.5 * float(shell)) * h ** 3
+    return vox if signed is None else min(signed, vox)
+
+
+def _connected_components(tris, n_vertices):
+    """Number of connected components of a triangle mesh's vertex graph (vertices no triangle uses do not count)."""
+    parent = np.arange(n_vertices)
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    for a, b, c in tris:
+        ra, rb, rc = find(a), find(b), find(c)
+        r = min(ra, rb, rc)
+        parent[ra] = parent[rb] = parent[rc] = r
+    used = np.unique(tris)
+    return len({find(int(v)) for v in used})
 
 
 def _compute_hulls(data, force):

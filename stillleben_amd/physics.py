@@ -375,7 +375,11 @@ def step_scene(scene, plane, **prm_kw):
     nbod = len(bodies)
     prm["max_hull_pairs_per_scene"] = min(65535, max(64, all_pairs))
     prm["max_contacts_per_scene"] = min(65535, max(64, 4 * all_pairs + 4 * nbod))
-    prm["max_body_pairs_per_scene"] = max(1, nbod * (nbod - 1) // 2)
+    # ... the list of touching body pairs as well, as far as the kernels' LDS holds a scene's groups (~26 B each beside 152 B per body:
+    # every pair up to 96 bodies); beyond that a body of a pile has a handful of neighbours, not all the others: 12 per body (6 from
+    # 256 bodies on, sizing_hints' rule) -- a step that offers more is counted (caps: group drops) and raises below, never dropped silently
+    if int(prm["max_body_pairs_per_scene"]) == 0:
+        prm["max_body_pairs_per_scene"] = max(1, nbod * (nbod - 1) // 2) if nbod <= 96 else min(nbod * (nbod - 1) // 2, 12 * nbod + 64)
     sig = _signature(scene, srec, bodies, prm)
     st = scene._phys_state
     resume = st is not None and st.sig == sig and len(st.bodies) == len(bodies)
@@ -401,6 +405,7 @@ def step_scene(scene, plane, **prm_kw):
             if o._linear_velocity is r[1] and o._angular_velocity is r[2]:
                 bodies["wake_counter"][i] = keep["wake_counter"][i]
                 bodies["flags"][i] = keep["flags"][i]
+                bodies["stab"][i] = keep["stab"][i]        # (the stabilisation's timers, slhip_body.stab)
             # (a velocity set from outside wakes the body, like PxRigidBody::setLinearVelocity's autowake)
         prm["resume"] = st.steps
     else:

@@ -657,6 +657,36 @@ def test_column_stands_through_scene_simulate(sl, oracle):
     assert scene._phys_state.steps == 1
 
 
+def test_scene_simulate_with_150_bodies(sl):
+    """A long-lived scene of 150 bodies (round-5 advisor): Scene.simulate sizes the scene's own scratch -- every body pair would not
+    fit the kernels' LDS beyond ~100 bodies, so the list of touching body pairs is capped at 12 per body there -- and steps it; the
+    grid of cubes on a slab stays where it is, resumed calls continue the state."""
+    cube = scaled(sl, S.CUBE, 0.05)
+    slab = scaled(sl, S.CUBE, 3.0)
+    h = 0.05 / np.sqrt(3.0) / 2.0
+    H = 3.0 / np.sqrt(3.0) / 2.0
+    scene = sl.Scene((160, 120))
+    base = sl.Object(slab)
+    base.static = True
+    p = torch.eye(4)
+    p[2, 3] = -H
+    base.set_pose(p)
+    scene.add_object(base)
+    for k in range(150):
+        o = sl.Object(cube)
+        p = torch.eye(4)
+        p[0, 3], p[1, 3], p[2, 3] = (k % 15 - 7) * 0.04, (k // 15 - 5) * 0.04, h + 0.003
+        o.set_pose(p)
+        scene.add_object(o)
+    for _ in range(20):
+        scene.simulate(0.01)
+    st = scene._phys_state
+    assert st.steps == 20 and len(st.bodies) == 151
+    z = np.array([float(o.pose()[2, 3]) for o in scene.objects[1:]])
+    assert np.allclose(z, h + 0.003, atol=2e-3), (z.min(), z.max())
+    assert float(st.bodies["stab"][1:, 1].min()) > 0.0            # every cube rests on the static slab: lightened by the stabilisation
+
+
 def test_manipulation_steps_equal_one_call(sl, oracle):
     """50 ManipulationSim.step calls == one 50-frame slhip_settle (manipulation_sim.cpp:83-93 steps one PxScene), bit for bit --
     and a plain object sharing the manipulator's mesh does not inherit its spring drive (round-3 advisor)."""

@@ -139,3 +139,27 @@ def test_solid_volume_of_closed_and_open_meshes():
     slab = SimpleNamespace(positions=p2, indices=t2.reshape(-1))
     true = 8 * 0.1 * 0.1 * 0.004
     assert hulls._solid_volume(slab) == pytest.approx(true, rel=0.35)
+
+
+def test_solid_volume_of_intersecting_closed_shells_counts_the_overlap_once(sl):
+    """Round-5 advisor: two closed boxes that overlap by half (a mug's body and handle, CAD assemblies) pass the closed-surface test,
+    but their summed signed volumes count the overlap twice -- the union's volume is what the 75 % rule (mesh.cpp:426-429) needs."""
+    from stillleben_amd import _loaders, hulls
+
+    def box(lo, hi, off):
+        c = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], np.float32)
+        f = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4],
+                      [1, 5, 7], [1, 7, 3]], np.uint32)
+        return c, f + off
+
+    a, fa = box((0, 0, 0), (0.2, 0.1, 0.1), 0)
+    b, fb = box((0.1, 0, 0), (0.3, 0.1, 0.1), 8)
+    cm = _loaders.ConsolidatedMesh()
+    cm.positions = np.concatenate([a, b])
+    cm.indices = np.concatenate([fa, fb]).reshape(-1).astype(np.uint32)
+    one = _loaders.ConsolidatedMesh()
+    one.positions, one.indices = a, fa.reshape(-1).astype(np.uint32)
+    assert hulls._solid_volume(one) == pytest.approx(0.002, rel=1e-6)              # one closed shell: the divergence theorem, exactly
+    v = hulls._solid_volume(cm)
+    assert v < 0.004 * 0.9                                                         # not the doubly counted 0.004 ...
+    assert v == pytest.approx(0.003, rel=0.12)                                     # ... but the union, to the voxel grid's resolution
