@@ -139,8 +139,10 @@ typedef struct {
     int culled;           /* offered by its manifold but left out of the solver by pair_contact_budget (valid = 0) */
 } contact;
 
-#define MAX_CONTACTS_PER_HP 4
+#define MAX_CONTACTS_PER_HP 4   /* points of a manifold */
 #define PLANE_SLOTS 4
+#define PATCH_STRIDE 5          /* slots of a patch in the step's contact array: its points, then its centre row (patch_centre) */
+#define PATCH_ORDER(k) ((k) == 0 ? MAX_CONTACTS_PER_HP : (k) - 1)   /* ... in the order of the solver's list: the centre row first */
 
 /* Persistent contact manifold of one hull pair (PhysX keeps one per shape pair, PCM [ext]): the contact points in the two
    bodies' object frames, the normal in B's frame, and the impulses the solver ended the step with -- the next step refreshes
@@ -151,6 +153,7 @@ typedef struct {
     v3 nb;                 /* the contact normal the manifold was BUILT with, in B's object frame */
     v3 la[4], lb[4];       /* contact points in A's / B's object frame */
     float ln[4];           /* accumulated normal impulses at the end of the step */
+    float lc;              /* ... and that of the patch's centre row */
 } pmanifold;
 
 /* ... and of one body against the table: the contact points are hull vertices, matched by their number */
@@ -158,6 +161,7 @@ typedef struct {
     int stamp, count;
     int id[4];
     float ln[4];
+    float lc;
 } pplane;
 
 typedef struct {
@@ -172,7 +176,7 @@ typedef struct {
     int n_groups;
     int *g_begin, *g_end, *g_a, *g_b, *g_color;   /* [P + NB] */
     int n_colors;
-    contact* c;                          /* [(P + NB) * MAX_CONTACTS_PER_HP]: four slots per hull pair, then four per body (table) */
+    contact* c;                          /* [(P + NB) * PATCH_STRIDE]: five slots per hull pair (four points + the centre row), then five per body (table) */
     wbody* wb;                           /* [NB] */
     /* Pair cache (temporal coherence, like PhysX's cached separating axis): the last converged or
        separating simplex of every hull pair of the scene, [n_hulls][n_hulls] by scene-local hull
@@ -221,7 +225,7 @@ static scene_ws* ws_alloc(int P, int C, int NB, int BP)
     ws->hp_ha = (int*)malloc(sizeof(int) * P); ws->hp_hb = (int*)malloc(sizeof(int) * P);
     ws->g_begin = (int*)malloc(sizeof(int) * G); ws->g_end = (int*)malloc(sizeof(int) * G);
     ws->g_a = (int*)malloc(sizeof(int) * G); ws->g_b = (int*)malloc(sizeof(int) * G); ws->g_color = (int*)malloc(sizeof(int) * G);
-    ws->c = (contact*)malloc(sizeof(contact) * G * MAX_CONTACTS_PER_HP);
+    ws->c = (contact*)malloc(sizeof(contact) * G * PATCH_STRIDE);
     ws->wb = (wbody*)malloc(sizeof(wbody) * (NB ? NB : 1));
     ws->hp_pm = (pmanifold**)malloc(sizeof(pmanifold*) * P);
     ws->pp = (pplane*)calloc(NB ? NB : 1, sizeof(pplane));
@@ -899,7 +903,7 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
                                 const slhip_settle_params* prm, float margin, contact* out, gjk_seed* cached,
                                 pmanifold* pm, int step)
 {
-    for (int i = 0; i < MAX_CONTACTS_PER_HP; ++i) { out[i].valid = 0; out[i].culled = 0; }
+    for (int i = 0; i < PATCH_STRIDE; ++i) { out[i].valid = 0; out[i].culled = 0; out[i].ln = 0.0f; }
     const wbody* wa = &wbs[ia];
     const wbody* wb = &wbs[ib];
     shape A, B;
@@ -916,11 +920,11 @@ static float hull_pair_contacts(const slhip_body* bodies, const wbody* wbs, int 
     gjk_seed seed;
     pmanifold prev;
     memset(&prev, 0, sizeof(prev));
-    if (pm && pm->stamp == step - 1) prev = *pm;
+    if (pm && pm->stamp == step - 1) { prev = *pm; out[MAX_CONTACTS_PER_HP].ln = WARM_START * prev.lc; }
     /* what a pair keeps from step to step lives as long as the pair stays a broadphase candidate (PhysX destroys a pair's contact
        manager and cache when its bounds stop overlapping [ext]): a pair that was not listed in the previous step starts cold */
     if (pm && cached && pm->stamp != step - 1) { cached->n = 0; cached->idx[0] = cached->idx[1] = cached->idx[2] = 0; }
-    if (pm) { pm->stamp = step; pm->count = 0; }
+    if (pm) { pm->stamp = step; pm->count = 0; pm->lc = 0.0f; }
     int code = gjk_distance_seeded(&A, &B, sub(ca, cb), margin, &pa, &pb, &dist, cached, &seed, GJK_MAX_ITER);
     if (g_stats) g_stats[1024 + (g_last_gjk_iters > 63 ? 63 : g_last_gjk_iters)]++; /* [1024, 1088): iterations of the main runs */
     if (cached && code != 0) *cached = seed; /* overlap keeps the previous entry */
@@ -1025,7 +1029,7 @@ static void plane_contacts(const slhip_body* bodies, const wbody* wbs, int ia, c
                            const float* hull_verts, const slhip_settle_params* prm, float plane_z,
                            float margin, contact* out, pplane* pp, int step)
 {
-    for (int i = 0; i < PLANE_SLOTS; ++i) { out[i].valid = 0; out[i].culled = 0; }
+    for (int i = 0; i < PATCH_STRIDE; ++i) { out[i].valid = 0; out[i].culled = 0; out[i].ln = 0.0f; }
     const slhip_body* b = &bodies[ia];
     const wbody* w = &wbs[ia];
     plane_it it = {w, b, hulls, hull_verts, plane_z, margin};
@@ -1034,8 +1038,8 @@ static void plane_contacts(const slhip_body* bodies, const wbody* wbs, int ia, c
     int id0 = 0, id1 = 0, id2 = 0, id3 = 0;
     pplane prev;
     prev.count = 0;
-    if (pp && pp->stamp == step - 1) prev = *pp;
-    if (pp) { pp->stamp = step; pp->count = 0; }
+    if (pp && pp->stamp == step - 1) { prev = *pp; out[PLANE_SLOTS].ln = WARM_START * prev.lc; }
+    if (pp) { pp->stamp = step; pp->count = 0; pp->lc = 0.0f; }
 #define PLANE_ID(h, i) ((int)(((h) - b->hull_begin) << 8 | (i)))
     for (uint32_t h = b->hull_begin; h < b->hull_end; ++h)
         for (uint32_t i = 0; i < hulls[h].vtx_count; ++i) {
@@ -1194,6 +1198,12 @@ static void solve_patch(contact* c, wbody* wbs, const slhip_settle_params* prm, 
 {
     float nsum = 0.0f;
     int m = 0;
+    /* the centre row first: it takes the part of the correction the whole face shares, without turning the bodies against each
+       other; the points' rows then see what is left (patch_centre) */
+    if (c[MAX_CONTACTS_PER_HP].valid) {
+        solve_normal(&c[MAX_CONTACTS_PER_HP], wbs, prm, biased);
+        nsum = nsum + c[MAX_CONTACTS_PER_HP].ln;
+    }
     for (int i = 0; i < MAX_CONTACTS_PER_HP; ++i) {
         if (!c[i].valid) continue;
         solve_normal(&c[i], wbs, prm, biased);
@@ -1209,6 +1219,35 @@ static void solve_patch(contact* c, wbody* wbs, const slhip_settle_params* prm, 
         solve_friction(&c[i], wbs, share);
         ++done;
     }
+}
+
+/* The CENTRE ROW of a patch of three or four points (a face resting on a face): one more normal row at the mean of the points,
+   with their mean separation -- a point of the same contact face, so nothing the manifold does not already say.  Gauss-Seidel
+   walks a patch's points one after the other; the first one met takes most of a correction all of them share and turns the
+   bodies against each other, the following rows take part of that back, and what is left after 4 + 4 sweeps is a net angular
+   velocity in the same sense step after step: a column of cubes leans over within seconds (measured in round 6: exact boxes,
+   0.1 rad/s per step from a symmetric start).  The centre row carries the shared part through the patch's centre, where it
+   turns nothing; the corner rows are left with the differences.  No friction acts at it (the anchors stay the first two
+   points); its impulse counts towards the patch's normal impulse and is carried from step to step like the points'. */
+static void patch_centre(contact* c)
+{
+    contact* cc = &c[MAX_CONTACTS_PER_HP];
+    const float carried = cc->ln;
+    cc->valid = 0;
+    int m = 0;
+    v3 ra = V(0, 0, 0), rb = V(0, 0, 0);
+    float sep = 0.0f;
+    for (int i = 0; i < MAX_CONTACTS_PER_HP; ++i) {
+        if (!c[i].valid) continue;
+        ra = add(ra, c[i].ra); rb = add(rb, c[i].rb); sep = sep + c[i].sep;
+        ++m;
+    }
+    if (m < 3) return;
+    const float inv = 1.0f / (float)m;
+    *cc = c[0];
+    cc->ra = scale(ra, inv); cc->rb = scale(rb, inv); cc->sep = sep * inv;
+    cc->ln = carried; cc->lt1 = 0.0f; cc->lt2 = 0.0f;
+    cc->valid = 1; cc->culled = 0;
 }
 
 /* D6 joint of ManipulationSim (manipulation_sim.cpp:46-93): world-anchored, linear X/Y/Z driven by
@@ -1324,9 +1363,9 @@ static void step_stats(const scene_ws* ws)
     int longest[64] = {0};
     for (int g = 0; g < ws->n_groups; ++g) {
         int rows = 0;
-        for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += MAX_CONTACTS_PER_HP) {
+        for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += PATCH_STRIDE) {
             int m = 0;
-            for (int k = 0; k < MAX_CONTACTS_PER_HP; ++k) m += ws->c[i + k].valid ? 1 : 0;
+            for (int k = 0; k < PATCH_STRIDE; ++k) m += ws->c[i + k].valid ? 1 : 0;
             active += m;
             anchors += m >= 2 ? 2 : m;
             rows += m + (m >= 2 ? 2 : m);
@@ -1350,7 +1389,7 @@ static void solve_iteration(scene_ws* ws, const slhip_body* bodies, int nb, cons
     for (int col = 0; col < ws->n_colors; ++col)
         for (int g = 0; g < ws->n_groups; ++g) {
             if (ws->g_color[g] != col) continue;
-            for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += MAX_CONTACTS_PER_HP) solve_patch(&ws->c[i], ws->wb, prm, biased);
+            for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += PATCH_STRIDE) solve_patch(&ws->c[i], ws->wb, prm, biased);
         }
     for (int i = 0; i < nb; ++i) solve_drive(&bodies[i], &ws->wb[i], prm, biased);
 }
@@ -1455,7 +1494,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
     int pairs_found = 0, g_overflow = 0;
     /* (b) plane contacts FIRST: one group per dynamic body near the table (their contacts have
        priority under the active-contact cap); slots live after the hull-pair slots */
-    const int plane_base = ws->P * MAX_CONTACTS_PER_HP;
+    const int plane_base = ws->P * PATCH_STRIDE;
     if (sc->has_plane) {
         for (int i = 0; i < nb; ++i) {
             if (!wb[i].dynamic) continue;
@@ -1463,12 +1502,12 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
             float vz = wb[i].v.z < 0.0f ? -wb[i].v.z * dt : 0.0f;
             float margin = prm->contact_offset + vz;
             if (ci.z - bodies[i].bsphere[3] - sc->plane_z > margin) continue;
-            contact* out = &ws->c[plane_base + i * PLANE_SLOTS];
+            contact* out = &ws->c[plane_base + i * PATCH_STRIDE];
             plane_contacts(bodies, wb, i, hulls, hull_verts, prm, sc->plane_z, margin, out, &ws->pp[i], ws->step);
             int g = ws->n_groups++;
             ws->g_a[g] = i; ws->g_b[g] = -1;
-            ws->g_begin[g] = plane_base + i * PLANE_SLOTS;
-            ws->g_end[g] = plane_base + (i + 1) * PLANE_SLOTS;
+            ws->g_begin[g] = plane_base + i * PATCH_STRIDE;
+            ws->g_end[g] = plane_base + (i + 1) * PATCH_STRIDE;
         }
     }
 
@@ -1506,8 +1545,8 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
             if (ws->n_hp > first) {
                 int g = ws->n_groups++;
                 ws->g_a[g] = i; ws->g_b[g] = j;
-                ws->g_begin[g] = first * MAX_CONTACTS_PER_HP;
-                ws->g_end[g] = ws->n_hp * MAX_CONTACTS_PER_HP;
+                ws->g_begin[g] = first * PATCH_STRIDE;
+                ws->g_end[g] = ws->n_hp * PATCH_STRIDE;
             }
         }
 
@@ -1529,7 +1568,7 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
             ws->hp_pm[k] = &ws->pm[(size_t)la * ws->n_hulls + lb];
         }
         float s = hull_pair_contacts(bodies, wb, i, j, &hulls[ws->hp_ha[k]], &hulls[ws->hp_hb[k]], hull_verts, prm,
-                                     margin, &ws->c[k * MAX_CONTACTS_PER_HP], cached, ws->hp_pm[k], ws->step);
+                                     margin, &ws->c[k * PATCH_STRIDE], cached, ws->hp_pm[k], ws->step);
         /* min separation per object (scene.cpp:73-116; plane contacts are ignored there) */
         if (s < bodies[i].separation) bodies[i].separation = s;
         if (s < bodies[j].separation) bodies[j].separation = s;
@@ -1540,9 +1579,9 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
     for (int g = 0; g < ws->n_groups; ++g) {
         if (ws->g_b[g] < 0) continue;
         int n_cp = 0;
-        for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += MAX_CONTACTS_PER_HP) n_cp += ws->c[i].valid ? 1 : 0;
+        for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += PATCH_STRIDE) n_cp += ws->c[i].valid ? 1 : 0;
         const int limit = n_cp <= THIN_FULL ? 4 : n_cp <= THIN_HALF ? 2 : 1;
-        for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += MAX_CONTACTS_PER_HP)
+        for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += PATCH_STRIDE)
             for (int k = limit; k < MAX_CONTACTS_PER_HP; ++k) ws->c[i + k].valid = 0;
     }
 
@@ -1573,6 +1612,10 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
         if (reduced) ws->cap_hits[4]++;
     }
 
+    /* the centre rows of the patches that kept three or four points */
+    for (int g = 0; g < ws->n_groups; ++g)
+        for (int i = ws->g_begin[g]; i < ws->g_end[g]; i += PATCH_STRIDE) patch_centre(&ws->c[i]);
+
     /* The solver takes every contact (PhysX has no cap, scene.cpp:738-739) -- up to the capacity of the list the caller sized
        (max_contacts_per_scene): what a step offers beyond it is dropped in list order, the table's contacts first in the list,
        and counted. */
@@ -1587,11 +1630,13 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
             ws->cap_hits[0]++;
             int active = 0;
             for (int g = 0; g < ws->n_groups; ++g)
-                for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) {
-                    if (!ws->c[i].valid) continue;
-                    if (active >= ws->C) ws->c[i].valid = 0;
-                    else ++active;
-                }
+                for (int p = ws->g_begin[g]; p < ws->g_end[g]; p += PATCH_STRIDE)
+                    for (int k = 0; k < PATCH_STRIDE; ++k) {
+                        const int i = p + PATCH_ORDER(k);      /* list order: a patch's centre row, then its points */
+                        if (!ws->c[i].valid) continue;
+                        if (active >= ws->C) ws->c[i].valid = 0;
+                        else ++active;
+                    }
         }
     }
 
@@ -1628,11 +1673,12 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
     for (int col = 0; col < ws->n_colors; ++col)
         for (int g = 0; g < ws->n_groups; ++g) {
             if (ws->g_color[g] != col) continue;
-            for (int i = ws->g_begin[g]; i < ws->g_end[g]; ++i) {
-                contact* c = &ws->c[i];
-                if (!c->valid) continue;
-                apply_impulse(&wb[c->a], c->b >= 0 ? &wb[c->b] : NULL, c, scale(c->n, c->ln));
-            }
+            for (int p = ws->g_begin[g]; p < ws->g_end[g]; p += PATCH_STRIDE)
+                for (int k = 0; k < PATCH_STRIDE; ++k) {
+                    contact* c = &ws->c[p + PATCH_ORDER(k)];
+                    if (!c->valid) continue;
+                    apply_impulse(&wb[c->a], c->b >= 0 ? &wb[c->b] : NULL, c, scale(c->n, c->ln));
+                }
         }
     for (uint32_t it = 0; it < prm->pos_iters; ++it) solve_iteration(ws, bodies, nb, prm, 1);
 
@@ -1661,19 +1707,21 @@ static void step_scene(const slhip_settle_scene* sc, slhip_body* bodies_all, con
     for (int k = 0; k < ws->n_hp; ++k) {
         pmanifold* pm = ws->hp_pm[k];
         if (!pm) continue;
-        const contact* c = &ws->c[k * MAX_CONTACTS_PER_HP];
+        const contact* c = &ws->c[k * PATCH_STRIDE];
         int kept = 0;   /* points the active-contact cap dropped (a suffix) leave the manifold */
         while (kept < pm->count && (c[kept].valid || c[kept].culled)) { pm->ln[kept] = c[kept].valid ? c[kept].ln : 0.0f; ++kept; }
         pm->count = kept;
+        pm->lc = c[MAX_CONTACTS_PER_HP].valid ? c[MAX_CONTACTS_PER_HP].ln : 0.0f;
     }
     if (sc->has_plane)
         for (int i = 0; i < nb; ++i) {
             pplane* pp = &ws->pp[i];
             if (pp->stamp != ws->step) continue;
-            const contact* c = &ws->c[plane_base + i * PLANE_SLOTS];
+            const contact* c = &ws->c[plane_base + i * PATCH_STRIDE];
             int kept = 0;
             while (kept < pp->count && c[kept].valid) { pp->ln[kept] = c[kept].ln; ++kept; }
             pp->count = kept;
+            pp->lc = c[PLANE_SLOTS].valid ? c[PLANE_SLOTS].ln : 0.0f;
         }
     ws->step++;
 
@@ -1965,7 +2013,7 @@ int slref_debug_contacts(const slhip_settle_scene* sc, const slhip_body* bodies_
         for (int j = i + 1; j < nb; ++j)
             for (uint32_t ha = bodies[i].hull_begin; ha < bodies[i].hull_end; ++ha)
                 for (uint32_t hb = bodies[j].hull_begin; hb < bodies[j].hull_end; ++hb) {
-                    contact c[MAX_CONTACTS_PER_HP];
+                    contact c[PATCH_STRIDE];
                     hull_pair_contacts(bodies, ws->wb, i, j, &hulls[ha], &hulls[hb], hull_verts, prm,
                                        2.0f * prm->contact_offset, c, NULL, NULL, 0);
                     for (int k = 0; k < MAX_CONTACTS_PER_HP; ++k) {
@@ -1979,7 +2027,7 @@ int slref_debug_contacts(const slhip_settle_scene* sc, const slhip_body* bodies_
                 }
     if (sc->has_plane)
         for (int i = 0; i < nb; ++i) {
-            contact c[PLANE_SLOTS];
+            contact c[PATCH_STRIDE];
             plane_contacts(bodies, ws->wb, i, hulls, hull_verts, prm, sc->plane_z, prm->contact_offset, c, NULL, 0);
             for (int k = 0; k < PLANE_SLOTS; ++k) {
                 if (!c[k].valid || rows >= max_rows) continue;

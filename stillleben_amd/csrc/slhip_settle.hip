@@ -904,6 +904,28 @@ __device__ __forceinline__ void fill_contact(Contact* c, int a, int b, const WBo
     *c = k;
 }
 
+// The CENTRE ROW of a patch of three or four points (oracle patch_centre): one more normal row at the mean of the points' arms with
+// their mean separation, the HEAD of its patch in the list (the points follow; none of them carries the head mark); no friction
+// acts at it -- marked by lt1 < 0 until prep_contact, by kt1 < 0 from then on.
+__device__ __forceinline__ void fill_centre(Contact* c, int a, int b, int m, v3 sum_ra, v3 sum_rb, float sum_sep,
+                                            v3 n, float rest, float e, float warm)
+{
+    // (the sums run over the points in their order, from +0: sum = sum + x)
+    const float inv = 1.0f / (float)m;
+    Contact k;
+    k.ra = scale(sum_ra, inv);
+    k.rb = scale(sum_rb, inv);
+    k.n = n;
+    k.err = sum_sep * inv - rest;
+    k.kn = 0.0f;
+    k.kt1 = __int_as_float(a); k.kt2 = __int_as_float(b);
+    k.ln = warm;
+    k.lt1 = -1.0f; k.lt2 = 0.0f;                            // the centre mark (prep_contact moves it to kt1)
+    k.bounce = e;
+    k.til = -1.0f;                                         // the patch's head
+    *c = k;
+}
+
 // world AABB overlap of two hulls within margin (|R| * half extents around R c + t)
 __device__ __forceinline__ bool aabb_overlap(const WBody& wa, const slhip_hull& ha, const WBody& wb, const slhip_hull& hb,
                                              float margin)
@@ -970,6 +992,7 @@ __device__ void prep_contact(Contact* cp, const WBody* wbs, float bounce_thresho
     if (bounce > tu) tu = bounce;
     cp->err = tb;
     cp->kn = c.kn; cp->kt1 = c.kt1; cp->kt2 = c.kt2; cp->bounce = tu;
+    if (c.lt1 < 0.0f) { cp->kt1 = -1.0f; cp->lt1 = 0.0f; }   // a patch's centre row: no friction acts at it
     cp->til = c.til < 0.0f ? -til : til;
 }
 
@@ -1045,7 +1068,7 @@ __device__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib,
     int p0 = begin;
     for (int ci = begin; ci < end; ++ci) {
         const Contact c = ac[ci];
-        if (c.til < 0.0f) { nsum = 0.0f; p0 = ci; }
+        if (c.til < 0.0f) { nsum = 0.0f; p0 = c.kt1 < 0.0f ? ci + 1 : ci; }   // (behind the patch's centre row, if it has one)
         const v3 r = side ? c.rb : c.ra;
         v3 pv = add(M.v, cross(M.w, r));
         v3 d = sub(pv, pair_swap(pv));              // side 0: a - b, side 1: b - a
@@ -1155,8 +1178,9 @@ __device__ void solve_group(const ContactList ac, int begin, int end, int ia, in
         if (side == 0) { Contact* w = ac.at(at); w->lt1 = l1; w->lt2 = l2; }
     };
     while (ci < end) {
-        const int p0 = ci;
         nsum = 0.0f;
+        if (nxt.kt1 < 0.0f) normal_row(nullptr);          // the patch's centre row: first, never an anchor (three or four points follow)
+        const int p0 = ci;
         Anchor a0, a1;
         normal_row(&a0);
         if (more && !(nxt.til < 0.0f)) {

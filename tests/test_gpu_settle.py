@@ -333,7 +333,8 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
         (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015)], vel=[(0.8, 0, 0)]), dict(frames=120, gravity=(K.G * math.sin(math.atan(0.15)), 0.0, -K.G * math.cos(math.atan(0.15))))),   # the sliding box
         (K.build(sl, [K.at(-h - 0.0005, 0, K.TABLE + h + 0.0015), K.at(h + 0.0005, 0, K.TABLE + h + 0.0015), K.at(0, 0, K.TABLE + 3 * h + 0.0045)]), dict(frames=150)),   # the pile of three
         (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015), _yawed(K.at(0, 0, K.TABLE + 3 * h + 0.0045), math.pi / 4)]), dict(frames=60)),   # face manifold = corners of an octagon
-        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(8)]), dict(frames=120)),   # the column of eight while it stands
+        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(8)]), dict(frames=400)),   # the column of eight: stands since round 6 (the patches' centre rows)
+        (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015 + k * (2 * h + 0.003)) for k in range(12)]), dict(frames=200)),   # ... and of twelve
         # the stabilisation (scene.cpp:163): a cube kept awake is lightened, damped and, after 1.5 s, frozen; a pile of two beside a falling cube
         (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015)]), dict(frames=300, sleep_threshold=0.0, frozen=True)),
         (K.build(sl, [K.at(0, 0, K.TABLE + h + 0.0015), K.at(0, 0, K.TABLE + 3 * h + 0.0045), K.at(1.0, 0, 3.0)]), dict(frames=30, sleep_threshold=0.0)),
