@@ -712,6 +712,9 @@ struct MainTarget {
 #ifndef SLHIP_SHADOW_WINDOW
 #define SLHIP_SHADOW_WINDOW 64     // texels per side of the LDS window of k_shadow_raster (0: every fragment is a global atomic)
 #endif
+#ifndef SLHIP_SHADOW_WINDOW_PITCH
+#define SLHIP_SHADOW_WINDOW_PITCH (SLHIP_SHADOW_WINDOW + 1)   // words per window row: one more than the side, so that the texels of a column lie in different LDS banks (each lane walks its own triangle: vertical neighbours met in the same bank -- conflict share 0.31 at a pitch of 64)
+#endif
 struct ShadowTarget {
     unsigned* sm;  // [S,S] float bits
     int W;
@@ -727,7 +730,7 @@ struct ShadowTarget {
 #if SLHIP_SHADOW_WINDOW
         const unsigned ux = (unsigned)(px - wx0), uy = (unsigned)(py - wy0);
         if (win != nullptr && ux < (unsigned)SLHIP_SHADOW_WINDOW && uy < (unsigned)SLHIP_SHADOW_WINDOW) {
-            atomicMin(win + uy * SLHIP_SHADOW_WINDOW + ux, bits);
+            atomicMin(win + uy * SLHIP_SHADOW_WINDOW_PITCH + ux, bits);
             return;
         }
 #endif
@@ -1083,7 +1086,8 @@ __global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_shadow_raster(slhip_
     // resolved there (LDS atomics), and the touched texels go to the map once, 64 consecutive texels per atomic instruction --
     // the same minimum per texel, whatever the order.
     constexpr int kWin = SLHIP_SHADOW_WINDOW;
-    __shared__ unsigned win[kWin * kWin];
+    constexpr int kPitch = SLHIP_SHADOW_WINDOW_PITCH;
+    __shared__ unsigned win[kWin * kPitch];
     __shared__ int worg[2];
 #endif
     // one block per chunk, the (few) active lights in a loop: the index fetch is shared and no
@@ -1097,7 +1101,7 @@ __global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_shadow_raster(slhip_
         if (draw && t.flipped) draw = false;  // front face culled
 #if SLHIP_SHADOW_WINDOW
         if (threadIdx.x < 2) worg[threadIdx.x] = 0x7fffffff;
-        for (int k = (int)threadIdx.x; k < kWin * kWin; k += 256) win[k] = 0x3F800000u;      // 1.0: the cleared map
+        for (int k = (int)threadIdx.x; k < kWin * kPitch; k += 256) win[k] = 0x3F800000u;      // 1.0: the cleared map
         __syncthreads();
         if (draw) { atomicMin(&worg[0], t.xmin); atomicMin(&worg[1], t.ymin); }
         __syncthreads();
@@ -1128,7 +1132,7 @@ __global__ __launch_bounds__(256) SLHIP_LIGHT_KERNEL void k_shadow_raster(slhip_
         if (wx0 != 0x7fffffff) {
             unsigned* sm = shadow + ((size_t)ch.scene * nl + light) * S * S;
             for (int k = (int)threadIdx.x; k < kWin * kWin; k += 256) {
-                const unsigned v = win[k];
+                const unsigned v = win[(k / kWin) * kPitch + (k % kWin)];
                 const int x = wx0 + (k % kWin), y = wy0 + (k / kWin);
                 if (v != 0x3F800000u && x < S && y < S) atomicMin(sm + (size_t)y * S + x, v);
             }

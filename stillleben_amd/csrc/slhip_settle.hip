@@ -108,6 +108,17 @@ struct WBody {
     float mu_s, mu_d;     // friction of the body (combined per group in the solver)
 };
 
+// The part of a working body the solver's sweeps touch -- the TAIL of WBody, word for word: what a solver wave keeps in LDS per body
+// (76 bytes instead of 152: the pose part stays in the scratch, read where the step integrates and stores; an odd number of words per
+// body, so lanes walking different bodies hit different banks).
+struct SBody {
+    v3 v, w; m3 Iinv_w;
+    float inv_mass; int dynamic;
+    float mu_s, mu_d;
+};
+static_assert(sizeof(WBody) == 152 && sizeof(SBody) == 76, "working body layouts");
+constexpr int kSBodyWords = (int)sizeof(SBody) / 4, kWBodyWords = (int)sizeof(WBody) / 4;
+
 // accumulated drive impulses of ManipulationSim bodies (global scratch: only driven bodies touch it)
 struct DriveAcc { float dl[3], da[3]; };
 
@@ -1010,7 +1021,8 @@ struct BodyRegs {
     bool dynamic;
 };
 
-__device__ __forceinline__ void load_regs(const WBody& b, BodyRegs& r)
+template <class Body>
+__device__ __forceinline__ void load_regs(const Body& b, BodyRegs& r)
 {
     r.v = b.v; r.w = b.w; r.Iinv = b.Iinv_w; r.inv_mass = b.inv_mass; r.dynamic = b.dynamic != 0;
 }
@@ -1043,7 +1055,8 @@ struct ContactList {
 
 // (the group lies in the LDS-resident part of the list: every row reads its contact where it needs it -- LDS latency is short, and
 // carrying a prefetched contact around the loop costs eighteen register moves per row)
-__device__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib, int side, WBody* wbs, float inv_dt,
+template <class Body>
+__device__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib, int side, Body* wbs, float inv_dt,
                             bool biased, float plane_mu_s, float plane_mu_d)
 {
     if (begin >= end) return;
@@ -1113,7 +1126,8 @@ __device__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib,
 // fetch: beyond the LDS-resident part that would be an exposed round trip to the L2 per patch)
 struct Anchor { v3 r, n; float til, kt1, kt2, lt1, lt2; };
 
-__device__ void solve_group(const ContactList ac, int begin, int end, int ia, int ib, int side, WBody* wbs, float inv_dt,
+template <class Body>
+__device__ void solve_group(const ContactList ac, int begin, int end, int ia, int ib, int side, Body* wbs, float inv_dt,
                             bool biased, float plane_mu_s, float plane_mu_d)
 {
     if (begin >= end) return;
@@ -1198,7 +1212,8 @@ __device__ void solve_group(const ContactList ac, int begin, int end, int ia, in
 
 // Warm start of ONE group by its lane pair (oracle: the loop before the first sweep): every contact's carried normal impulse is
 // applied to the two bodies, contacts in order; same lane roles and sign conventions as solve_group.
-__device__ void warm_group(const ContactList ac, int begin, int end, int ia, int ib, int side, WBody* wbs)
+template <class Body>
+__device__ void warm_group(const ContactList ac, int begin, int end, int ia, int ib, int side, Body* wbs)
 {
     if (begin >= end) return;
     const int mine = side ? ib : ia;
@@ -1308,10 +1323,29 @@ __device__ __forceinline__ float kinetic_energy(const float (&L)[9], const m3& R
     return 0.5f * (dot(v, v) + ang);
 }
 
-__device__ void store_velocities(slhip_body& b, const WBody& w)
+__device__ __forceinline__ void store_velocities(slhip_body& b, v3 v, v3 w)
 {
-    b.lin_vel[0] = w.v.x; b.lin_vel[1] = w.v.y; b.lin_vel[2] = w.v.z;
-    b.ang_vel[0] = w.w.x; b.ang_vel[1] = w.w.y; b.ang_vel[2] = w.w.z;
+    b.lin_vel[0] = v.x; b.lin_vel[1] = v.y; b.lin_vel[2] = v.z;
+    b.ang_vel[0] = w.x; b.ang_vel[1] = w.y; b.ang_vel[2] = w.z;
+}
+
+__device__ __forceinline__ void store_pose(slhip_body& b, const m3& R, v3 t)
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) b.pose[4 * r + c] = R.m[3 * r + c];
+    b.pose[3] = t.x; b.pose[7] = t.y; b.pose[11] = t.z;
+    b.pose[12] = 0.0f; b.pose[13] = 0.0f; b.pose[14] = 0.0f; b.pose[15] = 1.0f;
+}
+
+// the spring drive of a ManipulationSim body inside a solver wave: the working body put together from its pose in the scratch and
+// its solver part in LDS (driven bodies are rare: one per manipulation scene)
+__device__ void solve_drive(const slhip_body& b, WBody& w, DriveAcc& acc, const slhip_settle_params& prm, bool biased);
+__device__ __forceinline__ void drive_body(const slhip_body& b, const WBody& pose, SBody& sb, DriveAcc& acc, const slhip_settle_params& prm, bool biased)
+{
+    WBody w = pose;
+    w.v = sb.v; w.w = sb.w; w.Iinv_w = sb.Iinv_w; w.inv_mass = sb.inv_mass; w.dynamic = sb.dynamic;
+    solve_drive(b, w, acc, prm, biased);
+    sb.v = w.v; sb.w = w.w;
 }
 
 __device__ void store_body(slhip_body& b, const WBody& w)
