@@ -713,7 +713,7 @@ struct MainTarget {
 #define SLHIP_SHADOW_WINDOW 64     // texels per side of the LDS window of k_shadow_raster (0: every fragment is a global atomic)
 #endif
 #ifndef SLHIP_SHADOW_WINDOW_PITCH
-#define SLHIP_SHADOW_WINDOW_PITCH (SLHIP_SHADOW_WINDOW + 1)   // words per window row: one more than the side, so that the texels of a column lie in different LDS banks (each lane walks its own triangle: vertical neighbours met in the same bank -- conflict share 0.31 at a pitch of 64)
+#define SLHIP_SHADOW_WINDOW_PITCH SLHIP_SHADOW_WINDOW         // words per window row.  Round 6 measured a pitch of 65 (the texels of a column in different LDS banks; the counters' conflict share of this kernel is 0.31): 11.0 -> 11.8 ms per 1024 scenes -- the conflicts are lanes meeting in the SAME texel (neighbouring triangles), which no pitch separates, and the flush pays the odd pitch's index arithmetic
 #endif
 struct ShadowTarget {
     unsigned* sm;  // [S,S] float bits

@@ -116,6 +116,42 @@ def test_fronto_parallel_lambert_known_answer(sl, eng):
     assert hdr[H // 2, W // 2, 3] == 1.0
 
 
+def test_auto_exposure_of_a_two_tone_picture_known_answer(sl, eng):
+    """The hand-computed tone map of tests/test_oracle_render.py (a uniformly lit grey face under the reference's auto exposure renders
+    at 207 whatever the light's intensity: no oracle involved) on the kernels' 8-bit picture (k_lum_reduce + k_tonemap)."""
+    from test_oracle_render import auto_exposure_kat_expected, auto_exposure_kat_scene
+
+    want = auto_exposure_kat_expected()
+    pics = []
+    for light in (3.0, 30.0):
+        scene = auto_exposure_kat_scene(sl, light)
+        W, H = scene.viewport
+        bufs = eng.render([scene], _abi.OUT_ALL, ssao=False, shadows=False)
+        torch.cuda.synchronize()
+        rgb, inst = bufs.rgb.cpu().numpy()[0], bufs.instance.cpu().numpy()[0, :, :, 0]
+        face = inst == 1
+        assert abs(int(rgb[H // 2, W // 2, 0]) - want) <= 1 and np.abs(rgb[face][:, :3].astype(int) - want).max() <= 2
+        assert (rgb[~face] == 0).all()
+        pics.append(rgb.copy())
+    assert np.abs(pics[0].astype(int) - pics[1].astype(int)).max() <= 1
+
+
+def test_depth_peel_second_layer_known_answer(sl, eng):
+    """Two fronto-parallel sheets (tests/test_oracle_render.py): the layer peeled off behind the near sheet IS the far sheet, at its
+    analytic depth -- on the kernels' outputs, no oracle involved."""
+    from test_oracle_render import depth_peel_kat_check, depth_peel_kat_scene
+
+    scene = depth_peel_kat_scene(sl)
+    mask = _abi.OUT_COORD | _abi.OUT_INSTANCE
+    b0 = eng.render([scene], mask, ssao=False, shadows=False)
+    torch.cuda.synchronize()
+    first = (b0.instance.cpu().numpy()[0, :, :, 0].copy(), b0.coord.cpu().numpy()[0, :, :, 3].copy())
+    b1 = eng.render([scene], mask, ssao=False, shadows=False, depth_peel=b0.coord.clone())
+    torch.cuda.synchronize()
+    second = (b1.instance.cpu().numpy()[0, :, :, 0].copy(), b1.coord.cpu().numpy()[0, :, :, 3].copy())
+    depth_peel_kat_check(scene, first, second)
+
+
 def test_cast_shadow_known_answer(sl, eng):
     """The geometric shadow of tests/test_oracle_render.py (a slab test in numpy: no oracle involved) on the kernels' float image:
     inside the analytic shadow the ambient-only picture, outside it the picture without shadows, bit for bit; the outline within

@@ -377,6 +377,57 @@ def test_physics_kat_scenarios_match_the_oracle(sl, oracle):
     assert math.degrees(math.acos(max(-1.0, min(1.0, float(gpu[0]["pose"][10]))))) > 45.0
 
 
+def test_rolling_and_drive_known_answers_match_the_oracle(sl, oracle):
+    """The rolling cylinder and the D6 drive's equilibrium / force limit of tests/test_oracle_physics_kat.py through slhip_settle: the
+    oracle's bits, and the known answers themselves on the device's results."""
+    import math
+
+    import test_oracle_physics_kat as K
+    from stillleben_amd import physics
+
+    se = physics.settle_engine()
+    # the cylinder: v = omega r, (2/3) g sin(theta) to within the prism's facets
+    th = math.atan(0.1)
+    r = 0.05
+    scene = sl.Scene((64, 48))
+    o = sl.Object(K.prism_mesh(sl, 32, r, 0.04))
+    scene.add_object(o)
+    o.set_pose(torch.from_numpy(K.at(0, 0, K.TABLE + r + 0.0015)))
+    srec, bodies = SB.build_settle_batch([scene], se.pool, [(True, K.TABLE)])
+    hulls, verts = se.pool.arrays()
+    prm = SB.default_params(tabletop=False, dt=0.01, frames=60, substeps=1)
+    prm["gravity"] = (0.0, K.G * math.sin(th), -K.G * math.cos(th))
+    gpu = se.run(srec, bodies.copy(), prm)
+    ref = bodies.copy()
+    oracle.settle(srec, ref, hulls, verts, prm)
+    assert_bodies_equal(gpu, ref)
+    v, w = float(gpu[0]["lin_vel"][1]), float(gpu[0]["ang_vel"][0])
+    assert v > 0.2 and abs(v + w * r) < 0.02 * v
+    # the drive: m g / k below the target; 60 dt / m per step at the force limit
+    cube = K.cube_mesh(sl, 0.1)
+    for target, z0, frames, gravity in (((0.0, 0.0, 1.0), 1.0, 1500, (0.0, 0.0, -K.G)), ((5.0, 0.0, 0.0), 0.0, 5, (0.0, 0.0, 0.0))):
+        scene = sl.Scene((64, 48))
+        tool = sl.Object(cube)
+        p = torch.eye(4)
+        p[2, 3] = z0
+        sl.ManipulationSim(scene, tool, p)
+        tool._drive["target"] = np.asarray(target, np.float32)
+        se.pool.__dict__.pop("_body_templates", None)
+        srec, bodies = SB.build_settle_batch([scene], se.pool, [(False, 0.0)])
+        hulls, verts = se.pool.arrays()
+        prm = SB.default_params(tabletop=False, dt=0.01, frames=frames, substeps=1)
+        prm["gravity"] = gravity
+        gpu = se.run(srec, bodies.copy(), prm)
+        ref = bodies.copy()
+        oracle.settle(srec, ref, hulls, verts, prm)
+        assert_bodies_equal(gpu, ref)
+        m = 1.0 / float(bodies[0]["inv_mass"])
+        if frames > 100:
+            assert abs(float(gpu[0]["pose"][11]) - (1.0 - m * K.G / 600.0)) < 2e-6
+        else:
+            assert abs(float(gpu[0]["lin_vel"][0]) - 60.0 / m * 0.01 * frames) < 1e-4 * 60.0 / m * 0.01 * frames
+
+
 def test_solver_wave_packing_and_odd_batches(sl, oracle, monkeypatch):
     """The lockstep pipeline on a batch of mixed scenes (tabletop settle): solver waves of one, two or four cost-sorted scenes by
     need (default), at most one and at most four per wave give the oracle's bits, also when the last multi-scene solver wave holds

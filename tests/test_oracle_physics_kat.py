@@ -403,3 +403,102 @@ def test_stabilisation_spreads_through_an_island(sl, oracle):
     oracle.settle(srec, bodies, hulls, verts, prm)
     assert float(bodies[0]["stab"][1]) > 0.03 and float(bodies[1]["stab"][1]) > 0.03
     assert float(bodies[2]["stab"][1]) == 0.0 and float(bodies[2]["stab"][0]) == 0.0
+
+
+def prism_mesh(sl, n, r, half_len):
+    """A regular n-gon prism, axis along x (one 2n-vertex hull): the nearest a <= 64-vertex hull comes to a cylinder."""
+    from scipy.spatial import ConvexHull
+
+    from stillleben_amd import _loaders
+    from stillleben_amd.hulls import Hull
+
+    ang = np.arange(n) * 2.0 * np.pi / n
+    ring = np.stack([r * np.cos(ang), r * np.sin(ang)], 1)
+    pts = np.concatenate([np.concatenate([np.full((n, 1), -half_len), ring], 1),
+                          np.concatenate([np.full((n, 1), half_len), ring], 1)]).astype(np.float32)
+    faces = ConvexHull(pts.astype(np.float64)).simplices.copy()
+    nn = np.cross(pts[faces[:, 1]] - pts[faces[:, 0]], pts[faces[:, 2]] - pts[faces[:, 0]])
+    flip = np.einsum("ij,ij->i", nn, pts[faces[:, 0]]) < 0
+    faces[flip] = faces[flip][:, [0, 2, 1]]
+    cm = _loaders.ConsolidatedMesh()
+    cm.positions = pts
+    cm.normals = (pts / np.linalg.norm(pts, axis=1)[:, None]).astype(np.float32)
+    cm.uvs = np.zeros((len(pts), 2), np.float32)
+    cm.colors = np.ones((len(pts), 4), np.float32)
+    cm.indices = np.ascontiguousarray(faces).reshape(-1).astype(np.uint32)
+    cm.textures = []
+    cm._tex_alpha = []
+    cm.materials = [_loaders.Material(base_color=(0.8, 0.8, 0.8, 1))]
+    cm.submeshes = [_loaders.SubMesh(0, len(cm.indices), 0)]
+    return sl.Mesh.from_data(cm, hulls=[Hull(pts, faces.astype(np.int32))], filename="memory://prism%d_%g_%g" % (n, r, half_len))
+
+
+def rolling_state(sl, tan_theta):
+    r = 0.05
+    scene = sl.Scene((64, 48))
+    o = sl.Object(prism_mesh(sl, 32, r, 0.04))
+    scene.add_object(o)
+    o.set_pose(torch.from_numpy(at(0, 0, TABLE + r + 0.0015)))
+    pool = SB.HullPool()
+    srec, bodies = SB.build_settle_batch([scene], pool, [(True, TABLE)])
+    hulls, verts = pool.arrays()
+    return (srec, bodies, hulls, verts), r
+
+
+@pytest.mark.parametrize("tan_theta", [0.05, 0.1])
+def test_a_cylinder_rolls_down_an_incline_without_slipping(sl, oracle, tan_theta):
+    """A solid cylinder (a 32-gon prism of 64 hull vertices) on an incline below the friction angle (tan theta < mu_s = 0.4) cannot
+    slide: it rolls, v = omega r, with (2/3) g sin(theta) for the ideal cylinder (I = m r^2 / 2).  The prism's facets (9.8 mm, the
+    size of the contact band) and the angular damping of 0.05 / s take a few per cent off -- it must not be faster, and not slower
+    than 85 % of it.  Rigid-body mechanics: no constant of the solver enters."""
+    th = math.atan(tan_theta)
+    state, r = rolling_state(sl, tan_theta)
+    step(oracle, state, 30, gravity=(0.0, 0.0, -G * math.cos(th)))            # come to rest on the table first
+    y0 = float(state[1][0]["pose"][7])
+    T = 0.6
+    b = step(oracle, state, int(round(T / 0.01)), gravity=(0.0, G * math.sin(th), -G * math.cos(th)))
+    v, w = float(b[0]["lin_vel"][1]), float(b[0]["ang_vel"][0])
+    a = 2.0 * (float(b[0]["pose"][7]) - y0) / T ** 2
+    ideal = (2.0 / 3.0) * G * math.sin(th)
+    assert v == pytest.approx(-w * r, rel=0.01)                                # rolling without slipping
+    assert 0.85 * ideal < a <= 1.01 * ideal, (a, ideal)
+    assert abs(float(b[0]["pose"][3])) < 1e-3                                  # ... straight down the slope
+
+
+def drive_state(sl, target, z0=0.0):
+    cube = cube_mesh(sl, 0.1)
+    scene = sl.Scene((64, 48))
+    tool = sl.Object(cube)
+    p = torch.eye(4)
+    p[2, 3] = z0
+    sl.ManipulationSim(scene, tool, p)
+    tool._drive["target"] = np.asarray(target, np.float32)
+    pool = SB.HullPool()
+    srec, bodies = SB.build_settle_batch([scene], pool, [(False, 0.0)])
+    hulls, verts = pool.arrays()
+    return srec, bodies, hulls, verts
+
+
+def test_drive_spring_holds_a_body_mg_over_k_below_its_target(sl, oracle):
+    """ManipulationSim's D6 drive (manipulation_sim.cpp:46-81: stiffness 600, damping 0.1, force limit 60) is a spring: under gravity the
+    manipulator comes to rest m g / k below its target -- the equilibrium the constants of manipulation_sim.cpp:55 imply."""
+    srec, bodies, hulls, verts = drive_state(sl, (0.0, 0.0, 1.0), z0=1.0)
+    m = 1.0 / float(bodies[0]["inv_mass"])
+    prm = SB.default_params(tabletop=False, dt=0.01, frames=1500, substeps=1)
+    oracle.settle(srec, bodies, hulls, verts, prm)
+    assert m * G < 60.0                                                        # inside the force limit
+    assert float(bodies[0]["pose"][11]) == pytest.approx(1.0 - m * G / 600.0, abs=2e-6)
+    assert np.abs(bodies[0]["lin_vel"][:3]).max() < 1e-4
+
+
+@pytest.mark.parametrize("steps", [1, 3, 5])
+def test_drive_force_limit_caps_the_pull(sl, oracle, steps):
+    """... and a target 5 m away asks the spring for 3000 N: the drive delivers its force limit of 60 N (manipulation_sim.cpp:55), the
+    body gains 60 dt / m per step."""
+    srec, bodies, hulls, verts = drive_state(sl, (5.0, 0.0, 0.0))
+    m = 1.0 / float(bodies[0]["inv_mass"])
+    prm = SB.default_params(tabletop=False, dt=0.01, frames=steps, substeps=1)
+    prm["gravity"] = (0.0, 0.0, 0.0)
+    oracle.settle(srec, bodies, hulls, verts, prm)
+    assert float(bodies[0]["lin_vel"][0]) == pytest.approx(60.0 / m * 0.01 * steps, rel=1e-5)
+    assert np.abs(bodies[0]["lin_vel"][1:3]).max() == 0.0 and np.abs(bodies[0]["ang_vel"][:3]).max() < 1e-6

@@ -521,3 +521,83 @@ def test_cast_shadow_known_answer(sl, oracle):
     ambient = oracle_render(oracle, [cast_shadow_kat_scene(sl, 0.0)[0]], flags=_abi.OUT_ALL, want_hdr=True)
     cast_shadow_kat_check(lit_scene, ld, with_shadow.cam_coord[0], with_shadow.instance[0, :, :, 0],
                           with_shadow.hdr[0][:, :, :3], without.hdr[0][:, :, :3], ambient.hdr[0][:, :, :3])
+
+
+def auto_exposure_kat_scene(sl, light):
+    """lambert_kat_scene with the auto exposure of the reference (manualExposure < 0) and a light of the given colour."""
+    scene = lambert_kat_scene(sl, (320, 240))
+    scene.light_colors = torch.tensor([[light, light, light], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    scene.manual_exposure = -1.0
+    return scene
+
+
+def auto_exposure_kat_expected():
+    """tone_map_shader.frag:102-131 by hand for a two-tone picture -- a uniformly lit grey face of radiance L over the cleared
+    background (0, 0, 0, 0): the 1 x 1 mip level is (f L, f L, f L, f) for a coverage f, so avg.rgb / avg.a = L whatever f is;
+    lum = 0.1 L (the luma weights add up to 1); the face's Y = L is divided by 9.6 x 0.1 L + 1e-4: 1 / 0.96 whatever L is; grey
+    stays grey through Yxy and back; ACES(1 / 0.96) = 0.8123; no gamma (the shader's last line overwrites it): 207."""
+    x = 1.0 / 0.96
+    v = (x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14)
+    return int(math.floor(v * 255.0 + 0.5))
+
+
+def test_auto_exposure_of_a_two_tone_picture_known_answer(sl, oracle):
+    want = auto_exposure_kat_expected()
+    assert want == 207
+    pics = []
+    for light in (3.0, 30.0):
+        scene = auto_exposure_kat_scene(sl, light)
+        r = oracle_render(oracle, [scene], flags=_abi.OUT_ALL)
+        W, H = scene.viewport
+        face = r.instance[0, :, :, 0] == 1
+        assert 0.02 < face.mean() < 0.5
+        px = r.rgb[0][face][:, :3].astype(int)
+        # the face is uniform to 3 % (Fresnel / G towards its corners): every pixel within 2 steps of the hand-computed value,
+        # the centre -- the brightest spot, 1.5 % above the mean -- within 1
+        assert abs(int(r.rgb[0, H // 2, W // 2, 0]) - want) <= 1 and np.abs(px - want).max() <= 2, (px.min(), px.max())
+        assert (r.rgb[0][~face] == 0).all()
+        pics.append(r.rgb[0].copy())
+    # ten times the light: the same picture (one step of rounding at most)
+    assert np.abs(pics[0].astype(int) - pics[1].astype(int)).max() <= 1
+
+
+def depth_peel_kat_scene(sl):
+    """Two fronto-parallel square sheets on the optical axis: a small one 3 m from the camera, a large one 5 m from it."""
+    near = S.delaunay_sheet(sl, 40, seed=1, half=0.4)
+    far = S.delaunay_sheet(sl, 40, seed=2, half=1.2)
+    scene = S.sheet_scene(sl, near, roll_deg=0.0, distance=3.0)
+    o = sl.Object(far)
+    cam = scene.camera_pose().numpy().astype(np.float64)
+    P = np.eye(4)
+    P[:3, :3] = np.diag([1.0, -1.0, -1.0])
+    P[:3, 3] = [0.0, 0.0, 5.0]
+    o.set_pose(torch.from_numpy((cam @ P).astype(np.float32)))
+    scene.add_object(o)
+    return scene
+
+
+def depth_peel_kat_check(scene, first, second):
+    """first / second: (instance [H, W], depth [H, W]) of the plain render and of the render peeled by it.  Where the near sheet
+    covers the far one the second layer IS the far sheet (instance 2 at depth 5), where the first layer already shows the far
+    sheet or nothing the second layer is empty -- and the near sheet's outline is the analytic square |x|, |y| <= 0.4 at z = 3."""
+    (i0, d0), (i1, d1) = first, second
+    H, W = i0.shape
+    P = scene.projection_matrix().numpy()
+    fx, fy, cx, cy = P[0, 0] * W / 2, P[1, 1] * H / 2, W / 2, H / 2
+    xs, ys = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5)
+    inside_near = (np.abs((xs - cx) / fx * 3.0) < 0.4 - 0.02) & (np.abs((ys - cy) / fy * 3.0) < 0.4 - 0.02)
+    outside_near = (np.abs((xs - cx) / fx * 3.0) > 0.4 + 0.02) | (np.abs((ys - cy) / fy * 3.0) > 0.4 + 0.02)
+    assert inside_near.sum() > 1000
+    assert (i0[inside_near] == 1).all() and np.allclose(d0[inside_near], 3.0, atol=1e-5)
+    assert (i1[inside_near] == 2).all() and np.allclose(d1[inside_near], 5.0, atol=1e-5)
+    assert (i1[outside_near] == 0).all()
+    far_only = outside_near & (i0 == 2)
+    assert far_only.sum() > 1000 and np.allclose(d0[far_only], 5.0, atol=1e-5)
+
+
+def test_depth_peel_second_layer_known_answer(sl, oracle):
+    scene = depth_peel_kat_scene(sl)
+    flags = _abi.OUT_COORD | _abi.OUT_INSTANCE
+    r0 = oracle_render(oracle, [scene], flags=flags)
+    r1 = oracle_render(oracle, [scene], flags=flags, depth_peel=r0.coord)
+    depth_peel_kat_check(scene, (r0.instance[0, :, :, 0], r0.coord[0, :, :, 3]), (r1.instance[0, :, :, 0], r1.coord[0, :, :, 3]))
