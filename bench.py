@@ -68,6 +68,10 @@ def parse():
                     help="slhip_settle_params.pair_contact_budget: 0 (default) = every contact point goes to the solver, as in PhysX; "
                          "N > 0 = the compound manifold reduction (NOT in the reference): a body pair touching through more hull pairs "
                          "keeps the N deepest -- 32 is what rounds 3 and 4 ran (+2 %% scenes/s: 10 090 against 9 880 on one box)")
+    ap.add_argument("--hulls", default="vhacd", choices=["vhacd", "native"],
+                    help="collision hulls of the 21 classes: vhacd = the decompositions the reference's own V-HACD gave this geometry "
+                         "(shipped fixture, the default), native = the in-tree decomposition (stillleben_amd/acd.py over the quick-hull of "
+                         "libslhip.so): row S1 of SURVEY 8a feeding the measured number")
     ap.add_argument("--no-ssao", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes per host thread of the bounded CPU-baseline sample")
@@ -461,9 +465,9 @@ def main():
     from stillleben_amd import synthetic
     from stillleben_amd.parallel import BatchGatherer, SlhipComm
 
-    sl.init_cuda(local_rank)
     t_prep = time.perf_counter()
-    meshes = synthetic.ycb_like_meshes(seed=0)
+    meshes = synthetic.ycb_like_meshes(seed=0, hulls=args.hulls)   # (before the device is touched: the native decomposition forks workers)
+    sl.init_cuda(local_rank)
     table = sl.AssetTable(meshes)                 # once per process: the 21 classes' vertices, textures, hulls -> HBM
     if args.render_chunk is None:
         args.render_chunk = 1024
@@ -859,6 +863,8 @@ def report(args, world, elapsed, table, pipe, t_settle, t_settle_alone, t_stage,
                         "all four stages inside the timed region" % (args.batch, "off" if args.no_ssao else "on"),
             "scenes_per_gpu_per_step": args.batch, "render_chunk": args.render_chunk, "resolution": list(RESOLUTION),
             "objects": N_OBJECTS, "settle_streams": len(pipe.s_settle), "render_streams": len(pipe.s_render_all),
+            "collision_hulls": ("the reference's V-HACD on this geometry (shipped fixture)" if args.hulls == "vhacd" else
+                                "the in-tree decomposition (acd.py + slhip_host_convex_hull)") + ": %d hulls in the 21 classes" % int(sum(table.n_hulls)),
             "pair_contact_budget": caps["pair_contact_budget"] if caps else None,   # (slhip.h; 0 = every contact point, as in PhysX)
             "parallelism": ("scenes sharded by rank, no data-path collective; exchange: RCCL all-gather of a %d-scene C3 shard per "
                             "rank and step (%.0f MB per rank) -- %d of the %d scenes a rank renders per step are exchanged"

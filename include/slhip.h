@@ -40,7 +40,8 @@ extern "C" {
                                     outlives the call); slhip_settle_caps fills counts[8]
                                  4: slhip_settle_params.max_body_pairs_per_scene (120 bytes); slhip_settle_caps fills ten counts
                                  5: slhip_settle_params.stabilization_threshold (128 bytes); slhip_body.stab (304 bytes) carries the
-                                    stabilisation state of a body, SLHIP_BODY_FROZEN; slhip_settle_solver_wave_lds            */
+                                    stabilisation state of a body, SLHIP_BODY_FROZEN; slhip_settle_solver_wave_lds, slhip_host_convex_hull,
+                                    slhip_host_fill_holes                                                                      */
 #define SLHIP_NUM_LIGHTS 3 /* reference include/stillleben/common.h:17 */
 
 /* ---------------------------------------------------------------------------------------------
@@ -711,6 +712,15 @@ int slhip_records_count(const slhip_host_scene* scenes, uint32_t n_scenes, const
 int slhip_records_build_render(const slhip_host_scene* scenes, uint32_t n_scenes, const slhip_host_object* objects,
                                const slhip_draw* templates, uint32_t with_shadows, slhip_scene* srec, slhip_draw* drec,
                                uint32_t draw_capacity, slhip_chunk* crec, uint32_t chunk_capacity);
+
+/* Host geometry of the collision-shape stage (Mesh::loadPhysics, src/mesh.cpp:335-470, where the reference calls its
+ * vendored V-HACD and PhysX's convex cooking; csrc/slhip_hull.cpp).
+ * slhip_host_convex_hull: quick-hull of n points (xyz, double): up to tri_capacity index triples into `points` (a hull of n points has
+ * at most 2 n - 4 triangles), outward oriented.  Returns 0; 1 when the points span no volume (*n_tris_out = 0); -1 on error.
+ * slhip_host_fill_holes: solid fill of a voxel grid [nx][ny][nz] (bytes, C order, in place): every empty cell that cannot be reached
+ * from the border through empty face neighbours becomes 1 -- V-HACD's inside / outside classification.                           */
+int slhip_host_convex_hull(const double* points, uint32_t n, uint32_t* tris_out, uint32_t tri_capacity, uint32_t* n_tris_out);
+int slhip_host_fill_holes(uint8_t* grid, uint32_t nx, uint32_t ny, uint32_t nz);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU exchange: scenes are independent, every rank (one process per GPU, as

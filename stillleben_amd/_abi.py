@@ -270,6 +270,8 @@ def lib():
     L.slhip_settle_status.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]
     L.slhip_host_shadow_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.slhip_host_normal_matrix.argtypes = [C.c_void_p, C.c_void_p]
+    L.slhip_host_convex_hull.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.slhip_host_fill_holes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     L.slhip_records_count.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.slhip_records_build_render.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                              C.c_uint32, C.c_void_p, C.c_uint32]

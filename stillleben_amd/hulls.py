@@ -28,33 +28,82 @@ class Hull:
         return float(np.abs(np.einsum("ij,ij->i", v[t[:, 0]], np.cross(v[t[:, 1]], v[t[:, 2]])).sum()) / 6.0)
 
 
-def _qhull(points):
-    from scipy.spatial import ConvexHull, QhullError
+def native_hull(points):
+    """Triangles (int64 [T, 3], indices into `points`, outward) of the convex hull of float64 [N, 3] points: the quick-hull of
+    libslhip.so (slhip_host_convex_hull, csrc/slhip_hull.cpp).  A cloud that spans no volume (a sheet, a rod: Qhull's QhullError)
+    is joggled the way Qhull's 'QJ' does -- deterministic offsets of 1e-7 of its extent -- so that it still yields a (thin) hull;
+    None when even that fails (fewer than four distinct points)."""
+    import ctypes as C
 
+    from . import _abi
+
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    n = len(pts)
+    if n < 4:
+        return None
+    L = _abi.lib()
+    tris = np.zeros((max(4, 2 * n), 3), dtype=np.uint32)
+    nt = C.c_uint32(0)
+    rc = L.slhip_host_convex_hull(pts.ctypes.data, n, tris.ctypes.data, len(tris), C.byref(nt))
+    if rc == 1:
+        ext = float((pts.max(axis=0) - pts.min(axis=0)).max())
+        if not ext > 0.0:
+            return None
+        k = np.arange(3 * n, dtype=np.uint64).reshape(n, 3)
+        jog = ((k * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(1 << 20)).astype(np.float64) / float(1 << 20) - 0.5
+        moved = np.ascontiguousarray(pts + jog * (2e-7 * ext))
+        rc = L.slhip_host_convex_hull(moved.ctypes.data, n, tris.ctypes.data, len(tris), C.byref(nt))
+    if rc != 0:
+        if rc < 0:
+            _abi.check(-1, 'host geometry')
+        return None
+    return tris[: nt.value].astype(np.int64)
+
+
+def _hull_planes(v, tris):
+    """Outward unit normals and offsets of a hull's triangles: n . x + d <= 0 inside."""
+    n = np.cross(v[tris[:, 1]] - v[tris[:, 0]], v[tris[:, 2]] - v[tris[:, 0]])
+    ln = np.linalg.norm(n, axis=1)
+    ok = ln > 0
+    n = n[ok] / ln[ok, None]
+    return n, -np.einsum("ij,ij->i", n, v[tris[ok, 0]])
+
+
+def hull_volume(points):
+    """Volume of the convex hull of a point cloud (0 for a cloud that spans none)."""
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    if len(pts) < 4:
+        return 0.0
+    import ctypes as C
+
+    from . import _abi
+
+    tris = np.zeros((max(4, 2 * len(pts)), 3), dtype=np.uint32)
+    nt = C.c_uint32(0)
+    if _abi.lib().slhip_host_convex_hull(pts.ctypes.data, len(pts), tris.ctypes.data, len(tris), C.byref(nt)) != 0:
+        return 0.0
+    t = tris[: nt.value].astype(np.int64)
+    o = pts[t[0, 0]]
+    return float(np.abs(np.einsum("ij,ij->i", pts[t[:, 0]] - o, np.cross(pts[t[:, 1]] - o, pts[t[:, 2]] - o)).sum()) / 6.0)
+
+
+def _qhull(points):
+    """(vertices float64 [V, 3], triangles int64 [T, 3]) of the hull of a point cloud -- vertices in the lexicographic order of their
+    coordinates (what round 5's SciPy / Qhull path returned: np.unique's order, the hull's vertices in ascending index)."""
     pts = np.unique(np.asarray(points, dtype=np.float64), axis=0)
-    try:
-        h = ConvexHull(pts)
-    except QhullError:
-        h = ConvexHull(pts, qhull_options="QJ")
-    verts = h.vertices
+    tris = native_hull(pts)
+    if tris is None:
+        raise ValueError("convex hull of %d coincident / collinear points" % len(pts))
+    verts = np.unique(tris)
     remap = -np.ones(len(pts), dtype=np.int64)
     remap[verts] = np.arange(len(verts))
-    tris = remap[h.simplices]
-    v = pts[verts]
-    # orient outward
-    c = v.mean(axis=0)
-    n = np.cross(v[tris[:, 1]] - v[tris[:, 0]], v[tris[:, 2]] - v[tris[:, 0]])
-    flip = np.einsum("ij,ij->i", n, v[tris[:, 0]] - c) < 0
-    tris[flip] = tris[flip][:, [0, 2, 1]]
-    return v, tris
+    return pts[verts], remap[tris]
 
 
 def _reduce(points, max_verts=MAX_HULL_VERTS):
     """Hull with at most max_verts vertices: greedy inside-out construction -- start from the
     axis extremes and repeatedly add the hull vertex that lies farthest outside the current
     polytope (the vertex-limited quick-hull PhysX cooking performs, [ext])."""
-    from scipy.spatial import ConvexHull, QhullError
-
     v, t = _qhull(points)
     if len(v) <= max_verts:
         return Hull(v, t)
@@ -64,11 +113,11 @@ def _reduce(points, max_verts=MAX_HULL_VERTS):
             if j not in sel:
                 sel.append(j)
     while len(sel) < max_verts:
-        try:
-            h = ConvexHull(v[sel])
-        except QhullError:
-            h = ConvexHull(v[sel], qhull_options="QJ")
-        d = (v @ h.equations[:, :3].T + h.equations[:, 3]).max(axis=1)
+        tr = native_hull(v[sel])
+        if tr is None:
+            break
+        nrm, off = _hull_planes(v[sel], tr)
+        d = (v @ nrm.T + off).max(axis=1)
         d[sel] = -np.inf
         j = int(np.argmax(d))
         if d[j] <= 1e-12:

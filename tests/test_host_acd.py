@@ -163,3 +163,47 @@ def test_solid_volume_of_intersecting_closed_shells_counts_the_overlap_once(sl):
     v = hulls._solid_volume(cm)
     assert v < 0.004 * 0.9                                                         # not the doubly counted 0.004 ...
     assert v == pytest.approx(0.003, rel=0.12)                                     # ... but the union, to the voxel grid's resolution
+
+
+def test_native_quick_hull_matches_qhull(sl):
+    """slhip_host_convex_hull (csrc/slhip_hull.cpp) against SciPy's Qhull, which it replaced on the product path: the same hull
+    vertices and volume on random clouds, lattice points (coplanar / collinear points are no vertices), a cube; a flat cloud still
+    yields a (joggled, thin) hull; slhip_host_fill_holes against ndimage.binary_fill_holes."""
+    from scipy import ndimage
+    from scipy.spatial import ConvexHull
+
+    from stillleben_amd import _abi, hulls
+
+    rng = np.random.default_rng(3)
+    for n in (4, 9, 100, 3000):
+        p = rng.standard_normal((n, 3)) * rng.uniform(0.01, 5.0, 3)
+        tr = hulls.native_hull(p)
+        h = ConvexHull(p)
+        assert set(np.unique(tr).tolist()) == set(h.vertices.tolist())
+        assert hulls.hull_volume(p) == pytest.approx(h.volume, rel=1e-12)
+        # outward, closed: every directed edge has its opposite
+        e = np.concatenate([tr[:, [0, 1]], tr[:, [1, 2]], tr[:, [2, 0]]])
+        assert set(map(tuple, e.tolist())) == set(map(tuple, e[:, ::-1].tolist()))
+        c = p[np.unique(tr)].mean(axis=0)
+        nrm = np.cross(p[tr[:, 1]] - p[tr[:, 0]], p[tr[:, 2]] - p[tr[:, 0]])
+        assert (np.einsum("ij,ij->i", nrm, p[tr[:, 0]] - c) > 0).all()
+    g = np.array([[i, j, k] for i in range(7) for j in range(5) for k in range(4)], float)
+    assert len(np.unique(hulls.native_hull(g))) == 8 and hulls.hull_volume(g) == pytest.approx(6 * 4 * 3, rel=1e-12)
+    flat = np.concatenate([rng.uniform(-1, 1, (40, 2)), np.zeros((40, 1))], 1)
+    assert hulls.hull_volume(flat) == 0.0
+    v, t = hulls._qhull(flat)
+    assert len(v) >= 3 and len(t) >= 4
+    with pytest.raises(ValueError):
+        hulls._qhull(np.zeros((5, 3)))
+    # the solid fill: a closed box shell fills, a shell with a hole does not
+    grid = np.zeros((12, 10, 9), np.uint8)
+    grid[2:9, 2:8, 2:7] = 1
+    grid[3:8, 3:7, 3:6] = 0
+    for hole in (False, True):
+        a = grid.copy()
+        if hole:
+            a[5, 5, 2] = 0
+        want = ndimage.binary_fill_holes(a.astype(bool))
+        b = np.ascontiguousarray(a)
+        assert _abi.lib().slhip_host_fill_holes(b.ctypes.data, *b.shape) == 0
+        assert np.array_equal(b.astype(bool), want)
