@@ -1053,6 +1053,20 @@ struct ContactList {
     __device__ __forceinline__ float ln(int i) const { return i < n_lds ? lds[i].ln : glb[i].ln; }
 };
 
+// Developer build -DSLHIP_ROW_PROFILE (tools/row_profile.py): shader-clock stamps (s_memtime) around the parts of a contact row of the
+// LDS-resident sweep, summed over the lane pairs' first lanes -- [0] rows, [1] cycles from the row's start until its contact has
+// arrived from LDS, [2] the normal row's arithmetic (velocity at the point, DPP swap, impulse, both bodies updated), [3] patches,
+// [4] cycles of a patch's friction rows (two anchors, or one), [5] group visits, [6] cycles of a visit outside its rows (body
+// registers in / out, set-up).  A stamp costs an s_memtime + s_waitcnt: the figures are upper bounds of the unstamped code.
+#ifdef SLHIP_ROW_PROFILE
+__device__ unsigned long long g_row_prof[8];
+#define ROWP_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define ROWP_ADD(slot_, val_) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_row_prof[slot_], (unsigned long long)(val_)); } while (0)
+#else
+#define ROWP_STAMP(v)
+#define ROWP_ADD(slot_, val_)
+#endif
+
 // (the group lies in the LDS-resident part of the list: every row reads its contact where it needs it -- LDS latency is short, and
 // carrying a prefetched contact around the loop costs eighteen register moves per row)
 template <class Body>
@@ -1060,6 +1074,10 @@ __device__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib,
                             bool biased, float plane_mu_s, float plane_mu_d)
 {
     if (begin >= end) return;
+    ROWP_STAMP(tg0);
+#ifdef SLHIP_ROW_PROFILE
+    unsigned long long rows_cyc = 0ull;
+#endif
     const bool has_b = ib >= 0;
     const int mine = side ? ib : ia;
     BodyRegs M;
@@ -1080,7 +1098,12 @@ __device__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib,
     float nsum = 0.0f;
     int p0 = begin;
     for (int ci = begin; ci < end; ++ci) {
+        ROWP_STAMP(tr0);
         const Contact c = ac[ci];
+#ifdef SLHIP_ROW_PROFILE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        ROWP_STAMP(tr1);
         if (c.til < 0.0f) { nsum = 0.0f; p0 = c.kt1 < 0.0f ? ci + 1 : ci; }   // (behind the patch's centre row, if it has one)
         const v3 r = side ? c.rb : c.ra;
         v3 pv = add(M.v, cross(M.w, r));
@@ -1095,7 +1118,12 @@ __device__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib,
         if (side == 0) ac[ci].ln = ln;
         nsum = nsum + ln;
         const bool last = ci + 1 == end || ac[ci + 1].til < 0.0f;
+#ifdef SLHIP_ROW_PROFILE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        { ROWP_STAMP(tr2); ROWP_ADD(0, 1); ROWP_ADD(1, tr1 - tr0); ROWP_ADD(2, tr2 - tr1); rows_cyc += tr2 - tr0; }
+#endif
         if (!last) continue;
+        ROWP_STAMP(tf0);
         const int anchors = ci - p0 >= 1 ? 2 : 1;
         const float share = anchors == 2 ? 0.5f * nsum : nsum;
         for (int ai = 0; ai < anchors; ++ai) {
@@ -1118,8 +1146,15 @@ __device__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib,
             apply_mine(M, rq, madd(scale(t1, sgn * d1), t2, sgn * d2));
             if (side == 0) { ac[p0 + ai].lt1 = l1; ac[p0 + ai].lt2 = l2; }
         }
+#ifdef SLHIP_ROW_PROFILE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        { ROWP_STAMP(tf1); ROWP_ADD(3, 1); ROWP_ADD(4, tf1 - tf0); rows_cyc += tf1 - tf0; }
+#endif
     }
     if (M.dynamic) { wbs[mine].v = M.v; wbs[mine].w = M.w; }
+#ifdef SLHIP_ROW_PROFILE
+    { ROWP_STAMP(tg1); ROWP_ADD(5, 1); ROWP_ADD(6, (tg1 - tg0) - rows_cyc); }
+#endif
 }
 
 // what the friction rows need of a patch's anchor contact, kept from the moment it passes through its normal row (no second
@@ -1589,6 +1624,18 @@ extern "C" int slhip_settle_timings(float avg_ms_out[5], uint32_t launches_out[5
 {
     return settle_timings_read(avg_ms_out, launches_out, nullptr, nullptr, 0, nullptr);
 }
+
+#ifdef SLHIP_ROW_PROFILE
+// developer build only: reads and clears the row profile (tools/row_profile.py)
+extern "C" int slhip_settle_row_profile(unsigned long long out[8])
+{
+    SLHIP_CHECK(hipDeviceSynchronize());
+    SLHIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_row_prof), 8 * sizeof(unsigned long long)));
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    SLHIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_row_prof), zero, sizeof(zero)));
+    return 0;
+}
+#endif
 
 static int g_last_solve_lds = 0;   // LDS bytes per solver wave of the last lockstep slhip_settle call (measurement read-out)
 extern "C" int slhip_settle_solver_wave_lds(void) { return g_last_solve_lds; }
