@@ -1053,10 +1053,11 @@ struct ContactList {
     __device__ __forceinline__ float ln(int i) const { return i < n_lds ? lds[i].ln : glb[i].ln; }
 };
 
-// Developer build -DSLHIP_ROW_PROFILE (tools/row_profile.py): shader-clock stamps (s_memtime) around a lane pair's visit of a group
-// in the LDS-resident sweep, summed over the waves' first lanes -- [0] normal rows, [3] patches, [5] group visits, [6] cycles of
-// the visits (body registers in, rows, friction rows, registers out).  (The stamps around the PARTS of a row -- profiles/r06/
-// row_profile.txt, the loop before the prefetch -- are in the history: commit "tools/row_profile.py".)
+// Developer build -DSLHIP_ROW_PROFILE (tools/row_profile.py): shader-clock stamps (s_memtime) around the parts of a contact row of the
+// LDS-resident sweep, summed over the lane pairs' first lanes -- [0] rows, [1] cycles from the row's start until its contact has
+// arrived from LDS, [2] the normal row's arithmetic (velocity at the point, DPP swap, impulse, both bodies updated), [3] patches,
+// [4] cycles of a patch's friction rows (two anchors, or one), [5] group visits, [6] cycles of a visit outside its rows (body
+// registers in / out, set-up).  A stamp costs an s_memtime + s_waitcnt: the figures are upper bounds of the unstamped code.
 #ifdef SLHIP_ROW_PROFILE
 __device__ unsigned long long g_row_prof[8];
 #define ROWP_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
@@ -1066,22 +1067,17 @@ __device__ unsigned long long g_row_prof[8];
 #define ROWP_ADD(slot_, val_)
 #endif
 
-// what the friction rows need of a patch's anchor contact, kept from the moment it passes through its normal row (no second
-// fetch: a round trip to LDS -- or, beyond the LDS-resident part, to the L2 -- per anchor and sweep)
-struct Anchor { v3 r, n; float til, kt1, kt2, lt1, lt2; };
-
-// The group lies in the LDS-resident part of the list.  Round 6 measured a row of this loop with s_memtime stamps
-// (tools/row_profile.py, profiles/r06/row_profile.txt): 228 cycles until the row's 72-byte contact has arrived from LDS, 337 cycles
-// of arithmetic, and 1 457 cycles of friction rows per patch, two thirds of them the anchors' contacts fetched a second time and a
-// third look at the list for the next contact's head mark.  Hence: the NEXT contact is fetched while the current row runs -- two
-// register sets taken in turns (rows come in pairs: no copy from one to the other, which is what made round 4's prefetch lose) --,
-// the head mark of the next contact comes with it, and a patch's anchors stay in registers from their normal rows to the friction
-// rows.  Same arithmetic in the same order: the same bits.
+// (the group lies in the LDS-resident part of the list: every row reads its contact where it needs it -- LDS latency is short, and
+// carrying a prefetched contact around the loop costs eighteen register moves per row)
 template <class Body>
-__device__ __forceinline__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib, int side, Body* wbs, float inv_dt,
+__device__ void solve_group_lds(Contact* ac, int begin, int end, int ia, int ib, int side, Body* wbs, float inv_dt,
                             bool biased, float plane_mu_s, float plane_mu_d)
 {
     if (begin >= end) return;
+    ROWP_STAMP(tg0);
+#ifdef SLHIP_ROW_PROFILE
+    unsigned long long rows_cyc = 0ull;
+#endif
     const bool has_b = ib >= 0;
     const int mine = side ? ib : ia;
     BodyRegs M;
@@ -1097,42 +1093,21 @@ __device__ __forceinline__ void solve_group_lds(Contact* ac, int begin, int end,
     const float mu_d = 0.5f * (wbs[ia].mu_d + (has_b ? wbs[ib].mu_d : plane_mu_d));
     const float sgn = side ? -1.0f : 1.0f;
     // Friction patches (oracle solve_patch; PhysX's ePATCH model): the contacts of one manifold are contiguous, the first one
-    // carries the head mark (a patch of three or four points has its centre row there: no anchor).  Normal rows in order; when the
-    // patch ends, the friction rows of its (at most two) anchors -- its first two POINTS -- against their share of the patch's
-    // accumulated normal impulse.
+    // carries the head mark.  Normal rows in order; when the patch ends, the friction rows of its (at most two) anchors -- its
+    // first two contacts -- against their share of the patch's accumulated normal impulse.
     float nsum = 0.0f;
-    int npts = 0, p0 = begin;          // points of the current patch seen so far; its first point's index
-    // (the anchors as plain values: as structs behind the lambdas' references they were kept in scratch memory)
-    v3 a0r = V(0, 0, 0), a0n = V(0, 0, 0), a1r = V(0, 0, 0), a1n = V(0, 0, 0);
-    float a0til = 0.0f, a0kt1 = 0.0f, a0kt2 = 0.0f, a0lt1 = 0.0f, a0lt2 = 0.0f;
-    float a1til = 0.0f, a1kt1 = 0.0f, a1kt2 = 0.0f, a1lt1 = 0.0f, a1lt2 = 0.0f;
-    auto friction_row = [&](v3 qr, v3 qn, float qtil, float qkt1, float qkt2, float qlt1, float qlt2, int at, float share) __attribute__((always_inline)) {
-        const v3 pv = add(M.v, cross(M.w, qr));
-        const v3 d = sub(pv, pair_swap(pv));
-        v3 t1, t2;
-        tangents_cached(qn, fabsf(qtil), &t1, &t2);
-        float l1 = qlt1 - (sgn * dot(d, t1)) * qkt1;
-        float l2 = qlt2 - (sgn * dot(d, t2)) * qkt2;
-        const float mag2 = fmaf(l2, l2, l1 * l1);
-        const float lim_s = mu_s * share;
-        if (mag2 > lim_s * lim_s) {
-            const float mag = sqrtf(mag2);
-            const float k = (mu_d * share) / mag;
-            l1 *= k; l2 *= k;
-        }
-        const float d1 = l1 - qlt1, d2 = l2 - qlt2;
-        apply_mine(M, qr, madd(scale(t1, sgn * d1), t2, sgn * d2));
-        if (side == 0) { ac[at].lt1 = l1; ac[at].lt2 = l2; }
-    };
-    // one row: `c` is contact ci, `last` = the patch ends with it (the list ends, or the next contact carries the head mark)
-    auto row = [&](const Contact& c, int ci, bool last) __attribute__((always_inline)) {
-        bool point = true;
-        if (c.til < 0.0f) { nsum = 0.0f; npts = 0; point = !(c.kt1 < 0.0f); p0 = point ? ci : ci + 1; }
-        // (component by component: a select between two members of a struct in registers is otherwise folded into a load through
-        // a selected pointer, and the two contacts end up in scratch memory)
-        const v3 r = V(side ? c.rb.x : c.ra.x, side ? c.rb.y : c.ra.y, side ? c.rb.z : c.ra.z);
-        const v3 pv = add(M.v, cross(M.w, r));
-        const v3 d = sub(pv, pair_swap(pv));        // side 0: a - b, side 1: b - a
+    int p0 = begin;
+    for (int ci = begin; ci < end; ++ci) {
+        ROWP_STAMP(tr0);
+        const Contact c = ac[ci];
+#ifdef SLHIP_ROW_PROFILE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        ROWP_STAMP(tr1);
+        if (c.til < 0.0f) { nsum = 0.0f; p0 = c.kt1 < 0.0f ? ci + 1 : ci; }   // (behind the patch's centre row, if it has one)
+        const v3 r = side ? c.rb : c.ra;
+        v3 pv = add(M.v, cross(M.w, r));
+        v3 d = sub(pv, pair_swap(pv));              // side 0: a - b, side 1: b - a
         const float vn = sgn * dot(d, c.n);
         const float target = biased ? c.err : c.bounce;   // prep_contact
         float dl = (target - vn) * c.kn;
@@ -1142,60 +1117,56 @@ __device__ __forceinline__ void solve_group_lds(Contact* ac, int begin, int end,
         apply_mine(M, r, scale(c.n, sgn * dl));
         if (side == 0) ac[ci].ln = ln;
         nsum = nsum + ln;
-        {
-            // (value selects, not two branches that assign to different variables: the compiler folds those into ONE store through
-            // a selected address -- and moves the anchors to scratch memory to have addresses to select)
-            const bool f0 = point && npts == 0, f1 = point && npts == 1;
-            a0r = vsel(f0, r, a0r); a0n = vsel(f0, c.n, a0n);
-            a0til = f0 ? c.til : a0til; a0kt1 = f0 ? c.kt1 : a0kt1; a0kt2 = f0 ? c.kt2 : a0kt2; a0lt1 = f0 ? c.lt1 : a0lt1; a0lt2 = f0 ? c.lt2 : a0lt2;
-            a1r = vsel(f1, r, a1r); a1n = vsel(f1, c.n, a1n);
-            a1til = f1 ? c.til : a1til; a1kt1 = f1 ? c.kt1 : a1kt1; a1kt2 = f1 ? c.kt2 : a1kt2; a1lt1 = f1 ? c.lt1 : a1lt1; a1lt2 = f1 ? c.lt2 : a1lt2;
-            npts += point ? 1 : 0;
-        }
-        if (!last) return;
-        if (npts >= 2) {
-            const float share = 0.5f * nsum;
-            friction_row(a0r, a0n, a0til, a0kt1, a0kt2, a0lt1, a0lt2, p0, share);
-            friction_row(a1r, a1n, a1til, a1kt1, a1kt2, a1lt1, a1lt2, p0 + 1, share);
-        } else {
-            friction_row(a0r, a0n, a0til, a0kt1, a0kt2, a0lt1, a0lt2, p0, nsum);
-        }
-    };
+        const bool last = ci + 1 == end || ac[ci + 1].til < 0.0f;
 #ifdef SLHIP_ROW_PROFILE
-    const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
-    int n_patches = 0;
-    for (int k = begin; k < end; ++k) n_patches += ac[k].til < 0.0f ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        { ROWP_STAMP(tr2); ROWP_ADD(0, 1); ROWP_ADD(1, tr1 - tr0); ROWP_ADD(2, tr2 - tr1); rows_cyc += tr2 - tr0; }
 #endif
-    Contact A = ac[begin], B = A;
-    int ci = begin;
-    for (;;) {
-        bool more = ci + 1 < end;
-        if (more) B = ac[ci + 1];                  // in flight while row ci runs
-        row(A, ci, !more || B.til < 0.0f);
-        if (!more) break;
-        ++ci;
-        more = ci + 1 < end;
-        if (more) A = ac[ci + 1];
-        row(B, ci, !more || A.til < 0.0f);
-        if (!more) break;
-        ++ci;
+        if (!last) continue;
+        ROWP_STAMP(tf0);
+        const int anchors = ci - p0 >= 1 ? 2 : 1;
+        const float share = anchors == 2 ? 0.5f * nsum : nsum;
+        for (int ai = 0; ai < anchors; ++ai) {
+            const Contact q = ac[p0 + ai];
+            const v3 rq = side ? q.rb : q.ra;
+            pv = add(M.v, cross(M.w, rq));
+            d = sub(pv, pair_swap(pv));
+            v3 t1, t2;
+            tangents_cached(q.n, fabsf(q.til), &t1, &t2);
+            float l1 = q.lt1 - (sgn * dot(d, t1)) * q.kt1;
+            float l2 = q.lt2 - (sgn * dot(d, t2)) * q.kt2;
+            const float mag2 = fmaf(l2, l2, l1 * l1);
+            const float lim_s = mu_s * share;
+            if (mag2 > lim_s * lim_s) {
+                const float mag = sqrtf(mag2);
+                const float k = (mu_d * share) / mag;
+                l1 *= k; l2 *= k;
+            }
+            const float d1 = l1 - q.lt1, d2 = l2 - q.lt2;
+            apply_mine(M, rq, madd(scale(t1, sgn * d1), t2, sgn * d2));
+            if (side == 0) { ac[p0 + ai].lt1 = l1; ac[p0 + ai].lt2 = l2; }
+        }
+#ifdef SLHIP_ROW_PROFILE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        { ROWP_STAMP(tf1); ROWP_ADD(3, 1); ROWP_ADD(4, tf1 - tf0); rows_cyc += tf1 - tf0; }
+#endif
     }
     if (M.dynamic) { wbs[mine].v = M.v; wbs[mine].w = M.w; }
 #ifdef SLHIP_ROW_PROFILE
-    {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long tg1 = __builtin_amdgcn_s_memtime();
-        ROWP_ADD(0, end - begin); ROWP_ADD(3, n_patches); ROWP_ADD(5, 1); ROWP_ADD(6, tg1 - tg0);
-    }
+    { ROWP_STAMP(tg1); ROWP_ADD(5, 1); ROWP_ADD(6, (tg1 - tg0) - rows_cyc); }
 #endif
 }
 
-// ... and the group reaches beyond the LDS-resident part of the list (a scene with a wave of its own whose contacts do not all fit:
-// rare -- a call, not inlined: its register needs and its stack stay out of the common path)
+// what the friction rows need of a patch's anchor contact, kept from the moment it passes through its normal row (no second
+// fetch: beyond the LDS-resident part that would be an exposed round trip to the L2 per patch)
+struct Anchor { v3 r, n; float til, kt1, kt2, lt1, lt2; };
+
 template <class Body>
-__device__ __attribute__((noinline)) void solve_group_spilled(const ContactList ac, int begin, int end, int ia, int ib, int side, Body* wbs, float inv_dt,
+__device__ void solve_group(const ContactList ac, int begin, int end, int ia, int ib, int side, Body* wbs, float inv_dt,
                             bool biased, float plane_mu_s, float plane_mu_d)
 {
+    if (begin >= end) return;
+    if (end <= ac.n_lds) { solve_group_lds(ac.lds, begin, end, ia, ib, side, wbs, inv_dt, biased, plane_mu_s, plane_mu_d); return; }
     const bool has_b = ib >= 0;
     const int mine = side ? ib : ia;
     BodyRegs M;
@@ -1218,7 +1189,7 @@ __device__ __attribute__((noinline)) void solve_group_spilled(const ContactList 
     int ci = begin;
     bool more = true;
     float nsum = 0.0f;
-    auto normal_row = [&](Anchor* keep) __attribute__((always_inline)) {
+    auto normal_row = [&](Anchor* keep) {
         const Contact c = nxt;
         more = ci + 1 < end;
         if (more) nxt = ac.load(ci + 1);
@@ -1237,7 +1208,7 @@ __device__ __attribute__((noinline)) void solve_group_spilled(const ContactList 
         nsum = nsum + ln;
         ++ci;
     };
-    auto friction_rows = [&](const Anchor& q, int at, float share) __attribute__((always_inline)) {
+    auto friction_rows = [&](const Anchor& q, int at, float share) {
         const v3 pv = add(M.v, cross(M.w, q.r));
         const v3 d = sub(pv, pair_swap(pv));
         v3 t1, t2;
@@ -1272,15 +1243,6 @@ __device__ __attribute__((noinline)) void solve_group_spilled(const ContactList 
         }
     }
     if (M.dynamic) { wbs[mine].v = M.v; wbs[mine].w = M.w; }
-}
-
-template <class Body>
-__device__ __forceinline__ void solve_group(const ContactList ac, int begin, int end, int ia, int ib, int side, Body* wbs, float inv_dt,
-                                            bool biased, float plane_mu_s, float plane_mu_d)
-{
-    if (begin >= end) return;
-    if (end <= ac.n_lds) solve_group_lds(ac.lds, begin, end, ia, ib, side, wbs, inv_dt, biased, plane_mu_s, plane_mu_d);
-    else solve_group_spilled(ac, begin, end, ia, ib, side, wbs, inv_dt, biased, plane_mu_s, plane_mu_d);
 }
 
 // Warm start of ONE group by its lane pair (oracle: the loop before the first sweep): every contact's carried normal impulse is

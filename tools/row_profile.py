@@ -5,8 +5,8 @@ Needs the row-profile build of the library (s_memtime stamps inside solve_group_
     python tools/row_profile.py --build                 # here (cross-compile): stillleben_amd/lib/libslhip_rowprof.so
     SLHIP_LIB=stillleben_amd/lib/libslhip_rowprof.so python tools/row_profile.py [B=4096]     # on the GPU box
 
-One settle of B C2 scenes; prints the shader-clock cycles of a group visit per row (profiles/r06/row_profile.txt holds the split of
-a row into its parts, taken before the loop prefetched its contacts)."""
+One settle of B C2 scenes; prints per row / per patch / per group visit the shader-clock cycles of its parts (a stamp costs an
+s_memtime + s_waitcnt: upper bounds of the unstamped code)."""
 import ctypes as C
 import os
 import subprocess
@@ -46,8 +46,11 @@ batch.stage(scene_id_base=B)
 batch.settle()
 torch.cuda.synchronize()
 L.slhip_settle_row_profile(out)
-rows, patches, visits, cycles = float(out[0]), float(out[3]), float(out[5]), float(out[6])
-print("B=%d: %d normal rows, %d patches, %d group visits (first lane of every solver wave, LDS-resident groups)" % (B, rows, patches, visits))
-print("  per group visit: %.0f cycles, %.1f rows and %.2f patches" % (cycles / visits, rows / visits, patches / visits))
-print("  a contact row with its share of the friction rows and of the visit's set-up: %.0f cycles = %.2f us at 2.4 GHz" %
-      (cycles / rows, cycles / rows / 2400.0))
+rows, load, alu, patches, fric, visits, other = [float(out[i]) for i in range(7)]
+print("B=%d: %d normal rows, %d patches, %d group visits (lane pair 0 of every solver wave, LDS-resident groups)" % (B, rows, patches, visits))
+print("  per normal row : %.0f cycles until the contact is in registers (72 B from LDS) + %.0f cycles of arithmetic = %.0f" %
+      (load / rows, alu / rows, (load + alu) / rows))
+print("  per patch      : %.0f cycles of friction rows (%.2f rows per patch)" % (fric / patches, rows / patches))
+print("  per group visit: %.0f cycles outside the rows (body registers in / out), %.1f rows per visit" % (other / visits, rows / visits))
+print("  a contact row with its share of the friction: %.0f cycles = %.2f us at 2.4 GHz" %
+      ((load + alu + fric) / rows, (load + alu + fric) / rows / 2400.0))
