@@ -1067,6 +1067,13 @@ __device__ unsigned long long g_row_prof[8];
 #define ROWP_ADD(slot_, val_)
 #endif
 
+// Round 6 measured the parts of a row of this loop with s_memtime stamps (tools/row_profile.py, profiles/r06/row_profile.txt: 228
+// cycles until the row's 72-byte contact has arrived from LDS, 337 cycles of arithmetic, 1 457 cycles of friction rows per patch
+// of 2.8 points) and then built the loop that hides the first and halves the last -- the next contact fetched while the current
+// row runs (two register sets in turns: no copies), a patch's anchors kept in registers from their normal rows to the friction
+// rows; bit-exact (61 settle tests), 177 instead of 156 registers -- : k_w_solve 1.995 -> 1.987 ms per launch over 32 768 scenes.
+// The row's latency is not what bounds the kernel (the SIMD's other wave fills the wait); taken back (git history:
+// "k_w_solve: the next contact is fetched while the current row runs").
 // (the group lies in the LDS-resident part of the list: every row reads its contact where it needs it -- LDS latency is short, and
 // carrying a prefetched contact around the loop costs eighteen register moves per row)
 template <class Body>
