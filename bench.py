@@ -466,8 +466,10 @@ def main():
     from stillleben_amd.parallel import BatchGatherer, SlhipComm
 
     t_prep = time.perf_counter()
-    meshes = synthetic.ycb_like_meshes(seed=0, hulls=args.hulls)   # (before the device is touched: the native decomposition forks workers)
+    # (the native decomposition forks workers: before the device is touched)
+    hull_sets = synthetic.native_hull_sets(seed=0) if args.hulls == "native" else "vhacd"
     sl.init_cuda(local_rank)
+    meshes = synthetic.ycb_like_meshes(seed=0, hulls=hull_sets)
     table = sl.AssetTable(meshes)                 # once per process: the 21 classes' vertices, textures, hulls -> HBM
     if args.render_chunk is None:
         args.render_chunk = 1024

@@ -248,18 +248,33 @@ def _native_hulls(cm):
     return H._compute_hulls(cm, False)
 
 
+def native_hull_sets(seed=0, target_verts=8192):
+    """The in-tree decomposition of the 21 classes (one list of hulls per class), computed in worker processes.  Needs no context:
+    a caller that is about to initialise a device does this first (the workers are forked) and hands the result to
+    ycb_like_meshes(hulls=<the list>)."""
+    from concurrent.futures import ProcessPoolExecutor
+
+    made = [make_class_mesh(name, seed, target_verts, 64) for name in YCB_CLASSES]   # (the texture does not enter the geometry)
+    with ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        return list(ex.map(_native_hulls, [cm for cm, _ in made]))
+
+
 def ycb_like_meshes(seed=0, target_verts=8192, tex_size=1024, hulls="vhacd"):
     """21 sl.Mesh objects named after the YCB-Video classes, class_index = i + 1
     (reference examples/ycb.py:46-48).  hulls: "vhacd" (the decompositions the reference's V-HACD gave this very geometry,
     shipped as data/ycb_like_hulls_seed<seed>.npz by oracle/ref_build/gen_hulls.py; for another seed / size the in-tree
-    decomposition of hulls._compute_hulls computes them), "native" (always the in-tree decomposition) or "parts" (by
-    construction: one hull per primitive part)."""
+    decomposition of hulls._compute_hulls computes them), "native" (always the in-tree decomposition), "parts" (by
+    construction: one hull per primitive part) or a list of hull lists per class (native_hull_sets)."""
     from . import hulls as H
     from .mesh import Mesh
 
     made = [make_class_mesh(name, seed, target_verts, tex_size) for name in YCB_CLASSES]
     sets = [h for _, h in made]
-    if hulls in ("vhacd", "native"):
+    if isinstance(hulls, list):               # precomputed (native_hull_sets)
+        if len(hulls) != len(made):
+            raise ValueError("hulls: one list of hulls per class expected")
+        sets = hulls
+    elif hulls in ("vhacd", "native"):
         shipped = _shipped_hulls(seed, [cm for cm, _ in made]) if (hulls == "vhacd" and target_verts == 8192) else None
         if shipped is not None:
             sets = shipped
