@@ -714,7 +714,8 @@ def load_counters():
     """SQ / HBM counters of the dominant kernels, collected by tools/collect_counters.py from separate rocprofv3 --pmc
     passes at the bench shape and committed under profiles/ (the latest round's file wins).  `stale` says that the kernel
     sources changed since the counters were taken: per-instruction figures are then not quoted."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    rounds = sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit()), reverse=True)
+    for rnd in rounds:
         path = os.path.join(ROOT, "profiles", rnd, "counters.json")
         if os.path.exists(path):
             with open(path) as f:
