@@ -1672,31 +1672,6 @@ extern "C" int slhip_settle_scratch_bytes(uint32_t n_scenes, const slhip_settle_
     return 0;
 }
 
-// the heavy lane's stream and a ring of events that order it against the caller's stream (one per device of the process)
-constexpr int kHeavyChainDefault = 384;
-struct HeavyLane {
-    hipStream_t stream = nullptr;
-    hipEvent_t events[64];
-    int n_events = 0, next = 0;
-    hipEvent_t next_event() { hipEvent_t e = events[next]; next = (next + 1) % n_events; return e; }
-};
-static HeavyLane* heavy_lane()
-{
-    static HeavyLane lanes[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    HeavyLane& L = lanes[dev];
-    if (!L.stream) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, hi) != hipSuccess) { L.stream = nullptr; return nullptr; }
-        for (L.n_events = 0; L.n_events < 64; ++L.n_events)
-            if (hipEventCreateWithFlags(&L.events[L.n_events], hipEventDisableTiming) != hipSuccess) break;
-        if (L.n_events < 8) return nullptr;
-    }
-    return &L;
-}
-
 extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scenes, slhip_body* d_bodies,
                             const slhip_hull* d_hulls, const float* d_hull_verts, const slhip_settle_params* params,
                             void* d_scratch, uint64_t scratch_bytes, void* stream_)
@@ -1782,42 +1757,9 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
         // (probe: the frames from SLHIP_SETTLE_SWITCH_FRAME on in the persistent form -- both forms work on the same state)
         uint32_t lockstep_frames = params->frames;
         if (const char* e = getenv("SLHIP_SETTLE_SWITCH_FRAME")) { const int v = atoi(e); if (v >= 0 && (uint32_t)v < params->frames) lockstep_frames = (uint32_t)v; }
-        // The heavy lane (k_w_heavy, WideBufs.exile): every launch of the lockstep pipeline ends with the batch's slowest scene -- in
-        // the pile-up phase a handful of scenes whose solver chains run to hundreds of rows (nested concave shapes).  A scene whose chain
-        // reaches `heavy_chain` rows at the end of a frame leaves the pipeline and is carried through its remaining frames by a wave of
-        // its own on a second stream, picked up every other frame while scenes may still leave (the first 60 % of the call's frames).
-        // SLHIP_HEAVY_CHAIN=0 switches it off, another value sets the threshold.
-        int heavy_chain = params->frames >= 20u && lockstep_frames == params->frames ? kHeavyChainDefault : 0;
-        if (const char* e = getenv("SLHIP_HEAVY_CHAIN")) { const int v = atoi(e); if (v >= 0 && params->frames >= 2u && lockstep_frames == params->frames) heavy_chain = v; }
-        const uint32_t exile_until = heavy_chain > 0 ? (params->frames * 3u) / 5u : 0u;
-        uint32_t picked_up = 0u;
-        HeavyLane* lane = nullptr;
-        if (heavy_chain > 0) {
-            lane = heavy_lane();
-            if (!lane) heavy_chain = 0;
-        }
-        WideBufs Wh = W;                                   // the heavy lane's view: 64 KB of LDS for its scene's contacts, nobody leaves it
-        Wh.solve_lds = max(solve_lds, 64 * 1024);
-        Wh.heavy_chain = 0;
-        const int heavy_lds = max(max(BL.total, FL.total), Wh.solve_lds);
-        if (heavy_chain > 0) {
-            SLHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_heavy), hipFuncAttributeMaxDynamicSharedMemorySize, heavy_lds));
-            SLHIP_CHECK(hipMemsetAsync(W.exile, 0, 2 * sizeof(unsigned), stream));
-        }
-        auto pick_up = [&](uint32_t frames_done) -> int {
-            hipEvent_t ev = lane->next_event();
-            SLHIP_CHECK(hipEventRecord(ev, stream));
-            SLHIP_CHECK(hipStreamWaitEvent(lane->stream, ev, 0));
-            k_w_heavy<<<kHeavyBlocks, 64, heavy_lds, lane->stream>>>(d_scenes, d_bodies, d_hulls, d_hull_verts, *params, Wh, BL, FL, pc, drive_w,
-                                                                     n_scenes, picked_up, frames_done);
-            picked_up = frames_done;
-            return 0;
-        };
         uint32_t step = params->resume;
         for (uint32_t f = 0; f < lockstep_frames; ++f)
             for (uint32_t sub = 0; sub < params->substeps; ++sub, ++step) {
-                WideBufs Wl = W;                           // the lockstep pipeline's view of this step
-                Wl.heavy_chain = f < exile_until ? heavy_chain : 0;
                 // (a caller that never reads the timings must not grow the lists for ever: sampling stops at kMaxTimedEvents)
                 constexpr size_t kMaxTimedEvents = 1u << 16;
                 bool timed = g_settle_timing.on && step % g_settle_timing_every == 0u && g_settle_timing.events.size() < kMaxTimedEvents;
@@ -1837,25 +1779,16 @@ extern "C" int slhip_settle(const slhip_settle_scene* d_scenes, uint32_t n_scene
                 if (timed) (void)hipEventRecord(ev[2], stream);
                 k_w_manifold<<<work_grid, 64, 0, stream>>>(d_hull_verts, *params, W, list_stride);
                 if (timed) (void)hipEventRecord(ev[3], stream);
-                k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, Wl, FL, pc, step + 1u);
+                k_w_finish<<<n_scenes, 64, FL.total, stream>>>(d_scenes, d_bodies, *params, W, FL, pc, step + 1u);
                 if (timed) (void)hipEventRecord(ev[4], stream);
-                k_w_solve<<<n_scenes, 64, solve_lds, stream>>>(d_scenes, d_bodies, *params, Wl, drive_w,
-                                                               sub + 1 == params->substeps ? (int)(f + 1u) : 0, n_scenes);
+                k_w_solve<<<n_scenes, 64, solve_lds, stream>>>(d_scenes, d_bodies, *params, W, drive_w,
+                                                               sub + 1 == params->substeps ? 1 : 0, n_scenes);
                 if (timed) {
                     (void)hipEventRecord(ev[5], stream);
                     for (int k = 0; k < 5; ++k) g_settle_timing.pending.push_back({k, ev[k], ev[k + 1], step});
                     for (int k = 0; k < 6; ++k) g_settle_timing.events.push_back(ev[k]);
                 }
-                // pick-ups: every other frame while scenes may leave, and once more when they no longer do
-                if (heavy_chain > 0 && sub + 1 == params->substeps && f < exile_until && ((f & 1u) == 1u || f + 1u == exile_until))
-                    if (pick_up(f + 1u) != 0) return -1;
             }
-        if (heavy_chain > 0) {
-            // the call ends when the heavy lane's scenes are through as well
-            hipEvent_t ev = lane->next_event();
-            SLHIP_CHECK(hipEventRecord(ev, lane->stream));
-            SLHIP_CHECK(hipStreamWaitEvent(stream, ev, 0));
-        }
         if (lockstep_frames < params->frames) {
             slhip_settle_params rest = *params;
             rest.resume = step;

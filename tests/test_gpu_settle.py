@@ -778,33 +778,3 @@ def test_manipulation_steps_equal_one_call(sl, oracle):
     assert np.array_equal(one["pose"].reshape(-1, 4, 4), np.stack([o._pose for o in scene._objects]))
     assert np.array_equal(one["lin_vel"][:, :3], np.stack([o._linear_velocity for o in scene._objects]))
     assert float(scene.objects[1].pose()[0, 3]) > 0.105      # the tool pushed its neighbour
-
-
-@pytest.mark.parametrize("chain", [1, 24])
-def test_heavy_lane_hand_over_gives_the_same_bits(sl, oracle, monkeypatch, chain):
-    """The heavy lane of the lockstep form (k_w_heavy): a scene whose solver chain reaches SLHIP_HEAVY_CHAIN rows
-    at the end of a frame leaves the six-launches-per-step pipeline and is carried through its remaining frames by a wave of its own
-    on a second stream -- the same per-scene functions, so the same bits.  With the threshold at 1 every scene that touches anything
-    leaves at its first frame end, at 24 the piles leave one after the other while the others go on in lockstep: both give the
-    oracle's bodies, and what the scratch keeps (resume) is the complete state."""
-    monkeypatch.setenv("SLHIP_SETTLE_PERSISTENT", "0")
-    monkeypatch.setenv("SLHIP_HEAVY_CHAIN", str(chain))
-    cube = scaled(sl, S.CUBE, 0.15)
-    bunny = scaled(sl, S.BUNNY, 0.25)
-    scenes = []
-    for k in range(24):
-        scene = sl.Scene((160, 120), seed=300 + k)
-        for i in range(4 + k % 5):
-            scene.add_object(sl.Object(bunny if (i + k) % 4 == 1 else cube))
-        scenes.append(scene)
-    from stillleben_amd import physics
-
-    se = physics.settle_engine()
-    planes = [(physics.prepare_tabletop(sc), physics.PLANE_HALF_Z) for sc in scenes]
-    srec, bodies = SB.build_settle_batch(scenes, se.pool, planes)
-    prm = SB.default_params(tabletop=True, frames=40)
-    gpu = se.run(srec, bodies.copy(), prm)
-    hulls, verts = se.pool.arrays()
-    ref = bodies.copy()
-    oracle.settle(srec, ref, hulls, verts, SB.sizing_hints(prm, srec, bodies, hulls))
-    assert_bodies_equal(gpu, ref)
