@@ -33,7 +33,7 @@ def scaled(path, diag):
 cube_s, cube_l, bunny = scaled(S.CUBE, 0.12), scaled(S.CUBE, 0.3), scaled(S.BUNNY, 0.2)
 ycb = synthetic.ycb_like_meshes(seed=0, tex_size=8 if False else 64)
 se = physics.settle_engine()
-fields = ("pose", "lin_vel", "ang_vel", "separation", "flags", "stuck_counter", "wake_counter")
+fields = ("pose", "lin_vel", "ang_vel", "separation", "flags", "stuck_counter", "wake_counter", "stab")
 bad = 0
 t0 = time.time()
 for k in range(N):

@@ -28,7 +28,7 @@ ref = bodies.copy()
 t = time.time()
 oracle.settle(srec, ref, hulls, verts, prm)
 bad = 0
-for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "stuck_counter", "wake_counter"):
+for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "stuck_counter", "wake_counter", "stab"):
     a, b = np.ascontiguousarray(gpu[name]), np.ascontiguousarray(ref[name])
     if not np.array_equal(a.view(np.uint8), b.view(np.uint8)):
         bad += 1
