@@ -75,6 +75,9 @@ for k in range(N):
     gpu = se.run(srec, bodies.copy(), prm)
     hulls, verts = se.pool.arrays()
     ref = bodies.copy()
+    # the host path grows the lists when a heap needs it (SettleEngine.run): the oracle gets the capacities that run used
+    for key in ("max_hull_pairs_per_scene", "max_contacts_per_scene", "max_body_pairs_per_scene"):
+        prm[key] = se.last_params[key]
     oracle.settle(srec, ref, hulls, verts, prm)
     ov_gpu = se.overlap(srec, bodies)                          # slhip_overlap_any on the initial state
     ov_ref = oracle.overlap_any(srec, bodies, hulls, verts)

@@ -26,6 +26,9 @@ gpu = se.run(srec, bodies.copy(), prm)
 hulls, verts = se.pool.arrays()
 ref = bodies.copy()
 t = time.time()
+# the host path grows the lists when a heap needs it (SettleEngine.run): the oracle gets the capacities that run used
+for key in ("max_hull_pairs_per_scene", "max_contacts_per_scene", "max_body_pairs_per_scene"):
+    prm[key] = se.last_params[key]
 oracle.settle(srec, ref, hulls, verts, prm)
 bad = 0
 for name in ("pose", "lin_vel", "ang_vel", "separation", "flags", "stuck_counter", "wake_counter", "stab"):
