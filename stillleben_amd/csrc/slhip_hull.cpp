@@ -29,6 +29,8 @@ struct Face {
     P3 n;            // unit outward normal
     double d;        // n . x = d on the plane
     std::vector<int> outside;
+    int far_pt;      // the farthest of them, and its height (kept as points are filed: the search for the next point to add walks the
+    double far_h;    // faces, not their points)
     bool alive;
 };
 
@@ -49,6 +51,7 @@ struct Hull {
         f.d = dot(f.n, p[a]);
         f.alive = true;
         f.outside.clear();
+        f.far_pt = -1; f.far_h = 0.0;
         return true;
     }
 };
@@ -111,8 +114,16 @@ bool quick_hull(const P3* pts, int n, std::vector<int>& tris)
         H.faces.push_back(f);
     }
     auto assign = [&](int i, size_t first) {
-        for (size_t k = first; k < H.faces.size(); ++k)
-            if (H.faces[k].alive && H.height(H.faces[k], i) > H.eps) { H.faces[k].outside.push_back(i); return; }
+        for (size_t k = first; k < H.faces.size(); ++k) {
+            Face& f = H.faces[k];
+            if (!f.alive) continue;
+            const double h = H.height(f, i);
+            if (h > H.eps) {
+                f.outside.push_back(i);
+                if (h > f.far_h) { f.far_h = h; f.far_pt = i; }      // (ties: the first point filed)
+                return;
+            }
+        }
     };
     for (int i = 0; i < n; ++i)
         if (i != a && i != b && i != c && i != d) assign(i, 0);
@@ -124,11 +135,7 @@ bool quick_hull(const P3* pts, int n, std::vector<int>& tris)
         double hbest = 0.0;
         for (size_t k = 0; k < H.faces.size(); ++k) {
             const Face& f = H.faces[k];
-            if (!f.alive) continue;
-            for (int i : f.outside) {
-                const double h = H.height(f, i);
-                if (h > hbest) { hbest = h; fbest = (int)k; pbest = i; }
-            }
+            if (f.alive && f.far_pt >= 0 && f.far_h > hbest) { hbest = f.far_h; fbest = (int)k; pbest = f.far_pt; }
         }
         if (fbest < 0) break;
         seen.clear();
