@@ -43,7 +43,8 @@ def parse():
                          "is 2 MB per scene: 65 GB at 32768)")
     ap.add_argument("--render-chunk", type=int, default=None,
                     help="scenes per render launch sequence (fewer, larger sequences: every kernel boundary is a chance for "
-                         "queued settle workgroups to take the freed SIMDs); default 1024")
+                         "queued settle workgroups to take the freed SIMDs); default 512: the same rate as 1024 (round 6, 6-step runs: 9 926 / 9 989 "
+                         "against 9 931 / 9 995) with two 30 GB render scratch sets instead of two 60 GB ones -- peak HBM 175 GB instead of 262")
     ap.add_argument("--settle-streams", type=int, default=1,
                     help="settle launches kept in flight on streams of their own (the render of the previous step always "
                          "overlaps the settle of the next one)")
@@ -472,7 +473,7 @@ def main():
     meshes = synthetic.ycb_like_meshes(seed=0, hulls=hull_sets)
     table = sl.AssetTable(meshes)                 # once per process: the 21 classes' vertices, textures, hulls -> HBM
     if args.render_chunk is None:
-        args.render_chunk = 1024
+        args.render_chunk = 512
     args.render_chunk = min(args.render_chunk, args.batch)
     pipe = Pipeline(sl, table, args.batch, args.render_chunk, not args.no_ssao, max(1, args.settle_streams), seed=20260929, rank=rank,
                     render_streams=min(max(1, args.render_streams), 2), pair_contact_budget=args.pair_budget)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Collects, ON THE GPU BOX, everything bench.py's roofline objects quote, at the bench shape
-(32768 scenes per step, 1024-scene render sequences), and writes it under gpurun_out/<round>/:
+(32768 scenes per step, 512-scene render sequences), and writes it under gpurun_out/<round>/:
 
   kernel_stats.csv          rocprofv3 --kernel-trace --stats of the default `python bench.py`
   bench_under_rocprof.json  the JSON line printed by that very run (its HIP-event durations must agree with the CSV)
@@ -57,7 +57,7 @@ def pmc(out, tag, counters, cmd):
 def main():
     out = os.path.abspath(sys.argv[1])
     os.makedirs(out, exist_ok=True)
-    batch, chunk = 32768, 1024     # bench.py defaults
+    batch, chunk = 32768, 512     # bench.py defaults
     # 1. per-kernel durations of the default command + the bench line under the profiler
     d = os.path.join(out, "raw_stats")
     shutil.rmtree(d, ignore_errors=True)
